@@ -1,0 +1,188 @@
+/*
+ * spiral_hip.h -- C ABI of libspiral_hip.so: the MI355X (gfx950) implementation of the Spiral PIR
+ * server answer path of blyssprivacy/sdk `lib/spiral-rs` (feature `server`).
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface it replaces
+ * (file:line under /root/reference/lib/spiral-rs/src/).  Plain pointers and sizes only; all
+ * multi-byte data is little-endian / native-endian exactly as the reference's `to_ne_bytes`
+ * wire formats on x86-64 (client.rs:58,77,292; util.rs:294-319).
+ *
+ * Conventions
+ *   - Opaque handles, freed by the matching *_free.  The library never frees caller memory.
+ *   - Functions returning `int` return SP_OK (0) or a negative SP_E_* code; the message is in
+ *     sp_last_error() (thread-local).  Nothing panics/aborts across the ABI; a Rust shim turns a
+ *     non-zero status into the `panic!`/`assert!` the reference would have raised
+ *     (client.rs:213,304; server.rs:131-132,434-439).
+ *   - "ref layout": PolyMatrixRaw = rows*cols*N u64 (poly.rs:31-35,92-94); PolyMatrixNTT =
+ *     rows*cols*crt_count*N u64, each < moduli[crt] (poly.rs:263-265).  N = poly_len = 2048,
+ *     crt_count = 2, moduli {268369921, 249561089} (util.rs:245-248).
+ *   - Every compute entry point runs on the HIP device; there is no CPU fallback.  If no gfx950
+ *     device is usable the call fails with SP_E_HIP.
+ *   - Handles are immutable after creation and may be shared by host threads; each call takes a
+ *     private workspace + HIP stream from an internal pool.
+ */
+#ifndef SPIRAL_HIP_H
+#define SPIRAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SP_OK 0
+#define SP_E_ARG (-1)    /* bad argument / length mismatch (reference: assert_eq! on sizes) */
+#define SP_E_HIP (-2)    /* HIP runtime error or no device */
+#define SP_E_OOM (-3)    /* device or host allocation failed */
+#define SP_E_STATE (-4)  /* call sequence error */
+
+typedef struct sp_params sp_params_t; /* spiral_rs::params::Params           params.rs:49-82   */
+typedef struct sp_pp sp_pp_t;         /* spiral_rs::client::PublicParameters client.rs:146-152 */
+typedef struct sp_db sp_db_t;         /* the `db: &[u64]` argument of process_query, device-resident */
+typedef struct sp_query sp_query_t;   /* one in-flight query (expanded), for the multi-GPU split */
+
+const char* sp_last_error(void);
+/* Number of visible HIP devices (0 if none); selects `device` for this thread's subsequent calls. */
+int sp_device_count(void);
+int sp_set_device(int device);
+
+/* ------------------------------------------------------------------ Params
+ * util.rs:219-263 params_from_json(): keys n, nu_1, nu_2, p, q2_bits, t_gsw, t_conv, t_exp_left,
+ * t_exp_right, instances, db_item_size, version; presence of "direct_upload" disables query
+ * expansion.  Single or double quotes are accepted (the reference's presets use single quotes and
+ * `.replace("'", "\"")`, util.rs:104-120). */
+sp_params_t* sp_params_from_json(const char* json);
+void sp_params_free(sp_params_t*);
+/* Field / derived-size accessor: poly_len, crt_count, modulus, moduli0, moduli1, n, pt_modulus,
+ * q2_bits, t_conv, t_exp_left, t_exp_right, t_gsw, expand_queries, db_dim_1, db_dim_2, instances,
+ * db_item_size, version, g (params.rs:129), stop_round (:134), setup_bytes (:146), query_bytes
+ * (:169), num_items (:120), db_words (instances*n*n*num_items*N), response_bytes
+ * (server.rs:476-480).  Returns UINT64_MAX for an unknown name. */
+uint64_t sp_params_get(const sp_params_t*, const char* name);
+/* ntt_tables[crt][which][0..N) (params.rs:85-96, ntt.rs:39-65); which: 0 fwd, 1 fwd', 2 inv, 3 inv' */
+int sp_params_ntt_table(const sp_params_t*, int crt, int which, uint64_t* out_n);
+
+/* --------------------------------------------------------------------- DB
+ * The reference passes the whole preprocessed database as `db: &[u64]` on every call
+ * (server.rs:650-655) in the layout [instance][trial][z][ii][j], word = lo28 | hi28 << 32
+ * (server.rs:262-270).  A per-call host pointer cannot be streamed at HBM rate, so residency is the
+ * one deliberate API change: register once, query many times.
+ * Row sharding (multi-GPU): shard `s` of `S` holds first-dimension rows j in [s*dim0/S, (s+1)*dim0/S). */
+sp_db_t* sp_db_create(const sp_params_t*, int shard, int num_shards);
+void sp_db_free(sp_db_t*);
+/* Upload (a z-range of) one (instance,trial) plane given in the reference layout [z][ii][j] with
+ * the FULL dim0 rows per (z,ii); the shard keeps only its rows.  `words` points at row z0.
+ * Equivalent of handing generate_random_db_and_get_item / load_db_from_seek /
+ * load_preprocessed_db_from_file output (server.rs:223-275, 320-386) to process_query. */
+int sp_db_load_plane(sp_db_t*, int plane, int z0, int nz, const uint64_t* words);
+/* Whole database in one call: `words` = instances*n*n*N*num_per*dim0 u64 in the reference layout. */
+int sp_db_load(sp_db_t*, const uint64_t* words, size_t n_words);
+/* Synthetic benchmark database generated on the device: reference-layout word index i holds
+ * sp_synth_word(seed, i).  (Roofline runs at sizes no host buffer can hold.) */
+int sp_db_fill_synthetic(sp_db_t*, uint64_t seed);
+uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index);
+/* Read back words of the reference-layout view (debug / tests): plane, z, ii, j0..j0+count within the shard's rows */
+int sp_db_read_ref(const sp_db_t*, int plane, int z, int ii, int j0, int count, uint64_t* out);
+size_t sp_db_device_bytes(const sp_db_t*);
+
+/* ------------------------------------------------------- PublicParameters
+ * client.rs:212-259 PublicParameters::deserialize(params, data): 32-byte seed, row 0 of every
+ * matrix regenerated as Q - (ChaCha20Rng(seed).gen::<u64>() % Q) (client.rs:47-49, 68-75), other
+ * rows read as LE u64, everything NTT'd and kept device-resident.  len must equal setup_bytes. */
+sp_pp_t* sp_pp_deserialize(const sp_params_t*, const uint8_t* data, size_t len);
+void sp_pp_free(sp_pp_t*);
+/* NTT-form matrices in wire order, ref layout (tests): v_packing[n], v_expansion_left[g],
+ * v_expansion_right[stop_round+1] (if present on the wire), v_conversion[1]. */
+int sp_pp_export(const sp_pp_t*, uint64_t* out, size_t cap_words, size_t* n_words);
+
+/* ---------------------------------------------------------- process_query
+ * server.rs:650-741 process_query(params, public_params, query, db) -> Vec<u8>, with
+ * Query::deserialize (client.rs:303-329) folded in.  `query` is the 32-byte seed followed by the
+ * serialized query body (query_bytes long).  Requires a db created with num_shards == 1.
+ * out must hold response_bytes. */
+int sp_process_query(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
+                     const sp_db_t*, uint8_t* out, size_t out_cap, size_t* out_len);
+/* Same, B queries against one database pass each (sequentially pipelined on one stream). */
+int sp_process_query_batch(const sp_params_t*, const sp_pp_t* const* pps, const uint8_t* const* queries,
+                           const size_t* query_lens, int batch, const sp_db_t*, uint8_t* out,
+                           size_t out_stride, size_t* out_len);
+
+/* Multi-GPU split of process_query around the one exchange step (sum of per-shard partial
+ * first-dimension outputs):
+ *   begin  : Query::deserialize + expand_query + get_v_folding_neg     (server.rs:664-680)
+ *   sweep  : multiply_reg_by_database over this shard's rows             (server.rs:698-705)
+ *            -> partial residues (u32, < q) at sp_query_partial_ptr(), layout
+ *               [plane][r][crt][z][ii], sp_query_partial_words() u32 words; DEVICE memory
+ *   ...    : caller sums the partial buffers of all shards element-wise (RCCL ncclSum on u32;
+ *            8 shards * (q-1) < 2^31) and, on the rank that finishes, writes the sum back.
+ *   finish : % q, from_ntt, fold_ciphertexts, pack, encode                (server.rs:707-740)
+ * All three enqueue on the query's HIP stream; sp_query_sync() waits for it. */
+sp_query_t* sp_query_begin(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len);
+int sp_query_sweep(sp_query_t*, const sp_db_t*);
+void* sp_query_partial_ptr(sp_query_t*);
+size_t sp_query_partial_words(const sp_query_t*);
+int sp_query_sync(sp_query_t*);
+int sp_query_finish(sp_query_t*, uint8_t* out, size_t out_cap, size_t* out_len);
+void sp_query_free(sp_query_t*);
+/* HIP stream (hipStream_t) the query's work is enqueued on -- for event timing by the caller. */
+void* sp_query_stream(sp_query_t*);
+/* Stage timings of the last finish()ed query in milliseconds (HIP events on the query stream):
+ * [0] expand+conversion+folding_neg, [1] db sweep, [2] from_ntt+fold, [3] pack+encode(+D2H). */
+int sp_query_timings(const sp_query_t*, float* ms4);
+
+/* Stand-alone timed sweep for the roofline measurement: runs the db-sweep kernel `iters` times over
+ * `db` with the query slice of `q`, HIP events on the launch stream around the whole batch; returns
+ * average milliseconds per launch in *ms_per_launch. */
+int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch);
+
+/* ------------------------------------------------------------ stage level
+ * 1:1 with the reference's pub functions, operating on caller-owned host arrays in ref layout.
+ * These exist for parity tests and for callers (lib/server) that drive stages themselves. */
+
+/* ntt.rs:67-113 / 212-258: in-place forward / inverse negacyclic NTT of `count` polys (crt*N each) */
+int sp_ntt_forward(const sp_params_t*, uint64_t* data, size_t count);
+int sp_ntt_inverse(const sp_params_t*, uint64_t* data, size_t count);
+/* poly.rs:613-638 to_ntt / to_ntt_no_reduce: raw[count][N] -> ntt[count][crt*N] */
+int sp_to_ntt(const sp_params_t*, const uint64_t* raw, uint64_t* out, size_t count);
+/* poly.rs:646-663 from_ntt: ntt[count][crt*N] -> raw[count][N] (iNTT + CRT compose, params.rs:207-214) */
+int sp_from_ntt(const sp_params_t*, const uint64_t* ntt, uint64_t* out, size_t count);
+/* poly.rs:437-458 multiply: res[ar x bc] = a[ar x ac] * b[ac x bc] (NTT form) */
+int sp_multiply(const sp_params_t*, const uint64_t* a, size_t ar, size_t ac, const uint64_t* b, size_t bc,
+                uint64_t* res);
+/* poly.rs:539-551 automorph on `count` raw polys (x -> x^t, sign flip Q - a, Q for a == 0) */
+int sp_automorph(const sp_params_t*, const uint64_t* a, size_t count, size_t t, uint64_t* res);
+/* gadget.rs:34-60 gadget_invert_rdim followed by to_ntt_no_reduce is what the pipeline uses; this
+ * export returns the raw digits: inp[rows_in x cols] -> out[rows_out x cols] */
+int sp_gadget_invert_rdim(const sp_params_t*, const uint64_t* inp, size_t rows_in, size_t cols, uint64_t* out,
+                          size_t rows_out, size_t rdim);
+/* util.rs:323-355 reorient_reg_ciphertexts: v_reg[dim0] 2x1 NTT -> out[N*dim0*2] packed lo|hi<<32 */
+int sp_reorient_reg_ciphertexts(const sp_params_t*, const uint64_t* v_reg, uint64_t* out);
+/* server.rs:155-221 multiply_reg_by_database: db = one plane [N][num_per][dim0] (ref layout),
+ * v_firstdim = [N][dim0][2]; out = num_per 2x1 NTT cts (ref layout, out[i].data[r*2N + crt*N + z]) */
+int sp_multiply_reg_by_database(const sp_params_t*, const uint64_t* db, const uint64_t* v_firstdim, size_t dim0,
+                                size_t num_per, uint64_t* out);
+/* server.rs:19-121 coefficient_expansion on v[2^g] 2x1 NTT cts in place (v_w_* from pp; v_neg1 internal) */
+int sp_coefficient_expansion(const sp_params_t*, const sp_pp_t*, uint64_t* v, size_t g, size_t stop_round,
+                             size_t max_bits_to_gen_right);
+/* server.rs:123-151 regev_to_gsw (idx_factor 1, idx_offset 0): v_inp[t_gsw*num_gsw] 2x1 NTT ->
+ * v_gsw[num_gsw] 2 x 2t_gsw NTT, V = pp.v_conversion[0] */
+int sp_regev_to_gsw(const sp_params_t*, const sp_pp_t*, const uint64_t* v_inp, uint64_t* v_gsw, size_t num_gsw);
+/* server.rs:505-523 get_v_folding_neg: v_folding[nu_2] 2 x 2t_gsw NTT -> same shape */
+int sp_get_v_folding_neg(const sp_params_t*, const uint64_t* v_folding, uint64_t* out);
+/* server.rs:525-591 expand_query: v_reg_reoriented[N*dim0*2], v_folding[nu_2] 2 x 2t_gsw NTT */
+int sp_expand_query(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
+                    uint64_t* v_reg_reoriented, uint64_t* v_folding);
+/* server.rs:388-427 fold_ciphertexts: cts[num_per] raw 2x1 in/out (result in cts[0]; the other
+ * entries are scratch in the reference too and are returned unmodified here) */
+int sp_fold_ciphertexts(const sp_params_t*, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
+                        const uint64_t* v_folding_neg);
+/* server.rs:429-468 pack: v_ct[n*n] raw 2x1, v_w = pp.v_packing -> (n+1) x n NTT */
+int sp_pack(const sp_params_t*, const sp_pp_t*, const uint64_t* v_ct, uint64_t* out);
+/* server.rs:470-503 encode: v_packed[instances] raw (n+1) x n -> response bytes */
+int sp_encode(const sp_params_t*, const uint64_t* v_packed, uint8_t* out, size_t out_cap, size_t* out_len);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPIRAL_HIP_H */

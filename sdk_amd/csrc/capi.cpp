@@ -1,0 +1,792 @@
+// extern "C" surface of libspiral_hip.so (include/spiral_hip.h).
+#include <cstring>
+#include <new>
+
+#include "../../include/spiral_hip.h"
+#include "pipeline.hpp"
+
+using namespace spiral;
+
+static thread_local std::string g_last_error;
+
+template <typename F>
+static int guarded(F&& f) {
+  try {
+    f();
+    return SP_OK;
+  } catch (const ArgError& e) {
+    g_last_error = e.what();
+    return SP_E_ARG;
+  } catch (const OomError& e) {
+    g_last_error = e.what();
+    return SP_E_OOM;
+  } catch (const HipError& e) {
+    g_last_error = e.what();
+    return SP_E_HIP;
+  } catch (const std::bad_alloc&) {
+    g_last_error = "host allocation failed";
+    return SP_E_OOM;
+  } catch (const std::exception& e) {
+    g_last_error = e.what();
+    return SP_E_ARG;
+  }
+}
+
+struct sp_query {
+  sp_params* params = nullptr;
+  const sp_pp* pp = nullptr;
+  std::unique_ptr<Workspace> ws;
+  int state = 0;  // 1 begun, 2 swept, 3 finished
+  float ms[4] = {0, 0, 0, 0};
+  ~sp_query() {
+    if (ws && params) {
+      (void)hipStreamSynchronize(ws->stream);
+      params->release_ws(std::move(ws));
+    }
+  }
+};
+
+namespace {
+
+struct Scoped {  // a workspace borrowed for one stage-level call
+  sp_params* P;
+  std::unique_ptr<Workspace> ws;
+  explicit Scoped(const sp_params* p) : P(const_cast<sp_params*>(p)), ws(P->acquire_ws()) {}
+  ~Scoped() {
+    (void)hipStreamSynchronize(ws->stream);
+    P->release_ws(std::move(ws));
+  }
+  Workspace& operator*() { return *ws; }
+  Workspace* operator->() { return ws.get(); }
+};
+
+void need(bool c, const char* msg) {
+  if (!c) throw ArgError(msg);
+}
+
+// host u64 NTT words -> device u32
+void upload_ntt(Workspace& W, const uint64_t* host, size_t words, DevBuf<u32>& dst, DevBuf<u64>& tmp) {
+  tmp.ensure(words);
+  dst.ensure(words);
+  HIP_CHECK(hipMemcpyAsync(tmp.p, host, words * 8, hipMemcpyHostToDevice, W.stream));
+  launch_u64_to_u32(dst.p, tmp.p, (long)words, W.stream);
+}
+void download_ntt(Workspace& W, const u32* src, size_t words, uint64_t* host, DevBuf<u64>& tmp) {
+  tmp.ensure(words);
+  launch_u32_to_u64(tmp.p, src, (long)words, W.stream);
+  HIP_CHECK(hipMemcpyAsync(host, tmp.p, words * 8, hipMemcpyDeviceToHost, W.stream));
+  HIP_CHECK(hipStreamSynchronize(W.stream));
+}
+void upload_raw(Workspace& W, const uint64_t* host, size_t words, DevBuf<u64>& dst) {
+  dst.ensure(words);
+  HIP_CHECK(hipMemcpyAsync(dst.p, host, words * 8, hipMemcpyHostToDevice, W.stream));
+}
+void download_raw(Workspace& W, const u64* src, size_t words, uint64_t* host) {
+  HIP_CHECK(hipMemcpyAsync(host, src, words * 8, hipMemcpyDeviceToHost, W.stream));
+  HIP_CHECK(hipStreamSynchronize(W.stream));
+}
+
+void check_device(int dev) {
+  int cur = 0;
+  HIP_CHECK(hipGetDevice(&cur));
+  if (cur != dev) throw ArgError("handle belongs to HIP device " + std::to_string(dev) + " but the current device is " + std::to_string(cur));
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* sp_last_error(void) { return g_last_error.c_str(); }
+
+int sp_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) {
+    (void)hipGetLastError();
+    return 0;
+  }
+  return n;
+}
+int sp_set_device(int device) {
+  return guarded([&] { HIP_CHECK(hipSetDevice(device)); });
+}
+
+// ------------------------------------------------------------------------------------ Params
+sp_params_t* sp_params_from_json(const char* json) {
+  sp_params_t* out = nullptr;
+  int rc = guarded([&] {
+    need(json != nullptr, "json is null");
+    auto h = std::make_unique<sp_params>();
+    h->p = Params::from_json(json);
+    out = h.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+void sp_params_free(sp_params_t* p) { delete p; }
+
+uint64_t sp_params_get(const sp_params_t* h, const char* name) {
+  if (!h || !name) return UINT64_MAX;
+  const Params& p = h->p;
+  std::string s(name);
+  if (s == "poly_len") return p.poly_len;
+  if (s == "poly_len_log2") return p.poly_len_log2;
+  if (s == "crt_count") return p.crt_count;
+  if (s == "modulus") return p.modulus;
+  if (s == "modulus_log2") return p.modulus_log2;
+  if (s == "moduli0") return p.moduli[0];
+  if (s == "moduli1") return p.moduli[1];
+  if (s == "n") return p.n;
+  if (s == "pt_modulus") return p.pt_modulus;
+  if (s == "q2_bits") return p.q2_bits;
+  if (s == "t_conv") return p.t_conv;
+  if (s == "t_exp_left") return p.t_exp_left;
+  if (s == "t_exp_right") return p.t_exp_right;
+  if (s == "t_gsw") return p.t_gsw;
+  if (s == "expand_queries") return p.expand_queries;
+  if (s == "db_dim_1") return p.db_dim_1;
+  if (s == "db_dim_2") return p.db_dim_2;
+  if (s == "instances") return p.instances;
+  if (s == "db_item_size") return p.db_item_size;
+  if (s == "version") return p.version;
+  if (s == "g") return p.g();
+  if (s == "stop_round") return p.stop_round();
+  if (s == "setup_bytes") return p.setup_bytes();
+  if (s == "query_bytes") return p.query_bytes();
+  if (s == "num_items") return p.num_items();
+  if (s == "db_words") return p.db_words();
+  if (s == "response_bytes") return p.response_bytes();
+  return UINT64_MAX;
+}
+
+int sp_params_ntt_table(const sp_params_t* h, int crt, int which, uint64_t* out_n) {
+  return guarded([&] {
+    need(h && out_n && crt >= 0 && crt < 2 && which >= 0 && which < 4, "bad table selector");
+    const u32* t = h->p.table(crt, which);
+    for (size_t i = 0; i < POLY_LEN; i++) out_n[i] = t[i];
+  });
+}
+
+// ---------------------------------------------------------------------------------------- DB
+sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) {
+  sp_db_t* out = nullptr;
+  int rc = guarded([&] {
+    need(h != nullptr, "params is null");
+    const Params& p = h->p;
+    need(num_shards >= 1 && shard >= 0 && shard < num_shards, "bad shard");
+    need(p.dim0() % (size_t)num_shards == 0, "dim0 not divisible by num_shards");
+    auto d = std::make_unique<sp_db>();
+    d->params = h;
+    HIP_CHECK(hipGetDevice(&d->device));
+    d->shard = shard;
+    d->num_shards = num_shards;
+    d->nj = (int)(p.dim0() / num_shards);
+    d->j0 = shard * d->nj;
+    d->words.alloc(p.planes() * POLY_LEN * (size_t)d->nj * p.num_per());
+    const_cast<sp_params*>(h)->device_state();
+    out = d.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+void sp_db_free(sp_db_t* d) { delete d; }
+size_t sp_db_device_bytes(const sp_db_t* d) { return d ? d->words.bytes() : 0; }
+
+int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* words) {
+  return guarded([&] {
+    need(d && words, "null argument");
+    const Params& p = d->params->p;
+    need(plane >= 0 && (size_t)plane < p.planes() && z0 >= 0 && nz >= 0 && (size_t)(z0 + nz) <= POLY_LEN, "bad plane / z range");
+    check_device(d->device);
+    std::lock_guard<std::mutex> lk(d->mu);
+    const size_t row_words = p.num_per() * p.dim0();
+    const size_t max_stage = ((size_t)64 << 20) / 8;  // 64 MiB staging
+    const int zs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, max_stage / row_words));
+    DevBuf<u64> stage((size_t)zs * row_words);
+    u64* plane_base = d->words.p + (size_t)plane * POLY_LEN * d->nj * p.num_per();
+    for (int z = 0; z < nz; z += zs) {
+      const int cnt = std::min(zs, nz - z);
+      HIP_CHECK(hipMemcpy(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8, hipMemcpyHostToDevice));
+      launch_db_relayout(plane_base, stage.p, z0 + z, cnt, (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, 0);
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+  });
+}
+
+int sp_db_load(sp_db_t* d, const uint64_t* words, size_t n_words) {
+  if (!d || !words) {
+    g_last_error = "null argument";
+    return SP_E_ARG;
+  }
+  const Params& p = d->params->p;
+  if (n_words != p.db_words()) {
+    g_last_error = "db word count " + std::to_string(n_words) + " != " + std::to_string(p.db_words());
+    return SP_E_ARG;
+  }
+  const size_t plane_words = POLY_LEN * p.num_items();
+  for (size_t pl = 0; pl < p.planes(); pl++) {
+    int rc = sp_db_load_plane(d, (int)pl, 0, (int)POLY_LEN, words + pl * plane_words);
+    if (rc != SP_OK) return rc;
+  }
+  return SP_OK;
+}
+
+int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
+  return guarded([&] {
+    need(d != nullptr, "null db");
+    check_device(d->device);
+    const Params& p = d->params->p;
+    launch_db_synth(d->words.p, seed, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index) { return synth_word(seed, ref_index); }
+
+int sp_db_read_ref(const sp_db_t* d, int plane, int z, int ii, int j0, int count, uint64_t* out) {
+  return guarded([&] {
+    need(d && out, "null argument");
+    const Params& p = d->params->p;
+    need(plane >= 0 && (size_t)plane < p.planes() && z >= 0 && z < N && ii >= 0 && (size_t)ii < p.num_per() && j0 >= 0 &&
+             count >= 0 && j0 + count <= d->nj, "bad coordinates");
+    check_device(d->device);
+    const u64* base = d->words.p + (((size_t)plane * POLY_LEN + z) * d->nj + j0) * p.num_per() + ii;
+    HIP_CHECK(hipMemcpy2D(out, 8, base, p.num_per() * 8, 8, (size_t)count, hipMemcpyDeviceToHost));
+  });
+}
+
+// ------------------------------------------------------------------------- PublicParameters
+sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len) {
+  sp_pp_t* out = nullptr;
+  int rc = guarded([&] {
+    need(h && data, "null argument");
+    const Params& p = h->p;
+    if (len != p.setup_bytes()) throw ArgError("public parameter length " + std::to_string(len) + " != setup_bytes " + std::to_string(p.setup_bytes()));
+    DeviceState& D = const_cast<sp_params*>(h)->device_state();
+    auto pp = std::make_unique<sp_pp>();
+    pp->params = h;
+    pp->device = D.device;
+    struct Mat { size_t count, rows, cols; };
+    std::vector<Mat> mats;
+    mats.push_back({p.n, p.n + 1, p.t_conv});  // client.rs:221
+    size_t off = p.n * (p.n + 1) * p.t_conv;
+    pp->off_packing = 0;
+    if (p.expand_queries) {
+      pp->off_left = off;
+      mats.push_back({p.g(), 2, p.t_exp_left});
+      off += p.g() * 2 * p.t_exp_left;
+      pp->has_right = p.has_expansion_right_on_wire();
+      if (pp->has_right) {
+        pp->off_right = off;
+        mats.push_back({p.stop_round() + 1, 2, p.t_exp_right});
+        off += (p.stop_round() + 1) * 2 * p.t_exp_right;
+      } else {
+        pp->off_right = pp->off_left;
+      }
+      pp->off_conv = off;
+      mats.push_back({1, 2, 2 * p.t_conv});
+      off += 2 * 2 * p.t_conv;
+    }
+    pp->n_polys = off;
+    // host raw image: row 0 of every matrix from the seed stream, the rest from the wire
+    size_t rng_words = 0;
+    for (auto& m : mats) rng_words += m.count * m.cols * POLY_LEN;
+    std::vector<u64> ks(rng_words);
+    chacha20_keystream_u64(data, ks.data(), rng_words);
+    std::vector<u64> raw(off * POLY_LEN);
+    size_t kpos = 0, wpos = SEED_LENGTH, ppos = 0;
+    for (auto& m : mats)
+      for (size_t i = 0; i < m.count; i++) {
+        u64* dst = raw.data() + ppos * POLY_LEN;
+        const size_t first = m.cols * POLY_LEN;
+        for (size_t k = 0; k < first; k++) dst[k] = p.modulus - (ks[kpos + k] % p.modulus);  // client.rs:47-49
+        kpos += first;
+        const size_t rest = (m.rows - 1) * m.cols * POLY_LEN;
+        memcpy(dst + first, data + wpos, rest * 8);
+        wpos += rest * 8;
+        ppos += m.rows * m.cols;
+      }
+    need(wpos == len && ppos == off, "internal: pp layout mismatch");
+    DevBuf<u64> d_raw(raw.size());
+    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    pp->all.alloc(off * 2 * POLY_LEN);
+    FwdDesc f{d_raw.p, nullptr, pp->all.p, (int)off, 1, 1, 1, 64, 1, 0, 1};  // to_ntt_alloc (client.rs:244-247)
+    launch_ntt_fwd(D.T, f, 0);
+    // [W_0 | W_1 | ...] for pack (server.rs:450-463)
+    const size_t n = p.n, tc = p.t_conv;
+    pp->pack_cat.alloc((n + 1) * n * tc * 2 * POLY_LEN);
+    for (size_t rr = 0; rr < n + 1; rr++)
+      for (size_t r = 0; r < n; r++)
+        HIP_CHECK(hipMemcpyAsync(pp->pack_cat.p + (rr * n * tc + r * tc) * 2 * POLY_LEN,
+                                 pp->all.p + (pp->off_packing + r * (n + 1) * tc + rr * tc) * 2 * POLY_LEN,
+                                 tc * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, 0));
+    HIP_CHECK(hipDeviceSynchronize());
+    out = pp.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+void sp_pp_free(sp_pp_t* p) { delete p; }
+
+int sp_pp_export(const sp_pp_t* pp, uint64_t* out, size_t cap_words, size_t* n_words) {
+  return guarded([&] {
+    need(pp && out && n_words, "null argument");
+    check_device(pp->device);
+    const size_t words = pp->n_polys * 2 * POLY_LEN;
+    *n_words = words;
+    need(cap_words >= words, "output too small");
+    Scoped W(pp->params);
+    DevBuf<u64> tmp;
+    download_ntt(*W, pp->all.p, words, out, tmp);
+  });
+}
+
+// ------------------------------------------------------------------------------ process_query
+sp_query_t* sp_query_begin(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len) {
+  sp_query_t* out = nullptr;
+  int rc = guarded([&] {
+    need(h && pp && query, "null argument");
+    need(pp->params == h, "public parameters were created for different params");
+    check_device(pp->device);
+    auto q = std::make_unique<sp_query>();
+    q->params = const_cast<sp_params*>(h);
+    q->pp = pp;
+    q->ws = q->params->acquire_ws();
+    Workspace& W = *q->ws;
+    HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
+    run_begin(W, *pp, query, query_len);
+    HIP_CHECK(hipEventRecord(W.ev[1], W.stream));
+    q->state = 1;
+    out = q.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+
+int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
+  return guarded([&] {
+    need(q && db, "null argument");
+    need(q->state == 1, "sp_query_sweep: query not in 'begun' state");
+    need(db->params == q->params, "db was created for different params");
+    check_device(db->device);
+    Workspace& W = *q->ws;
+    run_sweep(W, *db);
+    HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
+    q->state = 2;
+  });
+}
+
+void* sp_query_partial_ptr(sp_query_t* q) { return q && q->ws ? (void*)q->ws->sweep_out.p : nullptr; }
+size_t sp_query_partial_words(const sp_query_t* q) {
+  if (!q) return 0;
+  const Params& p = q->params->p;
+  return p.planes() * 4 * POLY_LEN * p.num_per();
+}
+void* sp_query_stream(sp_query_t* q) { return q && q->ws ? (void*)q->ws->stream : nullptr; }
+
+int sp_query_sync(sp_query_t* q) {
+  return guarded([&] {
+    need(q && q->ws, "null query");
+    HIP_CHECK(hipStreamSynchronize(q->ws->stream));
+  });
+}
+
+static void finish_impl(sp_query_t* q, bool premod, uint8_t* out, size_t out_cap, size_t* out_len) {
+  need(q && out && out_len, "null argument");
+  need(q->state == 2, "sp_query_finish: sweep has not run");
+  const Params& p = q->params->p;
+  need(out_cap >= p.response_bytes(), "output buffer smaller than response_bytes");
+  Workspace& W = *q->ws;
+  run_finish(W, *q->pp, premod);
+  HIP_CHECK(hipStreamSynchronize(W.stream));
+  *out_len = encode_response(p, W.h_packed, out);
+  float t = 0;
+  HIP_CHECK(hipEventElapsedTime(&t, W.ev[0], W.ev[1]));
+  q->ms[0] = t;
+  HIP_CHECK(hipEventElapsedTime(&t, W.ev[1], W.ev[2]));
+  q->ms[1] = t;
+  HIP_CHECK(hipEventElapsedTime(&t, W.ev[2], W.ev[3]));
+  q->ms[2] = t;
+  HIP_CHECK(hipEventElapsedTime(&t, W.ev[3], W.ev[4]));
+  q->ms[3] = t;
+  q->state = 3;
+}
+
+int sp_query_finish(sp_query_t* q, uint8_t* out, size_t out_cap, size_t* out_len) {
+  // premod: the partial buffer may hold a sum of up to 8 residues (multi-GPU); % q is the identity otherwise
+  return guarded([&] { finish_impl(q, true, out, out_cap, out_len); });
+}
+
+int sp_query_timings(const sp_query_t* q, float* ms4) {
+  if (!q || !ms4 || q->state != 3) {
+    g_last_error = "timings are available after sp_query_finish";
+    return SP_E_STATE;
+  }
+  memcpy(ms4, q->ms, sizeof(q->ms));
+  return SP_OK;
+}
+void sp_query_free(sp_query_t* q) { delete q; }
+
+int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
+                     const sp_db_t* db, uint8_t* out, size_t out_cap, size_t* out_len) {
+  if (db && db->num_shards != 1) {
+    g_last_error = "sp_process_query needs an unsharded db; use sp_query_begin/sweep/finish for row shards";
+    return SP_E_ARG;
+  }
+  sp_query_t* q = sp_query_begin(h, pp, query, query_len);
+  if (!q) return g_last_error.find("hip") != std::string::npos ? SP_E_HIP : SP_E_ARG;
+  int rc = sp_query_sweep(q, db);
+  if (rc == SP_OK) rc = guarded([&] { finish_impl(q, false, out, out_cap, out_len); });
+  sp_query_free(q);
+  return rc;
+}
+
+int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, const uint8_t* const* queries,
+                           const size_t* query_lens, int batch, const sp_db_t* db, uint8_t* out, size_t out_stride,
+                           size_t* out_len) {
+  if (!pps || !queries || !query_lens || batch < 0) {
+    g_last_error = "null argument";
+    return SP_E_ARG;
+  }
+  for (int i = 0; i < batch; i++) {
+    int rc = sp_process_query(h, pps[i], queries[i], query_lens[i], db, out + (size_t)i * out_stride, out_stride, out_len);
+    if (rc != SP_OK) return rc;
+  }
+  return SP_OK;
+}
+
+int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch) {
+  return guarded([&] {
+    need(q && db && ms_per_launch && iters > 0, "bad argument");
+    need(q->state >= 1, "query not begun");
+    check_device(db->device);
+    Workspace& W = *q->ws;
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    run_sweep(W, *db);  // warm
+    HIP_CHECK(hipEventRecord(a, W.stream));
+    for (int i = 0; i < iters; i++) run_sweep(W, *db);
+    HIP_CHECK(hipEventRecord(b, W.stream));
+    HIP_CHECK(hipStreamSynchronize(W.stream));
+    float t = 0;
+    HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    *ms_per_launch = t / iters;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  });
+}
+
+// ------------------------------------------------------------------------------- stage level
+int sp_to_ntt(const sp_params_t* h, const uint64_t* raw, uint64_t* out, size_t count) {
+  return guarded([&] {
+    need(h && raw && out, "null argument");
+    if (count == 0) return;
+    Scoped W(h);
+    DevBuf<u64> d_raw, tmp;
+    DevBuf<u32> d_ntt(count * 2 * POLY_LEN);
+    upload_raw(*W, raw, count * POLY_LEN, d_raw);
+    FwdDesc f{d_raw.p, nullptr, d_ntt.p, (int)count, 1, 1, 1, 64, 1, 0, 1};
+    launch_ntt_fwd(W->D->T, f, W->stream);
+    download_ntt(*W, d_ntt.p, count * 2 * POLY_LEN, out, tmp);
+  });
+}
+
+int sp_from_ntt(const sp_params_t* h, const uint64_t* ntt, uint64_t* out, size_t count) {
+  return guarded([&] {
+    need(h && ntt && out, "null argument");
+    if (count == 0) return;
+    Scoped W(h);
+    DevBuf<u64> tmp, d_raw(count * POLY_LEN);
+    DevBuf<u32> d_ntt;
+    upload_ntt(*W, ntt, count * 2 * POLY_LEN, d_ntt, tmp);
+    InvDesc inv{};
+    inv.src = d_ntt.p;
+    inv.poly_stride = 2 * POLY_LEN;
+    inv.crt_stride = POLY_LEN;
+    inv.z_stride = 1;
+    inv.dst = d_raw.p;
+    inv.n_polys = (int)count;
+    launch_ntt_inv(W->D->T, inv, W->stream);
+    download_raw(*W, d_raw.p, count * POLY_LEN, out);
+  });
+}
+
+int sp_ntt_forward(const sp_params_t* h, uint64_t* data, size_t count) {
+  return guarded([&] {
+    need(h && data, "null argument");
+    if (count == 0) return;
+    // each [crt] half is transformed under its own modulus: run the (value mod q_c -> NTT) kernel on
+    // every half and keep the matching modulus
+    std::vector<u64> full(count * 2 * 2 * POLY_LEN);
+    int rc = sp_to_ntt(h, data, full.data(), count * 2);
+    if (rc != SP_OK) throw HipError(g_last_error);
+    for (size_t i = 0; i < count; i++)
+      for (size_t c = 0; c < 2; c++)
+        memcpy(data + (i * 2 + c) * POLY_LEN, full.data() + ((i * 2 + c) * 2 + c) * POLY_LEN, POLY_LEN * 8);
+  });
+}
+
+int sp_ntt_inverse(const sp_params_t* h, uint64_t* data, size_t count) {
+  return guarded([&] {
+    need(h && data, "null argument");
+    if (count == 0) return;
+    // inverse both residues on the device; the per-modulus outputs are the residues of the composed value
+    std::vector<u64> raw(count * POLY_LEN);
+    int rc = sp_from_ntt(h, data, raw.data(), count);
+    if (rc != SP_OK) throw HipError(g_last_error);
+    for (size_t i = 0; i < count; i++)
+      for (size_t z = 0; z < POLY_LEN; z++) {
+        data[(i * 2 + 0) * POLY_LEN + z] = raw[i * POLY_LEN + z] % h->p.moduli[0];
+        data[(i * 2 + 1) * POLY_LEN + z] = raw[i * POLY_LEN + z] % h->p.moduli[1];
+      }
+  });
+}
+
+int sp_multiply(const sp_params_t* h, const uint64_t* a, size_t ar, size_t ac, const uint64_t* b, size_t bc,
+                uint64_t* res) {
+  return guarded([&] {
+    need(h && a && b && res && ar && ac && bc, "bad argument");
+    Scoped W(h);
+    DevBuf<u64> tmp;
+    DevBuf<u32> dA, dBt, dR(ar * bc * 2 * POLY_LEN);
+    upload_ntt(*W, a, ar * ac * 2 * POLY_LEN, dA, tmp);
+    // B is ac x bc; the MAC kernel wants the K operands of one output column contiguous: transpose on host
+    std::vector<u64> bt(ac * bc * 2 * POLY_LEN);
+    for (size_t k = 0; k < ac; k++)
+      for (size_t j = 0; j < bc; j++)
+        memcpy(bt.data() + (j * ac + k) * 2 * POLY_LEN, b + (k * bc + j) * 2 * POLY_LEN, 2 * POLY_LEN * 8);
+    DevBuf<u64> tmp2;
+    upload_ntt(*W, bt.data(), bt.size(), dBt, tmp2);
+    MacDesc m{};
+    m.A = dA.p;
+    m.B = dBt.p;
+    m.out = dR.p;
+    m.R = (int)ar;
+    m.K = (int)ac;
+    m.batch_inner = (int)bc;
+    m.batch_outer = 1;
+    m.B_inner_stride = (long)ac;
+    m.split_k = (int)ac;
+    m.out_batch_stride = 1;
+    m.out_row_stride = (int)bc;
+    launch_mac(W->D->T, m, W->stream);
+    download_ntt(*W, dR.p, ar * bc * 2 * POLY_LEN, res, tmp);
+  });
+}
+
+int sp_automorph(const sp_params_t* h, const uint64_t* a, size_t count, size_t t, uint64_t* res) {
+  return guarded([&] {
+    need(h && a && res && (t & 1), "bad argument (t must be odd)");
+    if (count == 0) return;
+    Scoped W(h);
+    DevBuf<u64> dA, dR(count * POLY_LEN);
+    upload_raw(*W, a, count * POLY_LEN, dA);
+    launch_automorph(W->D->T, dR.p, dA.p, (int)count, (int)t, W->stream);
+    download_raw(*W, dR.p, count * POLY_LEN, res);
+  });
+}
+
+int sp_gadget_invert_rdim(const sp_params_t* h, const uint64_t* inp, size_t rows_in, size_t cols, uint64_t* out,
+                          size_t rows_out, size_t rdim) {
+  return guarded([&] {
+    need(h && inp && out && rdim && rows_out % rdim == 0 && rdim <= rows_in, "bad argument");
+    Scoped W(h);
+    DevBuf<u64> dI, dO(rows_out * cols * POLY_LEN);
+    upload_raw(*W, inp, rows_in * cols * POLY_LEN, dI);
+    launch_gadget_raw(dO.p, dI.p, (int)rows_in, (int)cols, (int)rows_out, (int)rdim, (int)h->p.bits_per(rows_out / rdim), W->stream);
+    download_raw(*W, dO.p, rows_out * cols * POLY_LEN, out);
+  });
+}
+
+int sp_reorient_reg_ciphertexts(const sp_params_t* h, const uint64_t* v_reg, uint64_t* out) {
+  return guarded([&] {
+    need(h && v_reg && out, "null argument");
+    const Params& p = h->p;
+    Scoped W(h);
+    DevBuf<u64> tmp, dO(POLY_LEN * p.dim0() * 2);
+    DevBuf<u32> dV;
+    upload_ntt(*W, v_reg, p.dim0() * 2 * 2 * POLY_LEN, dV, tmp);
+    launch_reorient(dO.p, dV.p, 0, 1, (int)p.dim0(), W->stream);
+    download_raw(*W, dO.p, POLY_LEN * p.dim0() * 2, out);
+  });
+}
+
+int sp_multiply_reg_by_database(const sp_params_t* h, const uint64_t* db, const uint64_t* v_firstdim, size_t dim0,
+                                size_t num_per, uint64_t* out) {
+  return guarded([&] {
+    need(h && db && v_firstdim && out, "null argument");
+    need(dim0 >= 1 && num_per >= 1 && (num_per & (num_per - 1)) == 0 && num_per <= 65536 && dim0 <= 65536, "bad dimensions");
+    Scoped W(h);
+    const size_t words = POLY_LEN * num_per * dim0;
+    DevBuf<u64> d_ref(words), d_dev(words), d_q, d_out(num_per * 4 * POLY_LEN);
+    DevBuf<u32> d_res(4 * POLY_LEN * num_per);
+    HIP_CHECK(hipMemcpyAsync(d_ref.p, db, words * 8, hipMemcpyHostToDevice, W->stream));
+    launch_db_relayout(d_dev.p, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, W->stream);
+    upload_raw(*W, v_firstdim, POLY_LEN * dim0 * 2, d_q);
+    SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0};
+    launch_sweep(W->D->T, d, W->stream);
+    launch_sweep_out_to_ref(d_out.p, d_res.p, (int)num_per, W->stream);
+    download_raw(*W, d_out.p, num_per * 4 * POLY_LEN, out);
+  });
+}
+
+int sp_coefficient_expansion(const sp_params_t* h, const sp_pp_t* pp, uint64_t* v, size_t g, size_t stop_round,
+                             size_t max_bits_to_gen_right) {
+  return guarded([&] {
+    need(h && pp && v, "null argument");
+    const Params& p = h->p;
+    need(p.expand_queries, "params have no query expansion");
+    // the schedule (pruning) is derived from params exactly as expand_query derives it (server.rs:536-564)
+    const size_t sr = p.db_dim_2 > 0 ? p.stop_round() : 0, mb = p.db_dim_2 > 0 ? p.t_gsw * p.db_dim_2 : 0;
+    need(g == p.g() && stop_round == sr && max_bits_to_gen_right == mb, "g / stop_round / max_bits_to_gen_right must match params");
+    check_device(pp->device);
+    Scoped W(h);
+    W->ensure_expand();
+    const size_t words = ((size_t)1 << g) * 2 * 2 * POLY_LEN;
+    DevBuf<u64> tmp;
+    tmp.ensure(words);
+    HIP_CHECK(hipMemcpyAsync(tmp.p, v, words * 8, hipMemcpyHostToDevice, W->stream));
+    launch_u64_to_u32(W->v.p, tmp.p, (long)words, W->stream);
+    run_coefficient_expansion(*W, *pp, g);
+    download_ntt(*W, W->v.p, words, v, tmp);
+  });
+}
+
+int sp_regev_to_gsw(const sp_params_t* h, const sp_pp_t* pp, const uint64_t* v_inp, uint64_t* v_gsw, size_t num_gsw) {
+  return guarded([&] {
+    need(h && pp && v_inp && v_gsw, "null argument");
+    const Params& p = h->p;
+    need(num_gsw == p.db_dim_2 && num_gsw > 0, "num_gsw must equal nu_2");
+    check_device(pp->device);
+    Scoped W(h);
+    W->ensure_expand();
+    const size_t nb = num_gsw * p.t_gsw;
+    DevBuf<u64> tmp;
+    DevBuf<u32> dV;
+    upload_ntt(*W, v_inp, nb * 2 * 2 * POLY_LEN, dV, tmp);
+    std::vector<int> ct(nb), poly(nb);
+    for (size_t b = 0; b < nb; b++) {
+      ct[b] = (int)b;
+      poly[b] = (int)(2 * b);
+    }
+    DevBuf<int> dl(2 * nb);
+    HIP_CHECK(hipMemcpyAsync(dl.p, ct.data(), nb * sizeof(int), hipMemcpyHostToDevice, W->stream));
+    HIP_CHECK(hipMemcpyAsync(dl.p + nb, poly.data(), nb * sizeof(int), hipMemcpyHostToDevice, W->stream));
+    run_regev_to_gsw(*W, *pp, dV.p, dl.p, dl.p + nb);
+    // gather the right halves (2 x 2t_gsw per GSW ct)
+    const size_t two_t = 2 * p.t_gsw;
+    DevBuf<u32> dense(num_gsw * 2 * two_t * 2 * POLY_LEN);
+    for (size_t d = 0; d < num_gsw; d++)
+      for (size_t r = 0; r < 2; r++)
+        HIP_CHECK(hipMemcpyAsync(dense.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN,
+                                 W->fold_mats.p + ((d * 2 + r) * 2 * two_t + two_t) * 2 * POLY_LEN,
+                                 two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+    download_ntt(*W, dense.p, num_gsw * 2 * two_t * 2 * POLY_LEN, v_gsw, tmp);
+  });
+}
+
+int sp_get_v_folding_neg(const sp_params_t* h, const uint64_t* v_folding, uint64_t* out) {
+  return guarded([&] {
+    need(h && v_folding && out, "null argument");
+    const Params& p = h->p;
+    const size_t nu2 = p.db_dim_2, two_t = 2 * p.t_gsw;
+    if (nu2 == 0) return;
+    Scoped W(h);
+    W->ensure_expand();
+    DevBuf<u64> tmp;
+    DevBuf<u32> dense;
+    upload_ntt(*W, v_folding, nu2 * 2 * two_t * 2 * POLY_LEN, dense, tmp);
+    for (size_t d = 0; d < nu2; d++)
+      for (size_t r = 0; r < 2; r++)
+        HIP_CHECK(hipMemcpyAsync(W->fold_mats.p + ((d * 2 + r) * 2 * two_t + two_t) * 2 * POLY_LEN,
+                                 dense.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32),
+                                 hipMemcpyDeviceToDevice, W->stream));
+    run_folding_neg(*W);
+    for (size_t d = 0; d < nu2; d++)
+      for (size_t r = 0; r < 2; r++)
+        HIP_CHECK(hipMemcpyAsync(dense.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN,
+                                 W->fold_mats.p + ((d * 2 + r) * 2 * two_t) * 2 * POLY_LEN,
+                                 two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+    download_ntt(*W, dense.p, nu2 * 2 * two_t * 2 * POLY_LEN, out, tmp);
+  });
+}
+
+int sp_expand_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
+                    uint64_t* v_reg_reoriented, uint64_t* v_folding) {
+  return guarded([&] {
+    need(h && pp && query && v_reg_reoriented, "null argument");
+    const Params& p = h->p;
+    check_device(pp->device);
+    Scoped W(h);
+    run_begin(*W, *pp, query, query_len);
+    download_raw(*W, W->qv.p, POLY_LEN * p.dim0() * 2, v_reg_reoriented);
+    const size_t nu2 = p.db_dim_2, two_t = 2 * p.t_gsw;
+    if (nu2 > 0) {
+      need(v_folding != nullptr, "v_folding is null");
+      DevBuf<u32> dense(nu2 * 2 * two_t * 2 * POLY_LEN);
+      for (size_t d = 0; d < nu2; d++)
+        for (size_t r = 0; r < 2; r++)
+          HIP_CHECK(hipMemcpyAsync(dense.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN,
+                                   W->fold_mats.p + ((d * 2 + r) * 2 * two_t + two_t) * 2 * POLY_LEN,
+                                   two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+      DevBuf<u64> tmp;
+      download_ntt(*W, dense.p, nu2 * 2 * two_t * 2 * POLY_LEN, v_folding, tmp);
+    }
+  });
+}
+
+int sp_fold_ciphertexts(const sp_params_t* h, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
+                        const uint64_t* v_folding_neg) {
+  return guarded([&] {
+    need(h && cts && v_folding && v_folding_neg, "null argument");
+    const Params& p = h->p;
+    need(num_per >= 1 && (num_per & (num_per - 1)) == 0, "num_per must be a power of two");
+    size_t further = 0;
+    while (((size_t)1 << further) < num_per) further++;
+    if (further == 0) return;
+    need(further <= p.db_dim_2 || true, "");
+    const size_t two_t = 2 * p.t_gsw;
+    Scoped W(h);
+    W->ensure_expand();
+    // workspace sized for params' own num_per; make sure this call's size fits
+    W->foldX.ensure(num_per * 2 * POLY_LEN);
+    W->foldY.ensure(std::max<size_t>(num_per / 2, 1) * 2 * POLY_LEN);
+    W->fold_dig.ensure(num_per * two_t * 2 * POLY_LEN);
+    W->fold_ntt.ensure(std::max<size_t>(num_per / 2, 1) * 2 * 2 * POLY_LEN);
+    W->fold_mats.ensure(further * 2 * 2 * two_t * 2 * POLY_LEN);
+    DevBuf<u64> tmp;
+    DevBuf<u32> dF, dFn;
+    upload_ntt(*W, v_folding, further * 2 * two_t * 2 * POLY_LEN, dF, tmp);
+    DevBuf<u64> tmp2;
+    upload_ntt(*W, v_folding_neg, further * 2 * two_t * 2 * POLY_LEN, dFn, tmp2);
+    for (size_t d = 0; d < further; d++)
+      for (size_t r = 0; r < 2; r++) {
+        u32* row = W->fold_mats.p + ((d * 2 + r) * 2 * two_t) * 2 * POLY_LEN;
+        HIP_CHECK(hipMemcpyAsync(row, dFn.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+        HIP_CHECK(hipMemcpyAsync(row + two_t * 2 * POLY_LEN, dF.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+      }
+    HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
+    u64* res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per);
+    download_raw(*W, res, 2 * POLY_LEN, cts);
+  });
+}
+
+int sp_pack(const sp_params_t* h, const sp_pp_t* pp, const uint64_t* v_ct, uint64_t* out) {
+  return guarded([&] {
+    need(h && pp && v_ct && out, "null argument");
+    const Params& p = h->p;
+    need(p.instances == 1, "sp_pack packs one instance (n*n cts); call per instance");
+    check_device(pp->device);
+    Scoped W(h);
+    W->ensure_finish();
+    HIP_CHECK(hipMemcpyAsync(W->final_cts.p, v_ct, p.n * p.n * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
+    run_pack(*W, *pp);
+    DevBuf<u64> tmp;
+    download_ntt(*W, W->pack_res.p, (p.n + 1) * p.n * 2 * POLY_LEN, out, tmp);
+  });
+}
+
+int sp_encode(const sp_params_t* h, const uint64_t* v_packed, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    need(h && v_packed && out && out_len, "null argument");
+    need(out_cap >= h->p.response_bytes(), "output buffer smaller than response_bytes");
+    *out_len = encode_response(h->p, v_packed, out);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,678 @@
+// gfx950 (MI355X, CDNA4) kernels for the Spiral PIR answer path.  Integer mod-q arithmetic on the
+// vector ALU (u32 mul_lo/mul_hi, v_mad_u64_u32); no MFMA (this is not a floating-point contraction).
+// wave = 64 lanes; 256-thread workgroups unless stated.
+//
+// Reference semantics reproduced here (lib/spiral-rs/src): ntt.rs:67-113, 212-258 (negacyclic NTT,
+// Harvey lazy butterflies), poly.rs:351-663, gadget.rs:34-60, util.rs:323-355, server.rs:155-221.
+// Residues leave every kernel canonical (< q), so all intermediates equal the scalar reference's.
+#include "kernels.hpp"
+
+namespace spiral {
+
+// ------------------------------------------------------------------------------------------------
+// modular helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 reduce64(u64 x, const ModConst m) {
+  // x mod q for any u64 x:  floor(x * floor(2^64/q) / 2^64) is floor(x/q) or one less
+  u64 qe = __umul64hi(x, m.m64);
+  u64 r = x - qe * (u64)m.q;
+  u32 r32 = (u32)r;  // r < 2q < 2^29
+  return r32 >= m.q ? r32 - m.q : r32;
+}
+
+__device__ __forceinline__ u32 add_mod(u32 a, u32 b, u32 q) {
+  u32 s = a + b;
+  return s >= q ? s - q : s;
+}
+
+// Cooley-Tukey butterfly with Shoup quotient (ntt.rs:92-103): x,y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void ct_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u32 q2) {
+  u32 cx = x - (x >= q2 ? q2 : 0u);
+  u32 qt = __umulhi(y, wp);
+  u32 qn = w * y - qt * q;
+  x = cx + qn;
+  y = cx + q2 - qn;
+}
+// Gentleman-Sande butterfly with the 1/2 folded in (ntt.rs:236-249): x,y in [0,2q) -> [0,2q)
+__device__ __forceinline__ void gs_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u32 q2) {
+  u32 tt = q2 - y + x;
+  u32 s = x + y;
+  u32 cx = s - (s >= q2 ? q2 : 0u);
+  u32 ht = __umulhi(tt, wp);
+  x = (cx + ((tt & 1u) ? q : 0u)) >> 1;
+  y = w * tt - ht * q;
+}
+
+// LDS index padding.  PAD_A keeps the {tau+256k}, {256b+o+32k} and {32b+o+4k} access patterns
+// conflict-free for 4-byte accesses; PAD_B does the same for {32b+o+4k} and {8tau+k}.
+#define PAD_A(a) ((a) + (((a) >> 5) << 2))
+#define PAD_B(a) ((a) + ((a) >> 3))
+constexpr int LDS_WORDS = N + N / 8;  // >= max(PAD_A, PAD_B)
+
+// One register pass of the forward transform on the 8 elements {b*8S + o + S*k}: half-distances
+// 4S, 2S, S (stage A is skipped for the final S = 1 pass, where only distances 2 and 1 remain).
+template <int S, bool DO_A>
+__device__ __forceinline__ void fwd_pass(u32 (&v)[8], int b, const u32* __restrict__ fw, const u32* __restrict__ fwp,
+                                         u32 q, u32 q2) {
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ct_bfly(v[k], v[k + 4], w, wp, q, q2);
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int i = N / (4 * S) + 2 * b + h;
+      u32 w = fw[i], wp = fwp[i];
+      ct_bfly(v[4 * h + 0], v[4 * h + 2], w, wp, q, q2);
+      ct_bfly(v[4 * h + 1], v[4 * h + 3], w, wp, q, q2);
+    }
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      int i = N / (2 * S) + 4 * b + h;
+      ct_bfly(v[2 * h], v[2 * h + 1], fw[i], fwp[i], q, q2);
+    }
+  }
+}
+// Inverse: half-distances S, 2S, 4S on the same element set.
+template <int S, bool DO_A>
+__device__ __forceinline__ void inv_pass(u32 (&v)[8], int b, const u32* __restrict__ iw, const u32* __restrict__ iwp,
+                                         u32 q, u32 q2) {
+  {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      int i = N / (2 * S) + 4 * b + h;
+      gs_bfly(v[2 * h], v[2 * h + 1], iw[i], iwp[i], q, q2);
+    }
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int i = N / (4 * S) + 2 * b + h;
+      u32 w = iw[i], wp = iwp[i];
+      gs_bfly(v[4 * h + 0], v[4 * h + 2], w, wp, q, q2);
+      gs_bfly(v[4 * h + 1], v[4 * h + 3], w, wp, q, q2);
+    }
+  }
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) gs_bfly(v[k], v[k + 4], w, wp, q, q2);
+  }
+}
+
+// Forward 2048-point negacyclic NTT of the 8 values per thread held in pattern {tau + 256k}
+// (natural order in), leaving the result in pattern {8 tau + k} (reference output order).
+__device__ __forceinline__ void ntt_fwd_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ fw,
+                                              const u32* __restrict__ fwp, u32 q, u32 q2) {
+  fwd_pass<256, true>(v, 0, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldsA[PAD_A(tau + 256 * k)] = v[k];
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(256 * b + o + 32 * k)];
+    fwd_pass<32, true>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsB[PAD_A(256 * b + o + 32 * k)] = v[k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsB[PAD_A(32 * b + o + 4 * k)];
+    fwd_pass<4, true>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsA[PAD_B(32 * b + o + 4 * k)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_B(8 * tau + k)];
+  fwd_pass<1, false>(v, tau, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {  // ntt.rs:107-111
+    u32 x = v[k];
+    x -= (x >= q2 ? q2 : 0u);
+    x -= (x >= q ? q : 0u);
+    v[k] = x;
+  }
+}
+
+// Inverse: values in pattern {8 tau + k} (< 2q) -> pattern {tau + 256k}, canonical.
+__device__ __forceinline__ void ntt_inv_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ iw,
+                                              const u32* __restrict__ iwp, u32 q, u32 q2) {
+  inv_pass<1, false>(v, tau, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldsA[PAD_B(8 * tau + k)] = v[k];
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_B(32 * b + o + 4 * k)];
+    inv_pass<4, true>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsB[PAD_A(32 * b + o + 4 * k)] = v[k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsB[PAD_A(256 * b + o + 32 * k)];
+    inv_pass<32, true>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsA[PAD_A(256 * b + o + 32 * k)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(tau + 256 * k)];
+  inv_pass<256, true>(v, 0, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {  // ntt.rs:253-256
+    u32 x = v[k];
+    x -= (x >= q2 ? q2 : 0u);
+    x -= (x >= q ? q : 0u);
+    v[k] = x;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward NTT kernel: grid (n_out, 2 crt)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int o = blockIdx.x, c = blockIdx.y;
+  const int rows = d.rdim * d.t;
+  const int per_b = rows * d.cols;
+  const int b = o / per_b;
+  const int rem = o - b * per_b;
+  const int row = rem / d.cols, col = rem - row * d.cols;
+  const int kdig = row / d.rdim, j = row - kdig * d.rdim;
+  const long sb = d.src_idx ? (long)d.src_idx[b] : (long)b;
+  const u64* src = d.src + (sb * d.src_batch_stride + (long)(d.src_row0 + j) * d.src_cols + col) * N;
+  const ModConst m = T.c.mod[c];
+  const int sh = kdig * d.bits;
+  const bool plain = (d.bits >= 64);
+  const u64 mask = plain ? ~0ULL : ((1ULL << d.bits) - 1ULL);
+  u32 v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u64 x = src[tau + 256 * k];
+    u64 piece = (sh >= 64) ? 0ULL : ((x >> sh) & mask);  // gadget.rs:48-53
+    v[k] = (d.bits <= 28) ? (u32)piece : reduce64(piece, m);
+  }
+  const u32* fw = T.tw + (size_t)c * 4 * N;
+  ntt_fwd_block(v, tau, ldsA, ldsB, fw, fw + N, m.q, m.two_q);
+  uint4* dst = reinterpret_cast<uint4*>(d.dst + ((size_t)o * 2 + c) * N + 8 * tau);
+  dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
+  dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
+}
+void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
+  if (d.n_out <= 0) return;
+  hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// inverse NTT (both moduli) + Garner CRT -> raw u64.  grid (n_polys)
+// The composed value is the unique v in [0, Q) with v = x mod q0, v = y mod q1, i.e. exactly
+// (x*q1*(q1^-1 mod q0) + y*q0*(q0^-1 mod q1)) mod Q of params.rs:207-214.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int p = blockIdx.x;
+  long base;
+  long crt_stride = d.crt_stride, z_stride = d.z_stride;
+  if (d.sweep_np > 0) {
+    const long np = d.sweep_np;
+    const long ct = p >> 1, r = p & 1;
+    const long plane = ct / np, ii = ct - plane * np;
+    base = plane * 4 * N * np + r * 2 * N * np + ii;
+    crt_stride = N * np;
+    z_stride = np;
+  } else if (d.idx) {
+    int e = p / d.polys_per_idx, r = p - e * d.polys_per_idx;
+    base = (long)d.idx[e] * d.idx_stride + (long)r * d.poly_stride;
+  } else {
+    base = (long)p * d.poly_stride;
+  }
+  u32 res[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* src = d.src + base + (long)c * crt_stride;
+    u32 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 x = src[(long)(8 * tau + k) * z_stride];
+      if (d.premod) x = x % m.q;
+      v[k] = x;
+    }
+    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    if (c == 1) __syncthreads();
+    ntt_inv_block(v, tau, ldsA, ldsB, iw, iw + N, m.q, m.two_q);
+#pragma unroll
+    for (int k = 0; k < 8; k++) res[c][k] = v[k];
+  }
+  const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+  u64* dst = d.dst + (size_t)p * N;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    u32 x = res[0][k], y = res[1][k];
+    u32 xm = x >= q1 ? x - q1 : x;  // q0 < 2*q1
+    u32 dd = y >= xm ? y - xm : y + q1 - xm;
+    u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+    u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+    e = e >= q1 ? e - q1 : e;
+    u64 val = (u64)x + (u64)q0 * (u64)e;
+    int z = tau + 256 * k;
+    if (d.automorph_t) {  // poly.rs:393-405
+      unsigned zt = (unsigned)z * (unsigned)d.automorph_t;
+      unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
+      dst[rem] = (num & 1u) ? T.c.Q - val : val;
+    } else {
+      dst[z] = val;
+    }
+  }
+}
+void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
+  if (d.n_polys <= 0) return;
+  hipLaunchKernelGGL(k_ntt_inv, dim3(d.n_polys), dim3(256), 0, s, T, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// NTT-domain multiply-accumulate.  grid (2N/256, batch), one (crt, z) per thread.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // index into [crt][z]
+  const int c = e >> POLY_LEN_LOG2;
+  const int inner = blockIdx.y, outer = blockIdx.z;
+  const int b = outer * d.batch_inner + inner;
+  const ModConst m = T.c.mod[c];
+  const u32* B = d.B + ((size_t)outer * d.B_outer_stride + (size_t)inner * d.B_inner_stride) * 2 * N + e;
+  const long ob = d.out_idx ? (long)d.out_idx[b] : (long)b * d.out_batch_stride;
+  for (int r = 0; r < d.R; r++) {
+    const u32* A = d.A + (size_t)r * d.K * 2 * N + e;
+    const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
+    u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
+    for (int k0 = 0; k0 < d.K; k0 += 128) {  // products < 2^56: 128 terms + carry-in stay < 2^64
+      int k1 = min(k0 + 128, d.K);
+      for (int k = k0; k < k1; k++) {
+        const size_t kb = k < d.split_k ? (size_t)k : (size_t)(d.split_off + (k - d.split_k));
+        acc += (u64)A[(size_t)k * 2 * N] * (u64)B[kb * 2 * N];
+      }
+      acc = reduce64(acc, m);
+    }
+    d.out[op] = (u32)acc;
+  }
+}
+void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
+  if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
+  hipLaunchKernelGGL(k_mac, dim3(2 * N / 256, d.batch_inner, d.batch_outer), dim3(256), 0, s, T, d);
+}
+
+__global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, const int* idx, const u32* src) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int b = blockIdx.y;
+  const long dp = (long)idx[b] * 2 * N + e;
+  dst[dp] = add_mod(dst[dp], src[(size_t)b * 2 * N + e], T.c.mod[c].q);
+}
+void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(k_add_poly_into, dim3(2 * N / 256, batch), dim3(256), 0, s, T, dst, idx, src);
+}
+
+__global__ __launch_bounds__(256) void k_scalar_mul(DevTables T, u32* base, long dst_off, long src_off,
+                                                    const u32* scalar) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const long b = blockIdx.y;
+  const ModConst m = T.c.mod[c];
+  base[(dst_off + b) * 2 * N + e] = reduce64((u64)base[(src_off + b) * 2 * N + e] * (u64)scalar[e], m);
+}
+void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off, const u32* scalar, int n_polys,
+                       hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_scalar_mul, dim3(2 * N / 256, n_polys), dim3(256), 0, s, T, base, dst_off, src_off, scalar);
+}
+
+__global__ __launch_bounds__(256) void k_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src,
+                                                    const int* src_idx, int src_row_stride, int R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y / R, r = blockIdx.y % R;
+  dst[((long)dst_idx[b] + (long)r * dst_row_stride) * 2 * N + e] =
+      src[((long)src_idx[b] + (long)r * src_row_stride) * 2 * N + e];
+}
+void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
+                       int src_row_stride, int R, int batch, hipStream_t s) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(k_copy_polys, dim3(2 * N / 256, batch * R), dim3(256), 0, s, dst, dst_idx, dst_row_stride, src,
+                     src_idx, src_row_stride, R);
+}
+
+__global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, const u32* gadget_ntt, int two_t) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int col = blockIdx.y % two_t, r = blockIdx.y / two_t;
+  const int dd = blockIdx.z;
+  const u32 q = T.c.mod[c].q;
+  u32* row = mats + ((size_t)(dd * 2 + r) * 2 * two_t) * 2 * N;
+  const u32 cv = row[(size_t)(two_t + col) * 2 * N + e];
+  const u32 g = gadget_ntt[((size_t)r * two_t + col) * 2 * N + e];
+  row[(size_t)col * 2 * N + e] = add_mod(g, cv ? q - cv : 0u, q);
+}
+void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s) {
+  if (nu2 <= 0) return;
+  hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, mats, gadget_ntt, two_t);
+}
+
+__global__ __launch_bounds__(256) void k_add(DevTables T, u32* out, const u32* a, const u32* b) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)((i >> POLY_LEN_LOG2) & 1);
+  out[i] = add_mod(a[i], b[i], T.c.mod[c].q);
+}
+void launch_add(const DevTables& T, u32* out, const u32* a, const u32* b, int n_polys, hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_add, dim3((unsigned)((size_t)n_polys * 2 * N / 256)), dim3(256), 0, s, T, out, a, b);
+}
+
+__global__ __launch_bounds__(256) void k_invert_raw(u64 Q, u64* out, const u64* a, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = Q - a[i];
+}
+void launch_invert_raw(const DevTables& T, u64* out, const u64* a, long n_words, hipStream_t s) {
+  if (n_words <= 0) return;
+  hipLaunchKernelGGL(k_invert_raw, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, T.c.Q, out, a, n_words);
+}
+
+__global__ __launch_bounds__(256) void k_automorph(u64 Q, u64* out, const u64* a, int t) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  const size_t p = (size_t)blockIdx.y * N;
+  unsigned zt = (unsigned)z * (unsigned)t;
+  unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
+  u64 v = a[p + z];
+  out[p + rem] = (num & 1u) ? Q - v : v;
+}
+void launch_automorph(const DevTables& T, u64* out, const u64* a, int n_polys, int t, hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_automorph, dim3(N / 256, n_polys), dim3(256), 0, s, T.c.Q, out, a, t);
+}
+
+__global__ __launch_bounds__(256) void k_gadget_raw(u64* out, const u64* inp, int cols, int rdim, int bits) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;  // output poly index: row*cols + col
+  const int row = o / cols, col = o - row * cols;
+  const int k = row / rdim, j = row - k * rdim;
+  const int sh = k * bits;
+  const u64 mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL);
+  u64 x = inp[((size_t)j * cols + col) * N + z];
+  out[(size_t)o * N + z] = sh >= 64 ? 0ULL : ((x >> sh) & mask);
+}
+void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows_out, int rdim, int bits,
+                       hipStream_t s) {
+  (void)rows_in;
+  hipLaunchKernelGGL(k_gadget_raw, dim3(N / 256, rows_out * cols), dim3(256), 0, s, out, inp, cols, rdim, bits);
+}
+
+__global__ __launch_bounds__(256) void k_u64_to_u32(u32* out, const u64* in, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (u32)in[i];
+}
+__global__ __launch_bounds__(256) void k_u32_to_u64(u64* out, const u32* in, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (u64)in[i];
+}
+void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_u64_to_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+}
+void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_u32_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+}
+
+// out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
+__global__ __launch_bounds__(256) void k_reorient(u64* out, const u32* v, int first, int step, int dim0) {
+  __shared__ u64 tile[32][33];
+  // tile over (z, j) for a fixed r: blockIdx.x -> j tile, blockIdx.y -> z tile, blockIdx.z -> r
+  const int r = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int j0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int j = j0 + ty + 8 * i;
+    if (j < dim0) {
+      const u32* p = v + ((size_t)(first + step * j) * 2 + r) * 2 * N;
+      tile[ty + 8 * i][tx] = (u64)p[z0 + tx] | ((u64)p[N + z0 + tx] << 32);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int z = z0 + ty + 8 * i;
+    int j = j0 + tx;
+    if (j < dim0) out[((size_t)z * dim0 + j) * 2 + r] = tile[tx][ty + 8 * i];
+  }
+}
+void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
+  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, out, v, first, step, dim0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// database sweep  (server.rs:155-221)
+// ------------------------------------------------------------------------------------------------
+// WIDE (num_per >= 128): one wave per (plane, z, 128-wide ii chunk).  Lane l owns output columns
+// ii = chunk*128 + 2l, 2l+1 and streams its 16 bytes of every first-dimension row j: 1 KiB
+// contiguous per wave per row.  The query words for (z, j) are wave-uniform (scalar loads, SGPR
+// operands of v_mad_u64_u32); no cross-lane traffic at all.  Products are < 2^56, so 256 rows are
+// accumulated in u64 between Barrett folds (the reference uses u128 and one % at the end; the
+// residues are identical).
+template <int U>
+__global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;  // plane * N + z
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  if (plane >= d.planes) return;
+  const ulonglong2* p =
+      reinterpret_cast<const ulonglong2*>(d.db + ((size_t)zp * d.nj) * d.num_per + (size_t)chunk * 128) + lane;
+  const size_t stride = (size_t)(d.num_per >> 1);
+  const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+
+  u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0;  // word 0: n0_0, n0_1, n1_0, n1_1
+  u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // word 1
+  for (int jb = 0; jb < d.nj; jb += 256) {
+    const int je = min(jb + 256, d.nj);
+    int j = jb;
+    for (; j + U <= je; j += U) {
+      ulonglong2 w[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) w[u] = p[(size_t)(j + u) * stride];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint4 qa = qrow[j + u];  // (a0_lo, a0_hi, a1_lo, a1_hi)
+        const u32 b0l = (u32)w[u].x, b0h = (u32)(w[u].x >> 32);
+        const u32 b1l = (u32)w[u].y, b1h = (u32)(w[u].y >> 32);
+        a00 += (u64)qa.x * b0l;
+        a01 += (u64)qa.z * b0l;
+        a02 += (u64)qa.y * b0h;
+        a03 += (u64)qa.w * b0h;
+        a10 += (u64)qa.x * b1l;
+        a11 += (u64)qa.z * b1l;
+        a12 += (u64)qa.y * b1h;
+        a13 += (u64)qa.w * b1h;
+      }
+    }
+    for (; j < je; j++) {
+      const ulonglong2 w = p[(size_t)j * stride];
+      const uint4 qa = qrow[j];
+      const u32 b0l = (u32)w.x, b0h = (u32)(w.x >> 32);
+      const u32 b1l = (u32)w.y, b1h = (u32)(w.y >> 32);
+      a00 += (u64)qa.x * b0l;
+      a01 += (u64)qa.z * b0l;
+      a02 += (u64)qa.y * b0h;
+      a03 += (u64)qa.w * b0h;
+      a10 += (u64)qa.x * b1l;
+      a11 += (u64)qa.z * b1l;
+      a12 += (u64)qa.y * b1h;
+      a13 += (u64)qa.w * b1h;
+    }
+    a00 = reduce64(a00, m0);
+    a01 = reduce64(a01, m0);
+    a02 = reduce64(a02, m1);
+    a03 = reduce64(a03, m1);
+    a10 = reduce64(a10, m0);
+    a11 = reduce64(a11, m0);
+    a12 = reduce64(a12, m1);
+    a13 = reduce64(a13, m1);
+  }
+  // out[plane][r][crt][z][ii]
+  const size_t plane_words = (size_t)4 * N * d.num_per;
+  const size_t zi = (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
+  u32* o = d.out + (size_t)plane * plane_words + zi;
+  const size_t rc = (size_t)N * d.num_per;
+  *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)a00, (u32)a10);  // r=0, crt=0
+  *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)a02, (u32)a12);  // r=0, crt=1
+  *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)a01, (u32)a11);  // r=1, crt=0
+  *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)a03, (u32)a13);  // r=1, crt=1
+}
+
+// NARROW (num_per <= 64): one workgroup per (plane, z).  The nj*num_per words of the row block are
+// contiguous; thread tau reads word tau + 256*s, i.e. fixed ii = tau % num_per and rows
+// j = tau/num_per + s*(256/num_per).  Query limbs for this z are staged in LDS (16 B per row);
+// partial sums are Barrett-folded to < 2^28 and combined through LDS.
+__global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* qs = reinterpret_cast<uint4*>(smem);                          // [nj]
+  u32* red = reinterpret_cast<u32*>(smem + (size_t)d.nj * sizeof(uint4));  // [256][4]
+  const int tau = threadIdx.x;
+  const int zp = blockIdx.x;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  for (int j = tau; j < d.nj; j += 256) qs[j] = qrow[j];
+  __syncthreads();
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u64* p = d.db + (size_t)zp * d.nj * d.num_per;
+  const int L = d.nj * d.num_per;
+  const int np_log = __ffs(d.num_per) - 1;
+  u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int cnt = 0;
+  for (int f = tau; f < L; f += 256) {
+    const u64 w = p[f];
+    const uint4 qa = qs[f >> np_log];
+    const u32 bl = (u32)w, bh = (u32)(w >> 32);
+    a0 += (u64)qa.x * bl;
+    a1 += (u64)qa.z * bl;
+    a2 += (u64)qa.y * bh;
+    a3 += (u64)qa.w * bh;
+    if (++cnt == 255) {
+      cnt = 0;
+      a0 = reduce64(a0, m0);
+      a1 = reduce64(a1, m0);
+      a2 = reduce64(a2, m1);
+      a3 = reduce64(a3, m1);
+    }
+  }
+  red[tau * 4 + 0] = reduce64(a0, m0);
+  red[tau * 4 + 1] = reduce64(a1, m0);
+  red[tau * 4 + 2] = reduce64(a2, m1);
+  red[tau * 4 + 3] = reduce64(a3, m1);
+  __syncthreads();
+  // 4*num_per outputs; thread t < 4*num_per: which = t / num_per, ii = t % num_per
+  if (tau < 4 * d.num_per) {
+    const int which = tau >> np_log, ii = tau & (d.num_per - 1);
+    u64 sacc = 0;
+    for (int t2 = ii; t2 < 256; t2 += d.num_per) sacc += red[t2 * 4 + which];
+    const u32 r = reduce64(sacc, which < 2 ? m0 : m1);
+    // which: 0 n0_0 (r0,c0)  1 n0_1 (r1,c0)  2 n1_0 (r0,c1)  3 n1_1 (r1,c1)
+    const int rr = which & 1, cc = which >> 1;
+    d.out[(((size_t)plane * 2 + rr) * 2 + cc) * N * d.num_per + (size_t)z * d.num_per + ii] = r;
+  }
+}
+
+const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_wide" : "k_sweep_narrow"; }
+
+void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
+  if (d.num_per >= 128) {
+    const long units = (long)d.planes * N * (d.num_per >> 7);
+    hipLaunchKernelGGL(k_sweep_wide<8>, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
+  } else {
+    size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
+    hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+  }
+}
+
+// reference [z][ii][j] -> device [z][j - j0][ii] for nz rows starting at z0 (32x32 LDS tile transpose)
+__global__ __launch_bounds__(256) void k_db_relayout(u64* dst_plane, const u64* src, int z0, int num_per, int dim0,
+                                                     int j0, int nj) {
+  __shared__ u64 tile[32][33];
+  const int zl = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int jt = blockIdx.x * 32, it = blockIdx.y * 32;
+  const u64* s = src + (size_t)zl * num_per * dim0;
+  u64* dpl = dst_plane + (size_t)(z0 + zl) * nj * num_per;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int ii = it + ty + 8 * i, j = jt + tx;
+    if (ii < num_per && j < nj) tile[ty + 8 * i][tx] = s[(size_t)ii * dim0 + j0 + j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int j = jt + ty + 8 * i, ii = it + tx;
+    if (ii < num_per && j < nj) dpl[(size_t)j * num_per + ii] = tile[tx][ty + 8 * i];
+  }
+}
+void launch_db_relayout(u64* dst_plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
+                        hipStream_t s) {
+  if (nz <= 0) return;
+  hipLaunchKernelGGL(k_db_relayout, dim3((nj + 31) / 32, (num_per + 31) / 32, nz), dim3(256), 0, s, dst_plane, src, z0,
+                     num_per, dim0, j0, nj);
+}
+
+__global__ __launch_bounds__(256) void k_db_synth(u64* dst, u64 seed, int num_per, int dim0, int j0, int nj,
+                                                  size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    // device index i = ((zp * nj) + jl) * num_per + ii
+    size_t ii = i % num_per;
+    size_t t = i / num_per;
+    size_t jl = t % nj;
+    size_t zp = t / nj;
+    size_t ref = (zp * num_per + ii) * dim0 + j0 + jl;
+    dst[i] = synth_word(seed, ref);
+  }
+}
+void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, hipStream_t s) {
+  size_t total = (size_t)planes * N * nj * num_per;
+  hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total);
+}
+
+__global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* in, int num_per) {
+  // out[ii][r][crt][z] <- in[r][crt][z][ii]
+  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  size_t total = (size_t)4 * N * num_per;
+  if (i >= total) return;
+  size_t z = i & (N - 1);
+  size_t rc = (i >> POLY_LEN_LOG2) & 3;
+  size_t ii = i >> (POLY_LEN_LOG2 + 2);
+  out[i] = (u64)in[(rc * N + z) * num_per + ii];
+}
+void launch_sweep_out_to_ref(u64* out, const u32* in, int num_per, hipStream_t s) {
+  size_t total = (size_t)4 * N * num_per;
+  hipLaunchKernelGGL(k_sweep_out_to_ref, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, in, num_per);
+}
+
+}  // namespace spiral

@@ -1,0 +1,140 @@
+// Launch wrappers for the gfx950 kernels of the Spiral answer path (kernels.hip).
+// Device data model:
+//   NTT-form poly   : u32[2][N]  ([crt][z], residues < q_crt)           -- "npoly", 16 KiB
+//   raw poly        : u64[N]     (coefficients <= Q < 2^56)              -- "rpoly", 16 KiB
+//   matrices        : row-major arrays of polys, as the reference's PolyMatrix (poly.rs:31-35)
+// All launches are asynchronous on the given stream.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "params.hpp"
+
+namespace spiral {
+
+constexpr int N = (int)POLY_LEN;
+
+struct DevTables {
+  const u32* tw;  // [crt][4][N] twiddles (0 fwd, 1 fwd', 2 inv, 3 inv')
+  DevConsts c;
+};
+
+// ---- forward NTT family -------------------------------------------------------------------
+// Generic source descriptor for a batch of forward NTTs: output poly `o` (0 <= o < n_out) is the
+// NTT of digit `k` of raw poly `src`, where with out matrix (rdim*t x cols) per batch element
+// (gadget.rs:34-60):  b = o / (rdim*t*cols), row = (o / cols) % (rdim*t), col = o % cols,
+// k = row / rdim, j = row % rdim, src poly = b*src_batch_stride + (src_row0 + j)*src_cols + col.
+// t = 1, bits = 64 gives plain to_ntt (poly.rs:613-623: value reduced mod q_crt first).
+struct FwdDesc {
+  const u64* src;      // raw polys
+  const int* src_idx;  // optional: batch element b reads from src + src_idx[b]*src_batch_stride polys
+  u32* dst;            // n_out NTT polys, dense
+  int n_out;
+  int rdim, cols, t, bits;
+  int src_batch_stride;  // in polys
+  int src_row0, src_cols;
+};
+void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s);
+
+// ---- inverse NTT + CRT compose (poly.rs:646-663) -------------------------------------------
+// Source element (poly p, crt c, coefficient z) is read from
+//   src[(idx ? idx[p / polys_per_idx] * idx_stride + (p % polys_per_idx) * poly_stride : p * poly_stride)
+//       + c * crt_stride + z * z_stride]                      (all strides in u32 words)
+// premod: source values are sums of up to 8 residues (multi-GPU partials) -> reduce mod q first.
+struct InvDesc {
+  const u32* src;
+  const int* idx;
+  int polys_per_idx;
+  long idx_stride, poly_stride, crt_stride, z_stride;
+  u64* dst;  // n_polys raw polys, dense
+  int n_polys;
+  int premod;
+  // sweep_np > 0: source is the sweep-native [plane][r][crt][z][ii] buffer with num_per = sweep_np;
+  // poly p = (plane*num_per + ii)*2 + r (idx/strides ignored)
+  int sweep_np;
+  // optional fused automorphism (poly.rs:393-405) applied to the raw result: dst[(z*t) % N] = +-v
+  int automorph_t;  // 0 = none
+};
+void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s);
+
+// ---- NTT-domain multiply-accumulate (poly.rs:437-481) --------------------------------------
+// out[b][r] = (addend ? addend[b][r] : 0) + sum_k A[r][k] * B[b][k]   (pointwise, per crt), r < R
+//   A: R x K polys, shared by the batch.
+//   B operand k of batch element (outer, inner): poly
+//     outer*B_outer_stride + inner*B_inner_stride + (k < split_k ? k : split_off + (k - split_k))
+//   out / addend poly index: (out_idx ? out_idx[b] : b * out_batch_stride) + r * out_row_stride,
+//   b = outer*batch_inner + inner.
+struct MacDesc {
+  const u32* A;
+  const u32* B;
+  u32* out;
+  const u32* addend;  // may alias out
+  const int* out_idx;
+  int R, K;
+  int batch_inner, batch_outer;
+  long B_inner_stride, B_outer_stride;  // in polys
+  int split_k;
+  long split_off;  // in polys
+  int out_batch_stride, out_row_stride;
+};
+void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s);
+
+// dst poly idx[b] += src poly b   (NTT polys, mod q)
+void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s);
+// polys [dst_off + b] = scalar (1 poly) * polys [src_off + b], b < n_polys   (multiply_poly, poly.rs:351-358)
+void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off, const u32* scalar, int n_polys,
+                       hipStream_t s);
+// gather copy of NTT polys: dst poly (dst_idx[b] + r*dst_row_stride) = src poly (src_idx[b] + r*src_row_stride), r < R
+void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
+                       int src_row_stride, int R, int batch, hipStream_t s);
+// v_folding_neg = G - C in the NTT domain (== server.rs:505-523): for each GSW ct d,
+// mats[d][r][0..2t) = gadget_ntt[r][col] + q - mats[d][r][2t + col]; mats rows are 4t polys wide
+void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s);
+// out = a + b (mod q) over n_polys NTT polys (poly.rs:483-498)
+void launch_add(const DevTables& T, u32* out, const u32* a, const u32* b, int n_polys, hipStream_t s);
+// raw: out[i] = Q - a[i]  (poly.rs:387-391, gives Q for 0)
+void launch_invert_raw(const DevTables& T, u64* out, const u64* a, long n_words, hipStream_t s);
+// raw automorphism on n_polys polys (poly.rs:393-405)
+void launch_automorph(const DevTables& T, u64* out, const u64* a, int n_polys, int t, hipStream_t s);
+// raw digits (gadget.rs:34-60) without NTT: out[rows_out x cols] from inp[rows_in x cols]
+void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows_out, int rdim, int bits,
+                       hipStream_t s);
+// ref-layout conversions: u64 NTT poly words <-> u32 npolys
+void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s);
+void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s);
+
+// ---- query reorientation (util.rs:323-355) --------------------------------------------------
+// v (NTT cts, 2 polys each) at ct indices first + step*j, j < dim0  ->  out[z][j][r] = lo | hi << 32
+void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s);
+
+// ---- database sweep (server.rs:155-221) -----------------------------------------------------
+// Device DB layout per plane: [z][j_local][ii] u64 (word = lo28 | hi28<<32): the reference's
+// [z][ii][j] with the two inner axes swapped so that lanes run along ii.
+// qv: reoriented query [z][dim0][2] u64 (reference layout); rows j0 .. j0+nj of it are used.
+// out: u32 [plane][r][crt][z][ii] residues < q.
+struct SweepDesc {
+  const u64* db;  // plane 0 of this shard
+  const u64* qv;
+  u32* out;
+  int planes, num_per, dim0, j0, nj;
+};
+void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
+const char* sweep_kernel_name(int num_per);
+// reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order
+// words already on the device), dst plane base; keeps rows j0..j0+nj
+void launch_db_relayout(u64* dst_plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
+                        hipStream_t s);
+void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, hipStream_t s);
+// sweep-native out [plane][r][crt][z][ii] -> reference out[ii].data[r*2N + crt*N + z] (u64) for one plane
+void launch_sweep_out_to_ref(u64* out, const u32* in, int num_per, hipStream_t s);
+
+__host__ __device__ inline u64 synth_word(u64 seed, u64 idx) {
+  u64 z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  u64 lo = (u32)z % (u32)MODULUS_0;
+  u64 hi = (u32)(z >> 32) % (u32)MODULUS_1;
+  return lo | (hi << 32);
+}
+
+}  // namespace spiral

@@ -1,0 +1,54 @@
+// Per-call device workspace + the stage functions of the answer path (server.cpp).
+#pragma once
+#include "server.hpp"
+
+namespace spiral {
+
+struct Workspace {
+  const Params* P;
+  DeviceState* D;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
+  // expansion
+  DevBuf<u64> q_raw;      // query ct, raw 2x1
+  DevBuf<u32> v;          // [2^g] 2x1 NTT cts
+  DevBuf<u64> exp_raw;    // [active] automorphed raw cts
+  DevBuf<u32> exp_dig;    // digit NTTs of one group
+  DevBuf<u32> exp_ct1;    // NTT of row 1 of the automorphed cts
+  DevBuf<u64> qv;         // reoriented first-dimension query [N][dim0][2]
+  DevBuf<u32> fold_mats;  // [nu_2][2 rows][ G - C | C ] (2 x 4 t_gsw NTT polys per GSW ct)
+  DevBuf<u64> gsw_raw;
+  DevBuf<u32> gsw_dig;
+  // sweep
+  DevBuf<u32> sweep_out;  // [plane][r][crt][z][ii]
+  // fold / pack
+  DevBuf<u64> foldX, foldY, final_cts, pack_raw;
+  DevBuf<u32> fold_dig, fold_ntt, pack_dig, pack_ct2, pack_res;
+  // host staging (pinned)
+  u64* h_query = nullptr;
+  u64* h_packed = nullptr;
+  size_t h_packed_words = 0;
+
+  Workspace(const Params& P, DeviceState& D);
+  ~Workspace();
+  Workspace(const Workspace&) = delete;
+  Workspace& operator=(const Workspace&) = delete;
+  void ensure_expand();
+  void ensure_sweep();
+  void ensure_finish();
+  size_t plane_group() const;
+};
+
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds);
+void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
+void run_folding_neg(Workspace& W);
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
+void run_sweep(Workspace& W, const sp_db& db);
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts);
+void run_fold_all(Workspace& W, bool premod);
+void run_pack(Workspace& W, const sp_pp& pp);
+void run_finish(Workspace& W, const sp_pp& pp, bool premod);
+size_t encode_response(const Params& p, const u64* packed, uint8_t* out);
+
+}  // namespace spiral

@@ -1,0 +1,632 @@
+// Host-side orchestration of the Spiral answer path on one MI355X (see server.hpp).
+// Reference call tree reproduced: lib/spiral-rs/src/server.rs:650-741 (process_query) ->
+// :525-591 expand_query -> :19-121 coefficient_expansion, :123-151 regev_to_gsw; :505-523
+// get_v_folding_neg; :155-221 multiply_reg_by_database; :388-427 fold_ciphertexts; :429-468 pack;
+// :470-503 encode.  Deserialisers: client.rs:212-259, 303-329.
+#include "server.hpp"
+
+#include <algorithm>
+#include <cstring>
+
+#include "pipeline.hpp"
+
+namespace spiral {
+
+void hip_check(hipError_t e, const char* what, const char* file, int line) {
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw HipError(std::string(what) + " failed at " + file + ":" + std::to_string(line) + ": " + hipGetErrorString(e));
+  }
+}
+
+// ---------------------------------------------------------------------------------- ChaCha20
+static inline u32 rotl(u32 v, int c) { return (v << c) | (v >> (32 - c)); }
+static inline void quarter(u32* s, int a, int b, int c, int d) {
+  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+}
+void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
+  u32 init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
+  for (int i = 0; i < 8; i++) {
+    u32 w;
+    memcpy(&w, seed + 4 * i, 4);
+    init[4 + i] = w;
+  }
+  u64 ctr = 0;
+  size_t done = 0;
+  while (done < count) {
+    init[12] = (u32)ctr;
+    init[13] = (u32)(ctr >> 32);
+    init[14] = init[15] = 0;
+    u32 s[16];
+    memcpy(s, init, sizeof(s));
+    for (int rnd = 0; rnd < 10; rnd++) {
+      quarter(s, 0, 4, 8, 12); quarter(s, 1, 5, 9, 13); quarter(s, 2, 6, 10, 14); quarter(s, 3, 7, 11, 15);
+      quarter(s, 0, 5, 10, 15); quarter(s, 1, 6, 11, 12); quarter(s, 2, 7, 8, 13); quarter(s, 3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16 && done < count; i += 2, done++)
+      out[done] = (u64)(s[i] + init[i]) | ((u64)(s[i + 1] + init[i + 1]) << 32);
+    ctr++;
+  }
+}
+
+// ---------------------------------------------------------------------------------- device state
+static std::unique_ptr<DeviceState> build_device_state(const Params& P, int device) {
+  auto D = std::make_unique<DeviceState>();
+  D->device = device;
+  D->tw.alloc(P.ntt_tables.size());
+  HIP_CHECK(hipMemcpy(D->tw.p, P.ntt_tables.data(), P.ntt_tables.size() * sizeof(u32), hipMemcpyHostToDevice));
+  D->T.tw = D->tw.p;
+  D->T.c = P.dc;
+  const size_t g = P.expand_queries ? P.g() : 0;
+  const size_t nu2 = P.db_dim_2;
+
+  // -x^(N - 2^r) in NTT form (params.rs:98-107): coefficient Q-1 at idx; the other coefficients are
+  // Q in the reference (invert_poly of 0), i.e. 0 after reduction.
+  {
+    std::vector<u64> raw(std::max<size_t>(g, 1) * POLY_LEN, 0);
+    for (size_t r = 0; r < g && r < POLY_LEN_LOG2; r++) raw[r * POLY_LEN + (POLY_LEN - ((size_t)1 << r))] = P.modulus - 1;
+    DevBuf<u64> d_raw(raw.size());
+    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    D->neg1.alloc(std::max<size_t>(g, 1) * 2 * POLY_LEN);
+    FwdDesc f{d_raw.p, nullptr, D->neg1.p, (int)g, 1, 1, 1, 64, 1, 0, 1};
+    launch_ntt_fwd(D->T, f, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  // build_gadget(params, 2, 2*t_gsw).ntt()  (gadget.rs:11-32, server.rs:509)
+  {
+    const size_t cols = 2 * P.t_gsw, bits = P.bits_per(P.t_gsw);
+    std::vector<u64> raw(2 * cols * POLY_LEN, 0);
+    for (size_t i = 0; i < 2; i++)
+      for (size_t j = 0; j < P.t_gsw; j++) {
+        if (bits * j >= 64) continue;
+        raw[(i * cols + (i + j * 2)) * POLY_LEN] = 1ULL << (bits * j);
+      }
+    DevBuf<u64> d_raw(raw.size());
+    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    D->gadget_gsw.alloc(2 * cols * 2 * POLY_LEN);
+    FwdDesc f{d_raw.p, nullptr, D->gadget_gsw.p, (int)(2 * cols), 1, 1, 1, 64, 1, 0, 1};
+    launch_ntt_fwd(D->T, f, 0);
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+
+  // index lists
+  std::vector<int> L;
+  auto put = [&](const std::vector<int>& v) {
+    size_t off = L.size();
+    L.insert(L.end(), v.begin(), v.end());
+    return off;
+  };
+  if (P.expand_queries) {
+    const size_t stop_round = nu2 > 0 ? P.stop_round() : 0;
+    const size_t max_bits_right = nu2 > 0 ? P.t_gsw * nu2 : 0;
+    for (size_t r = 0; r < g; r++) {
+      RoundPlan rp;
+      rp.num_in = 1 << r;
+      rp.t_auto = (int)(POLY_LEN >> r) + 1;
+      std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout;
+      for (int half = 0; half < 2; half++)
+        for (int i = 0; i < rp.num_in; i++) {  // both halves enumerate from 0 (server.rs:112-119)
+          bool skip = (stop_round > 0 && r > stop_round && (i % 2) == 1) ||
+                      (stop_round > 0 && r == stop_round && (i % 2) == 1 && (size_t)(i / 2) >= max_bits_right);
+          if (skip) continue;
+          int ct = half * rp.num_in + i;
+          int pos = (int)all_ct.size();
+          all_ct.push_back(ct);
+          all_row1.push_back(ct * 2 + 1);
+          if (r != 0 && (i % 2) == 0) {
+            lpos.push_back(pos);
+            lout.push_back(ct * 2);
+          } else {
+            rpos.push_back(pos);
+            rout.push_back(ct * 2);
+          }
+        }
+      rp.n_all = (int)all_ct.size();
+      rp.n_left = (int)lpos.size();
+      rp.n_right = (int)rpos.size();
+      rp.all_ct = put(all_ct);
+      rp.all_row1 = put(all_row1);
+      rp.left_pos = put(lpos);
+      rp.left_out = put(lout);
+      rp.right_pos = put(rpos);
+      rp.right_out = put(rout);
+      D->max_all = std::max(D->max_all, (size_t)rp.n_all);
+      D->max_left = std::max(D->max_left, (size_t)rp.n_left);
+      D->max_right = std::max(D->max_right, (size_t)rp.n_right);
+      D->rounds.push_back(rp);
+    }
+  }
+  {
+    std::vector<int> src_ct, src_poly, out_even, out_odd;
+    for (size_t d = 0; d < nu2; d++)
+      for (size_t j = 0; j < P.t_gsw; j++) {
+        int b = (int)(d * P.t_gsw + j);
+        src_ct.push_back(2 * b + 1);
+        src_poly.push_back((2 * b + 1) * 2);
+        int row0 = (int)(d * 2 * 4 * P.t_gsw + 2 * P.t_gsw);
+        out_even.push_back(row0 + (int)(2 * j));
+        out_odd.push_back(row0 + (int)(2 * j + 1));
+      }
+    D->gsw_src_ct = put(src_ct);
+    D->gsw_src_poly = put(src_poly);
+    D->gsw_out_even = put(out_even);
+    D->gsw_out_odd = put(out_odd);
+  }
+  {
+    std::vector<int> src_ct, out, row;
+    const int n = (int)P.n;
+    for (int inst = 0; inst < (int)P.instances; inst++)
+      for (int c = 0; c < n; c++) {
+        out.push_back(inst * (n + 1) * n + c);
+        for (int r = 0; r < n; r++) {
+          src_ct.push_back(inst * n * n + r * n + c);
+          row.push_back(inst * (n + 1) * n + (1 + r) * n + c);
+        }
+      }
+    D->pack_src_ct = put(src_ct);
+    D->pack_out = put(out);
+    D->pack_row = put(row);
+  }
+  D->lists.alloc(std::max<size_t>(L.size(), 1));
+  if (!L.empty()) HIP_CHECK(hipMemcpy(D->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  return D;
+}
+
+}  // namespace spiral
+
+using namespace spiral;
+
+DeviceState& sp_params::device_state() {
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(mu);
+  for (auto& d : this->dev)
+    if (d->device == dev) return *d;
+  this->dev.push_back(build_device_state(p, dev));
+  return *this->dev.back();
+}
+
+std::unique_ptr<Workspace> sp_params::acquire_ws() {
+  int dev = 0;
+  HIP_CHECK(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lk(mu);
+    for (size_t i = 0; i < ws_pool.size(); i++)
+      if (ws_pool[i]->device == dev) {
+        auto w = std::move(ws_pool[i]);
+        ws_pool.erase(ws_pool.begin() + i);
+        return w;
+      }
+  }
+  return std::make_unique<Workspace>(p, device_state());
+}
+
+void sp_params::release_ws(std::unique_ptr<Workspace> ws) {
+  std::lock_guard<std::mutex> lk(mu);
+  ws_pool.push_back(std::move(ws));
+}
+
+sp_params::~sp_params() {}
+
+namespace spiral {
+
+// ---------------------------------------------------------------------------------- workspace
+Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
+  device = D.device;
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
+  h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
+  HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
+  q_raw.alloc(2 * POLY_LEN);
+}
+
+Workspace::~Workspace() {
+  if (h_query) (void)hipHostFree(h_query);
+  if (h_packed) (void)hipHostFree(h_packed);
+  for (auto& e : ev)
+    if (e) (void)hipEventDestroy(e);
+  if (stream) (void)hipStreamDestroy(stream);
+}
+
+void Workspace::ensure_expand() {
+  const Params& p = *P;
+  const size_t g = p.g();
+  v.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);
+  exp_raw.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
+  size_t dig = std::max(D->max_left * p.t_exp_left, D->max_right * p.t_exp_right);
+  exp_dig.ensure(std::max<size_t>(dig, 1) * 2 * POLY_LEN);
+  exp_ct1.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
+  qv.ensure(POLY_LEN * p.dim0() * 2);
+  const size_t nb = p.db_dim_2 * p.t_gsw;
+  fold_mats.ensure(std::max<size_t>(p.db_dim_2, 1) * 2 * 4 * p.t_gsw * 2 * POLY_LEN);
+  gsw_raw.ensure(std::max<size_t>(nb, 1) * 2 * POLY_LEN);
+  gsw_dig.ensure(std::max<size_t>(nb, 1) * 2 * p.t_conv * 2 * POLY_LEN);
+}
+
+size_t Workspace::plane_group() const {
+  const Params& p = *P;
+  size_t per_plane = p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN * sizeof(u32);  // fold digits
+  size_t budget = (size_t)2 << 30;
+  size_t pg = std::max<size_t>(1, budget / std::max<size_t>(per_plane, 1));
+  return std::min(pg, p.planes());
+}
+
+void Workspace::ensure_sweep() {
+  const Params& p = *P;
+  sweep_out.ensure(p.planes() * 4 * POLY_LEN * p.num_per());
+}
+
+void Workspace::ensure_finish() {
+  const Params& p = *P;
+  const size_t pg = plane_group();
+  foldX.ensure(pg * p.num_per() * 2 * POLY_LEN);
+  foldY.ensure(std::max<size_t>(pg * p.num_per() / 2, 1) * 2 * POLY_LEN);
+  fold_dig.ensure(pg * p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN);
+  fold_ntt.ensure(std::max<size_t>(pg * p.num_per() / 2, 1) * 2 * 2 * POLY_LEN);
+  final_cts.ensure(p.planes() * 2 * POLY_LEN);
+  const size_t nb = p.planes();
+  pack_dig.ensure(nb * p.t_conv * 2 * POLY_LEN);
+  pack_ct2.ensure(nb * 2 * POLY_LEN);
+  pack_res.ensure(p.instances * (p.n + 1) * p.n * 2 * POLY_LEN);
+  pack_raw.ensure(p.instances * (p.n + 1) * p.n * POLY_LEN);
+}
+
+// ---------------------------------------------------------------------------------- pipeline stages
+// server.rs:19-121; v[0] holds the NTT'd query ct.
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const int* L = D.lists.p;
+  const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
+  for (size_t r = 0; r < g_rounds; r++) {
+    const RoundPlan& rp = D.rounds[r];
+    // v[num_in + i] = neg1[r] * v[i]   (server.rs:105-110)
+    launch_scalar_mul(D.T, W.v.p, (long)rp.num_in * 2, 0, D.neg1.p + r * 2 * POLY_LEN, rp.num_in * 2, s);
+    // ct = from_ntt(v_i); ct_auto = automorph(ct, t)   (server.rs:80-81)
+    InvDesc inv{};
+    inv.src = W.v.p;
+    inv.idx = L + rp.all_ct;
+    inv.polys_per_idx = 2;
+    inv.idx_stride = 4 * POLY_LEN;
+    inv.poly_stride = 2 * POLY_LEN;
+    inv.crt_stride = POLY_LEN;
+    inv.z_stride = 1;
+    inv.dst = W.exp_raw.p;
+    inv.n_polys = rp.n_all * 2;
+    inv.automorph_t = rp.t_auto;
+    launch_ntt_inv(D.T, inv, s);
+    // gadget_invert_rdim(ct_auto, rdim = 1) -> to_ntt_no_reduce -> W * ginv; v_i += ...  (server.rs:82-102)
+    for (int side = 0; side < 2; side++) {
+      const int cnt = side == 0 ? rp.n_left : rp.n_right;
+      if (cnt == 0) continue;
+      const int t = side == 0 ? tl : tr;
+      FwdDesc f{};
+      f.src = W.exp_raw.p;
+      f.src_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
+      f.dst = W.exp_dig.p;
+      f.n_out = cnt * t;
+      f.rdim = 1;
+      f.cols = 1;
+      f.t = t;
+      f.bits = (int)p.bits_per(t);
+      f.src_batch_stride = 2;
+      f.src_row0 = 0;
+      f.src_cols = 1;
+      launch_ntt_fwd(D.T, f, s);
+      const size_t woff = side == 0 ? pp.off_left + r * 2 * tl
+                                    : (pp.has_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl);
+      MacDesc m{};
+      m.A = pp.all.p + woff * 2 * POLY_LEN;
+      m.B = W.exp_dig.p;
+      m.out = W.v.p;
+      m.addend = W.v.p;
+      m.out_idx = L + (side == 0 ? rp.left_out : rp.right_out);
+      m.R = 2;
+      m.K = t;
+      m.batch_inner = cnt;
+      m.batch_outer = 1;
+      m.B_inner_stride = t;
+      m.B_outer_stride = 0;
+      m.split_k = t;
+      m.split_off = 0;
+      m.out_batch_stride = 0;
+      m.out_row_stride = 1;
+      launch_mac(D.T, m, s);
+    }
+    // + [0; to_ntt(ct_auto row 1)]   (server.rs:84-88, 95-98)
+    FwdDesc f1{};
+    f1.src = W.exp_raw.p;
+    f1.dst = W.exp_ct1.p;
+    f1.n_out = rp.n_all;
+    f1.rdim = 1;
+    f1.cols = 1;
+    f1.t = 1;
+    f1.bits = 64;
+    f1.src_batch_stride = 2;
+    f1.src_row0 = 1;
+    f1.src_cols = 1;
+    launch_ntt_fwd(D.T, f1, s);
+    launch_add_poly_into(D.T, W.v.p, L + rp.all_row1, W.exp_ct1.p, rp.n_all, s);
+  }
+}
+
+// server.rs:123-151 with idx_factor 1, idx_offset 0, reading the inputs v[2b+1] in place and writing
+// the GSW matrices into the right half of fold_mats.
+void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const int* L = D.lists.p;
+  const int nb = (int)(p.db_dim_2 * p.t_gsw);
+  if (nb == 0) return;
+  const int four_t = (int)(4 * p.t_gsw);
+  launch_copy_polys(W.fold_mats.p, L + D.gsw_out_odd, four_t, v_src, src_poly, 1, 2, nb, s);
+  InvDesc inv{};
+  inv.src = v_src;
+  inv.idx = src_ct;
+  inv.polys_per_idx = 2;
+  inv.idx_stride = 4 * POLY_LEN;
+  inv.poly_stride = 2 * POLY_LEN;
+  inv.crt_stride = POLY_LEN;
+  inv.z_stride = 1;
+  inv.dst = W.gsw_raw.p;
+  inv.n_polys = nb * 2;
+  launch_ntt_inv(D.T, inv, s);
+  FwdDesc f{};
+  f.src = W.gsw_raw.p;
+  f.dst = W.gsw_dig.p;
+  f.n_out = nb * 2 * (int)p.t_conv;
+  f.rdim = 2;
+  f.cols = 1;
+  f.t = (int)p.t_conv;
+  f.bits = (int)p.bits_per(p.t_conv);
+  f.src_batch_stride = 2;
+  f.src_row0 = 0;
+  f.src_cols = 1;
+  launch_ntt_fwd(D.T, f, s);
+  MacDesc m{};
+  m.A = pp.all.p + pp.off_conv * 2 * POLY_LEN;
+  m.B = W.gsw_dig.p;
+  m.out = W.fold_mats.p;
+  m.out_idx = L + D.gsw_out_even;
+  m.R = 2;
+  m.K = 2 * (int)p.t_conv;
+  m.batch_inner = nb;
+  m.batch_outer = 1;
+  m.B_inner_stride = 2 * p.t_conv;
+  m.split_k = m.K;
+  m.out_row_stride = four_t;
+  launch_mac(D.T, m, s);
+}
+
+void run_folding_neg(Workspace& W) {
+  const Params& p = *W.P;
+  launch_folding_neg(W.D->T, W.fold_mats.p, W.D->gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), W.stream);
+}
+
+// Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  if (!p.expand_queries) throw ArgError("direct_upload (non-expanded) queries are not supported by this build");
+  if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
+  if (p.db_dim_2 == 0 && p.t_exp_left != p.t_exp_right) throw ArgError("nu_2 == 0 requires t_exp_left == t_exp_right (server.rs:573)");
+  W.ensure_expand();
+  hipStream_t s = W.stream;
+  // row 0 = Q - (rng.gen::<u64>() % Q) (client.rs:47-49), row 1 from the wire
+  chacha20_keystream_u64(query, W.h_query, POLY_LEN);
+  for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - (W.h_query[i] % p.modulus);
+  memcpy(W.h_query + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
+  HIP_CHECK(hipMemcpyAsync(W.q_raw.p, W.h_query, 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, s));
+  FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};  // v[0] = query.ct.ntt()  (server.rs:545)
+  launch_ntt_fwd(D.T, f, s);
+  const size_t g = p.g();
+  run_coefficient_expansion(W, pp, g);
+  const int* L = D.lists.p;
+  if (p.db_dim_2 > 0) {
+    launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+    run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+    run_folding_neg(W);
+  } else {
+    launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), s);  // server.rs:574-576
+  }
+}
+
+void run_sweep(Workspace& W, const sp_db& db) {
+  const Params& p = *W.P;
+  W.ensure_sweep();
+  SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), db.j0, db.nj};
+  launch_sweep(W.D->T, d, W.stream);
+}
+
+// fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
+// result ct of plane i ends up at the returned buffer + i*2N.
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const int two_t = (int)(2 * p.t_gsw);
+  int cur = num_cts;
+  int further = 0;
+  while (((int)1 << further) < num_cts) further++;
+  for (int d = 0; d < further; d++) {
+    const int half = cur / 2;
+    FwdDesc f{};
+    f.src = X;
+    f.dst = W.fold_dig.p;
+    f.n_out = np * cur * two_t;
+    f.rdim = 2;
+    f.cols = 1;
+    f.t = (int)p.t_gsw;
+    f.bits = (int)p.bits_per(p.t_gsw);
+    f.src_batch_stride = 2;
+    f.src_row0 = 0;
+    f.src_cols = 1;
+    launch_ntt_fwd(D.T, f, s);
+    MacDesc m{};
+    m.A = W.fold_mats.p + (size_t)(further - 1 - d) * 2 * 2 * two_t * 2 * POLY_LEN;
+    m.B = W.fold_dig.p;
+    m.out = W.fold_ntt.p;
+    m.R = 2;
+    m.K = 2 * two_t;
+    m.batch_inner = half;
+    m.batch_outer = np;
+    m.B_inner_stride = two_t;
+    m.B_outer_stride = (long)cur * two_t;
+    m.split_k = two_t;
+    m.split_off = (long)half * two_t;
+    m.out_batch_stride = 2;
+    m.out_row_stride = 1;
+    launch_mac(D.T, m, s);
+    InvDesc inv{};
+    inv.src = W.fold_ntt.p;
+    inv.poly_stride = 2 * POLY_LEN;
+    inv.crt_stride = POLY_LEN;
+    inv.z_stride = 1;
+    inv.dst = Y;
+    inv.n_polys = np * half * 2;
+    launch_ntt_inv(D.T, inv, s);
+    std::swap(X, Y);
+    cur = half;
+  }
+  return X;
+}
+
+// pack (server.rs:429-468) for all instances, then .raw() (server.rs:736) into pack_raw
+void run_pack(Workspace& W, const sp_pp& pp) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const int* L = D.lists.p;
+  const int n = (int)p.n, tc = (int)p.t_conv;
+  const int nb = (int)p.planes();
+  FwdDesc f{};
+  f.src = W.final_cts.p;
+  f.src_idx = L + D.pack_src_ct;
+  f.dst = W.pack_dig.p;
+  f.n_out = nb * tc;
+  f.rdim = 1;
+  f.cols = 1;
+  f.t = tc;
+  f.bits = (int)p.bits_per(tc);
+  f.src_batch_stride = 2;
+  f.src_row0 = 0;
+  f.src_cols = 1;
+  launch_ntt_fwd(D.T, f, s);
+  MacDesc m{};
+  m.A = pp.pack_cat.p;
+  m.B = W.pack_dig.p;
+  m.out = W.pack_res.p;
+  m.out_idx = L + D.pack_out;
+  m.R = n + 1;
+  m.K = n * tc;
+  m.batch_inner = (int)p.instances * n;
+  m.batch_outer = 1;
+  m.B_inner_stride = (long)n * tc;
+  m.split_k = m.K;
+  m.out_row_stride = n;
+  launch_mac(D.T, m, s);
+  FwdDesc f2 = f;
+  f2.dst = W.pack_ct2.p;
+  f2.n_out = nb;
+  f2.t = 1;
+  f2.bits = 64;
+  f2.src_row0 = 1;
+  launch_ntt_fwd(D.T, f2, s);
+  launch_add_poly_into(D.T, W.pack_res.p, L + D.pack_row, W.pack_ct2.p, nb, s);
+  InvDesc inv{};
+  inv.src = W.pack_res.p;
+  inv.poly_stride = 2 * POLY_LEN;
+  inv.crt_stride = POLY_LEN;
+  inv.z_stride = 1;
+  inv.dst = W.pack_raw.p;
+  inv.n_polys = (int)(p.instances * (p.n + 1) * p.n);
+  launch_ntt_inv(D.T, inv, s);
+}
+
+// from_ntt of the first-dimension outputs + fold, for every plane (server.rs:707-711, 731)
+void run_fold_all(Workspace& W, bool premod) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const size_t pg = W.plane_group();
+  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
+    const int np = (int)std::min(pg, p.planes() - pg0);
+    InvDesc inv{};
+    inv.src = W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per();
+    inv.sweep_np = (int)p.num_per();
+    inv.dst = W.foldX.p;
+    inv.n_polys = np * (int)p.num_per() * 2;
+    inv.premod = premod ? 1 : 0;
+    launch_ntt_inv(D.T, inv, s);
+    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per());
+    if (p.num_per() == 1) {
+      HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    } else {
+      // after the last level the np results are dense: [np][1 ct]
+      HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+    }
+  }
+}
+
+// ---- encode (server.rs:470-503) on the host: rescale (arith.rs:429-444) + LSB-first bit packing
+static inline u64 rescale_coeff(u64 a, u64 inp_mod, u64 out_mod) {
+  typedef __int128 i128;
+  const int64_t im = (int64_t)inp_mod;
+  int64_t v = (int64_t)(a % inp_mod);
+  if (v >= im / 2) v -= im;
+  const int64_t sign = v >= 0 ? 1 : -1;
+  i128 num = (i128)v * (i128)out_mod + (i128)(sign * (im / 2));
+  i128 res = num / (i128)inp_mod;  // truncating, as Rust's i128 `/`
+  const i128 om = (i128)out_mod;
+  res = (res + (i128)((inp_mod / out_mod) * out_mod) + 2 * om) % om;
+  return (u64)((res + om) % om);
+}
+
+size_t encode_response(const Params& p, const u64* packed, uint8_t* out) {
+  const u64 q1 = 4 * p.pt_modulus;
+  size_t q1_bits = 0;
+  while (((u64)1 << q1_bits) < q1) q1_bits++;
+  const u64 q2 = p.q2();
+  const size_t q2_bits = p.q2_bits;
+  const size_t total = p.response_bytes();
+  memset(out, 0, total);
+  u64* w = reinterpret_cast<u64*>(out);  // caller guarantees 8-byte alignment of `out`? no: use memcpy below
+  (void)w;
+  std::vector<u64> words(total / 8, 0);
+  size_t bit = 0;
+  auto put = [&](u64 val, size_t nbits) {
+    val &= (nbits >= 64) ? ~0ULL : (((u64)1 << nbits) - 1);
+    size_t wi = bit >> 6, off = bit & 63;
+    words[wi] |= val << off;
+    if (off + nbits > 64) words[wi + 1] |= val >> (64 - off);
+    bit += nbits;
+  };
+  const size_t mat = (p.n + 1) * p.n * POLY_LEN;
+  for (size_t inst = 0; inst < p.instances; inst++) {
+    const u64* m = packed + inst * mat;
+    for (size_t i = 0; i < p.n * POLY_LEN; i++) put(rescale_coeff(m[i], p.modulus, q2), q2_bits);
+    const u64* rest = m + p.n * POLY_LEN;
+    for (size_t i = 0; i < p.n * p.n * POLY_LEN; i++) put(rescale_coeff(rest[i], p.modulus, q1), q1_bits);
+  }
+  memcpy(out, words.data(), total);
+  return total;
+}
+
+void run_finish(Workspace& W, const sp_pp& pp, bool premod) {
+  const Params& p = *W.P;
+  W.ensure_finish();
+  run_fold_all(W, premod);
+  HIP_CHECK(hipEventRecord(W.ev[3], W.stream));
+  run_pack(W, pp);
+  HIP_CHECK(hipMemcpyAsync(W.h_packed, W.pack_raw.p, W.h_packed_words * sizeof(u64), hipMemcpyDeviceToHost, W.stream));
+  HIP_CHECK(hipEventRecord(W.ev[4], W.stream));
+  (void)p;
+}
+
+}  // namespace spiral

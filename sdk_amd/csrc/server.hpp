@@ -1,0 +1,135 @@
+// Host-side orchestration of the Spiral answer path on one MI355X.
+// Mirrors the spiral-rs server surface (lib/spiral-rs/src/server.rs): PublicParameters / Query
+// deserialisation (client.rs:212-259, 303-329), expand_query, multiply_reg_by_database,
+// fold_ciphertexts, pack, encode, process_query -- with all polynomial data device-resident.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+#include "params.hpp"
+
+namespace spiral {
+
+struct HipError : std::runtime_error {
+  explicit HipError(const std::string& s) : std::runtime_error(s) {}
+};
+struct ArgError : std::runtime_error {
+  explicit ArgError(const std::string& s) : std::runtime_error(s) {}
+};
+struct OomError : std::runtime_error {
+  explicit OomError(const std::string& s) : std::runtime_error(s) {}
+};
+
+void hip_check(hipError_t e, const char* what, const char* file, int line);
+#define HIP_CHECK(x) ::spiral::hip_check((x), #x, __FILE__, __LINE__)
+
+// RAII device buffer
+template <typename T>
+struct DevBuf {
+  T* p = nullptr;
+  size_t n = 0;
+  DevBuf() {}
+  explicit DevBuf(size_t count) { alloc(count); }
+  DevBuf(const DevBuf&) = delete;
+  DevBuf& operator=(const DevBuf&) = delete;
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf& operator=(DevBuf&& o) noexcept {
+    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    return *this;
+  }
+  ~DevBuf() { release(); }
+  void alloc(size_t count) {
+    release();
+    if (count == 0) return;
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      throw OomError(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
+    }
+    p = (T*)q;
+    n = count;
+  }
+  void ensure(size_t count) { if (count > n) alloc(count); }
+  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  size_t bytes() const { return n * sizeof(T); }
+};
+
+// ChaCha20 keystream as rand_chacha 0.3.1's ChaCha20Rng::from_seed produces it (key = seed, 64-bit
+// block counter from 0, stream 0); u64 = two consecutive u32 words, low first (client.rs:47-49).
+void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count);
+
+// Per-(Params, device) constants: twiddles, -x^(N-2^r) polys (params.rs:98-107), NTT of the GSW
+// gadget (server.rs:509), expansion schedules and the index lists the batched kernels consume.
+struct RoundPlan {
+  int num_in = 0, t_auto = 0;
+  int n_all = 0, n_left = 0, n_right = 0;
+  // offsets (in ints) into DeviceState::lists
+  size_t all_ct = 0;      // global ct index of each active ct
+  size_t all_row1 = 0;    // poly index (ct*2+1) of each active ct
+  size_t left_pos = 0;    // position within the active list of each left-group ct
+  size_t left_out = 0;    // poly index (ct*2) of each left-group ct
+  size_t right_pos = 0, right_out = 0;
+};
+
+struct DeviceState {
+  int device = -1;
+  DevTables T;
+  DevBuf<u32> tw;
+  DevBuf<u32> neg1;        // [g][1 poly]
+  DevBuf<u32> gadget_gsw;  // [2][2 t_gsw] polys
+  DevBuf<int> lists;
+  std::vector<RoundPlan> rounds;
+  size_t max_all = 0, max_left = 0, max_right = 0;
+  // regev_to_gsw lists (batch b = d*t_gsw + j)
+  size_t gsw_src_ct = 0;     // ct index 2b+1 (or b when nu_2 == 0: unused)
+  size_t gsw_src_poly = 0;   // poly index (2b+1)*2
+  size_t gsw_out_even = 0;   // fold_mats poly index of column 2j (row 0)
+  size_t gsw_out_odd = 0;    // column 2j+1
+  // pack lists (batch b = (inst*n + c)*n + r)
+  size_t pack_src_ct = 0;    // plane index inst*n*n + r*n + c
+  size_t pack_out = 0;       // result poly index inst*(n+1)*n + c           (per (inst,c))
+  size_t pack_row = 0;       // result poly index inst*(n+1)*n + (1+r)*n + c (per b)
+};
+
+struct Workspace;
+
+}  // namespace spiral
+
+// ---- the opaque C-ABI handle types --------------------------------------------------------------
+struct sp_params {
+  spiral::Params p;
+  std::mutex mu;
+  std::vector<std::unique_ptr<spiral::DeviceState>> dev;        // one per device used
+  std::vector<std::unique_ptr<spiral::Workspace>> ws_pool;      // idle workspaces
+  spiral::DeviceState& device_state();                          // for the current device
+  std::unique_ptr<spiral::Workspace> acquire_ws();
+  void release_ws(std::unique_ptr<spiral::Workspace> ws);
+  ~sp_params();
+};
+
+struct sp_pp {
+  const sp_params* params = nullptr;
+  int device = -1;
+  // NTT-form matrices, device resident
+  spiral::DevBuf<spiral::u32> all;  // wire order: v_packing[n], v_expansion_left[g], [v_expansion_right], v_conversion
+  size_t n_polys = 0;
+  size_t off_packing = 0, off_left = 0, off_right = 0, off_conv = 0;  // poly offsets
+  bool has_right = false;
+  spiral::DevBuf<spiral::u32> pack_cat;  // [(n+1)][n*t_conv] = [W_0 | W_1 | ...]
+};
+
+struct sp_db {
+  const sp_params* params = nullptr;
+  int device = -1;
+  int shard = 0, num_shards = 1;
+  int j0 = 0, nj = 0;
+  spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii]
+  std::mutex mu;
+};

@@ -1,0 +1,272 @@
+"""GPU parity: every stage of the HIP answer path, called through the C ABI, against the CPU oracle on
+identical seeded inputs -- bit-exact (integer arithmetic).  Mirrors the reference's test ladder
+(SURVEY.md App. F): L0 kernels, stage functions, end-to-end response bytes, then decrypt."""
+import numpy as np
+import pytest
+
+from conftest import C1, FAST, FAST56, P2, SERVER_DEFAULT, SMALL_INST2
+
+pytestmark = pytest.mark.gpu
+
+Q0, Q1 = 268369921, 249561089
+Q = Q0 * Q1
+
+
+@pytest.fixture(scope="module")
+def sp():
+    import sdk_amd
+    assert sdk_amd.lib().sp_device_count() >= 1, "no HIP device visible"
+    return sdk_amd
+
+
+def _pair(sp, oracle_mod, cfg):
+    return sp.Params(cfg), oracle_mod.Params(cfg)
+
+
+# ---------------------------------------------------------------------------------------- L0
+def test_params_tables_match(sp, oracle_mod):
+    p, o = _pair(sp, oracle_mod, P2)
+    for c in range(2):
+        for w in range(4):
+            assert (p.ntt_table(c, w) == o.ntt_table(c, w)).all()
+    for k in ("setup_bytes", "query_bytes", "g", "stop_round", "num_items", "modulus"):
+        assert p.get(k) == o.get(k)
+
+
+def _edge_polys(rng, n_random=6):
+    N = 2048
+    polys = [np.zeros(2 * N, dtype=np.uint64)]
+    a = np.zeros(2 * N, dtype=np.uint64); a[0] = 100; a[N] = 100; polys.append(a)
+    polys.append(np.concatenate([np.full(N, Q0 - 1, dtype=np.uint64), np.full(N, Q1 - 1, dtype=np.uint64)]))
+    polys.append(np.full(2 * N, 100, dtype=np.uint64))
+    for _ in range(n_random):
+        polys.append(np.concatenate([rng.integers(0, Q0, N, dtype=np.uint64), rng.integers(0, Q1, N, dtype=np.uint64)]))
+    return np.concatenate(polys)
+
+
+def test_ntt_forward_inverse(sp, oracle_mod):
+    p, o = _pair(sp, oracle_mod, FAST)
+    x = _edge_polys(np.random.default_rng(1))
+    f_gpu = sp.ntt_forward(p, x)
+    assert (f_gpu == o.ntt_forward(x)).all()
+    assert (sp.ntt_inverse(p, f_gpu) == x).all()
+    assert (sp.ntt_inverse(p, x) == o.ntt_inverse(x)).all()
+    # ntt.rs:400-423 KATs through the GPU
+    assert (f_gpu[2 * 2048:4 * 2048] == 100).all()
+
+
+def test_to_ntt_from_ntt(sp, oracle_mod):
+    p, o = _pair(sp, oracle_mod, FAST)
+    rng = np.random.default_rng(2)
+    raw = rng.integers(0, Q, 12 * 2048, dtype=np.uint64)
+    raw[:2048] = 0
+    raw[2048:4096] = Q           # the Q-for-zero values of automorph/invert
+    raw[4096:6144] = Q - 1
+    raw[6144] = (1 << 64) - 1    # Barrett on the full u64 range (arith.rs:122-134)
+    ntt_gpu = sp.to_ntt(p, raw)
+    assert (ntt_gpu == o.to_ntt(raw)).all()
+    back = sp.from_ntt(p, ntt_gpu)
+    assert (back == o.from_ntt(ntt_gpu)).all()
+    assert (back[6145:] == raw[6145:] % np.uint64(Q)).all()
+
+
+def test_multiply(sp, oracle_mod):  # poly.rs:731-743 + random 2x16 * 16x1 (the fold shape)
+    p, o = _pair(sp, oracle_mod, FAST)
+    m1 = np.zeros(2048, dtype=np.uint64); m1[1] = 100
+    m2 = np.zeros(2048, dtype=np.uint64); m2[1] = 7
+    m3 = sp.from_ntt(p, sp.multiply(p, sp.to_ntt(p, m1), 1, 1, sp.to_ntt(p, m2), 1))
+    assert int(m3[2]) == 700 and int(m3.sum()) == 700
+    rng = np.random.default_rng(3)
+    a = _rand_ntt(rng, 2 * 16)
+    b = _rand_ntt(rng, 16 * 3)
+    assert (sp.multiply(p, a, 2, 16, b, 3) == o.multiply(a, 2, 16, b, 3)).all()
+
+
+def _rand_ntt(rng, n_polys):
+    N = 2048
+    out = np.zeros((n_polys, 2, N), dtype=np.uint64)
+    out[:, 0] = rng.integers(0, Q0, (n_polys, N), dtype=np.uint64)
+    out[:, 1] = rng.integers(0, Q1, (n_polys, N), dtype=np.uint64)
+    return out.reshape(-1)
+
+
+def test_automorph_and_gadget(sp, oracle_mod):
+    import sdk_amd.spiral as S
+    p, o = _pair(sp, oracle_mod, FAST56)
+    rng = np.random.default_rng(4)
+    a = rng.integers(0, Q, 3 * 2048, dtype=np.uint64)
+    a[:2048:7] = 0
+    for t in (2049, 1025, 5, 3):
+        assert (S.automorph(p, a, t) == o.automorph(a, t)).all()
+    inp = rng.integers(0, Q, 2 * 2048, dtype=np.uint64)
+    inp[5] = Q
+    for rows_out, rdim in ((16, 2), (8, 1), (56, 1), (4, 1), (8, 2)):
+        rows_in = 2
+        g = S.gadget_invert_rdim(p, inp, rows_in, 1, rows_out, rdim)
+        assert (g == o.gadget_invert_rdim(inp, rows_in, 1, rows_out, rdim)).all(), (rows_out, rdim)
+
+
+# ------------------------------------------------------------------------------------ stages
+def _session(oracle_mod, cfg, idx, seed):
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(seed)
+    q = cl.generate_query(idx, seed + 1)
+    return o, cl, pp, q
+
+
+@pytest.mark.parametrize("cfg", [FAST, FAST56], ids=["fast", "fast56"])
+def test_pp_deserialize(sp, oracle_mod, cfg):
+    o, cl, pp, q = _session(oracle_mod, cfg, 5, 40)
+    p = sp.Params(cfg)
+    gpu = sp.PublicParameters.deserialize(p, pp).export()
+    assert (gpu == o.pp_deserialize_flat(pp)).all()
+    with pytest.raises(sp.SpiralError):
+        sp.PublicParameters.deserialize(p, pp[:-8])   # client.rs:213 assert_eq!
+
+
+@pytest.mark.parametrize("cfg,idx", [(FAST, 77), (FAST56, 300), (C1, 9999)], ids=["fast", "fast56", "c1"])
+def test_expand_query(sp, oracle_mod, cfg, idx):
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 50)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    v_reg, v_fold = sp.expand_query(p, gpp, q)
+    o_reg, o_fold = o.expand_query(pp, q)
+    assert (v_reg == o_reg).all()
+    assert (v_fold == o_fold).all()
+    assert (sp.get_v_folding_neg(p, v_fold) == o.get_v_folding_neg(o_fold)).all()
+
+
+def test_coefficient_expansion_and_regev_to_gsw(sp, oracle_mod):
+    cfg = FAST56
+    o, cl, pp, q = _session(oracle_mod, cfg, 11, 60)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    g, sr = o.g, o.stop_round
+    v = np.zeros((1 << g) * 2 * o.ntt_words, dtype=np.uint64)
+    v[:2 * o.ntt_words] = o.to_ntt(o.query_deserialize_ct(q))
+    mb = o.t_gsw * o.db_dim_2
+    v_gpu = sp.coefficient_expansion(p, gpp, v, g, sr, mb)
+    v_cpu = o.coefficient_expansion(pp, v, g, sr, mb)
+    assert (v_gpu == v_cpu).all()
+    w = 2 * o.ntt_words
+    v_gsw_inp = np.concatenate([v_cpu[(2 * i + 1) * w:(2 * i + 2) * w] for i in range(mb)])
+    flat = o.pp_deserialize_flat(pp)
+    v_conv = flat[-2 * 2 * o.t_conv * o.ntt_words:]
+    assert (sp.regev_to_gsw(p, gpp, v_gsw_inp, o.db_dim_2) == o.regev_to_gsw(v_gsw_inp, v_conv, o.db_dim_2)).all()
+
+
+@pytest.mark.parametrize("dim0,num_per", [(64, 4), (512, 32), (16, 64), (300, 128), (64, 256), (512, 1), (700, 2)])
+def test_multiply_reg_by_database_shapes(sp, oracle_mod, dim0, num_per):
+    """db sweep on random (not NTT-of-plaintext) words incl. ragged dim0 and the >255-row fold path."""
+    p, o = _pair(sp, oracle_mod, FAST)
+    rng = np.random.default_rng(dim0 * 1000 + num_per)
+    N = 2048
+    db = rng.integers(0, Q0, N * num_per * dim0, dtype=np.uint64) | (rng.integers(0, Q1, N * num_per * dim0, dtype=np.uint64) << np.uint64(32))
+    qv = rng.integers(0, Q0, N * dim0 * 2, dtype=np.uint64) | (rng.integers(0, Q1, N * dim0 * 2, dtype=np.uint64) << np.uint64(32))
+    # worst case for the u64 accumulators: all operands maximal
+    db[:num_per * dim0] = np.uint64((Q0 - 1) | ((Q1 - 1) << 32))
+    qv[:dim0 * 2] = np.uint64((Q0 - 1) | ((Q1 - 1) << 32))
+    got = sp.multiply_reg_by_database(p, db, qv, dim0, num_per)
+    exp = o.multiply_reg_by_database(db, qv, dim0, num_per)
+    assert (got == exp).all()
+
+
+def test_fold_pack_encode_stages(sp, oracle_mod):
+    cfg = FAST56
+    idx = 123
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 70)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    item, db = o.generate_random_db_and_get_item(idx)
+    v_reg, v_fold = o.expand_query(pp, q)
+    v_neg = o.get_v_folding_neg(v_fold)
+    N = 2048
+    slice_words = o.dim0 * o.num_per * N
+    cts = []
+    for trial in range(4):
+        out_cpu = o.multiply_reg_by_database(db[trial * slice_words:(trial + 1) * slice_words], v_reg)
+        out_gpu = sp.multiply_reg_by_database(p, db[trial * slice_words:(trial + 1) * slice_words], v_reg)
+        assert (out_gpu == out_cpu).all()
+        raw = o.from_ntt(out_cpu)
+        f_cpu = o.fold_ciphertexts(raw, v_fold, v_neg)[:2 * N]
+        f_gpu = sp.fold_ciphertexts(p, raw, v_fold, v_neg)[:2 * N]
+        assert (f_gpu == f_cpu).all()
+        cts.append(f_cpu)
+    v_ct = np.concatenate(cts)
+    flat = o.pp_deserialize_flat(pp)
+    v_w = flat[:o.n * (o.n + 1) * o.t_conv * o.ntt_words]
+    packed_cpu = o.pack(v_ct, v_w)
+    assert (sp.pack(p, gpp, v_ct) == packed_cpu).all()
+    praw = o.from_ntt(packed_cpu)
+    assert sp.encode(p, praw) == o.encode(praw)
+
+
+# -------------------------------------------------------------------------------- end to end
+@pytest.mark.parametrize("cfg,idx", [(FAST, 0), (FAST, 255), (FAST56, 301), (SMALL_INST2, 123),
+                                     (dict(FAST, nu_2=0, db_item_size=8192), 17),
+                                     (dict(FAST, nu_2=1), 99)],
+                         ids=["fast-0", "fast-255", "fast56", "inst2", "nu2_0", "nu2_1"])
+def test_process_query_bytes_and_decode(sp, oracle_mod, cfg, idx):
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 80 + idx)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    resp = sp.process_query(p, gpp, sp.Query.deserialize(p, q), gdb)
+    assert resp == o.process_query(pp, q, db)                 # byte-identical to the CPU restatement
+    assert cl.decode_response(resp) == o.item_to_vec(item)    # and it decodes (server.rs:1029-1042)
+    # a second query against the same registered DB (handles are reusable)
+    q2 = cl.generate_query((idx + 1) % o.num_items, 999)
+    assert sp.process_query(p, gpp, q2, gdb) == o.process_query(pp, q2, db)
+
+
+def test_process_query_c1(sp, oracle_mod):
+    """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
+    idx = 12345
+    o, cl, pp, q = _session(oracle_mod, C1, idx, 5)
+    p = sp.Params(C1)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    resp = sp.process_query(p, gpp, q, gdb)
+    assert resp == o.process_query(pp, q, db)
+    assert cl.decode_response(resp) == o.item_to_vec(item)
+
+
+def test_bad_lengths_raise(sp, oracle_mod):
+    o, cl, pp, q = _session(oracle_mod, FAST, 1, 7)
+    p = sp.Params(FAST)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p)
+    with pytest.raises(sp.SpiralError):
+        sp.process_query(p, gpp, q[:-1], gdb)          # client.rs:304 assert_eq!
+    with pytest.raises(sp.SpiralError):
+        gdb.load(np.zeros(10, dtype=np.uint64))
+
+
+def test_row_sharded_partials_sum_to_full(sp, oracle_mod):
+    """Multi-GPU split on one GPU: G shards' partial buffers summed element-wise == unsharded result."""
+    import ctypes as C
+    import torch
+    cfg, idx = FAST56, 200
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    expect = o.process_query(pp, q, db)
+    for G in (2, 4):
+        shards = [sp.Database(p, s, G).load(db) for s in range(G)]
+        runs = [sp.QueryRun(p, gpp, q).sweep(shards[s]) for s in range(G)]
+        words = runs[0].partial_words()
+        total = torch.zeros(words, dtype=torch.int32, device="cuda")
+        for r in runs:
+            r.sync()
+            buf = torch.empty(words, dtype=torch.int32, device="cuda")
+            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(r.partial_ptr()),
+                                                           C.c_size_t(words * 4), C.c_int(3))
+            total += buf
+        torch.cuda.synchronize()
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(runs[0].partial_ptr()), C.c_void_p(total.data_ptr()),
+                                                       C.c_size_t(words * 4), C.c_int(3))
+        assert runs[0].finish() == expect
