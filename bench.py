@@ -1,0 +1,225 @@
+#!/usr/bin/env python
+"""bench.py -- queries/s of the MI355X Spiral PIR answer path (BASELINE.json metric).
+
+One "step" = one full process_query (Query::deserialize + expand_query + db sweep + fold + pack +
+encode, server.rs:650-741) of ONE query over the resident synthetic database.
+  N = 1 : BASELINE.json configs[1] -- 2^20 items x 256 B (nu = (9,11), 64 GiB encoded DB in HBM).
+  N > 1 : the same database row-sharded over the N GPUs (dim0/N first-dimension rows each); every rank
+          sweeps its shard, the partial Regev ciphertexts (u32 residues) are summed onto rank 0 with one
+          RCCL reduce over xGMI, rank 0 folds/packs/encodes.  Strong scaling: total work is fixed.
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region (the 16 KiB query and
+the 20 KiB response are the only host traffic inside a step).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1]: literal 2^20 x 256 B (SURVEY.md 8(d) "C2"); gadget set of CFG_20_256 (util.rs:7-20)
+    "c2": {"n": 2, "nu_1": 9, "nu_2": 11, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
+    # configs[0]: 2^14 x 256 B
+    "c1": {"n": 2, "nu_1": 9, "nu_2": 5, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
+    # the reference's own packed preset CFG_20_256 (2^20 x 256 B packed into 2^15 x 8 KiB)
+    "p2": {"n": 2, "nu_1": 9, "nu_2": 6, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 8192},
+    "fast": {"n": 2, "nu_1": 6, "nu_2": 2, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+             "t_exp_right": 8, "instances": 1, "db_item_size": 8192},
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
+Q = 268369921 * 249561089
+
+
+def synthetic_wire_bytes(n_bytes, seed):
+    """A syntactically valid serialized pp / query: 32-byte seed then LE u64 words < Q.  The answer path's
+    arithmetic is data-independent, so throughput on these equals throughput on real ciphertexts; parity on
+    real ciphertexts is what tests/ checks."""
+    rng = np.random.default_rng(seed)
+    body = rng.integers(0, Q, (n_bytes - 32) // 8, dtype=np.uint64)
+    return rng.integers(0, 256, 32, dtype=np.uint8).tobytes() + body.tobytes()
+
+
+def sweep_algorithmic_bytes(cfg, shards):
+    """BASELINE.md section 2 / SURVEY.md 8(d): per query, per GPU shard (reference 8-byte word format)."""
+    N = 2048
+    T = cfg["instances"] * cfg["n"] ** 2
+    dim0, num_per = 1 << cfg["nu_1"], 1 << cfg["nu_2"]
+    return T * N * num_per * (dim0 // shards) * 8 + T * N * (dim0 // shards) * 2 * 8 + T * num_per * 4 * N * 8
+
+
+class _DevArray:
+    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
+
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
+
+
+def cpu_baseline(cfg_name, cfg):
+    """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample."""
+    import oracle
+    o = oracle.Params(cfg)
+    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    cl = oracle.Client(o)
+    pp = cl.generate_keys(11)
+    q = cl.generate_query(12345 % o.num_items, 12)
+    N, dim0, num_per, planes = 2048, o.dim0, o.num_per, o.instances * o.n * o.n
+    t0 = time.time()
+    v_reg, v_fold = o.expand_query(pp, q)
+    v_neg = o.get_v_folding_neg(v_fold)
+    t_expand = time.time() - t0
+    # sweep: nz z-rows of one plane on random words (the u128 MAC loop is data independent)
+    rng = np.random.default_rng(5)
+    nz = max(1, min(N, (1 << 25) // (num_per * dim0)))
+    dbs = rng.integers(0, 1 << 28, nz * num_per * dim0, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
+    t0 = time.time()
+    oracle.sweep_rows(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
+    t_sweep = (time.time() - t0) * (N / nz) * planes
+    # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
+    k = min(o.db_dim_2, 5)
+    leaves = 1 << k
+    cts_ntt = np.concatenate([rng.integers(0, 249561089, leaves * 2 * 2 * N, dtype=np.uint64)])
+    t0 = time.time()
+    raw = o.from_ntt(cts_ntt)
+    if k > 0:
+        o.fold_ciphertexts(raw, v_fold[:k * 2 * 2 * o.t_gsw * 2 * N], v_neg[:k * 2 * 2 * o.t_gsw * 2 * N], nu=k)
+    t_sub = time.time() - t0
+    t_fold = t_sub * (num_per / leaves) * planes
+    total = t_expand + t_sweep + t_fold
+    return {
+        "value": 1.0 / total, "unit": "queries/s", "cores": threads, "kind": "port",
+        "sample": ("C++ restatement of spiral-rs (oracle/), config %s: expand_query+get_v_folding_neg in full (%.2f s, "
+                   "%d OpenMP threads = the reference's rayon loops); multiply_reg_by_database timed on %d of %d z-rows "
+                   "of one plane and scaled x%d planes (%.1f s/query, single thread as server.rs:682-694); "
+                   "from_ntt+fold_ciphertexts timed on a %d-leaf subtree and scaled to %d leaves x %d planes (%.1f s/query, "
+                   "single thread); pack/encode omitted (<1%%)" %
+                   (cfg_name, t_expand, threads, nz, N, planes, t_sweep, leaves, num_per, planes, t_fold)),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--config", default=os.environ.get("SPIRAL_BENCH_CONFIG", "c2"), choices=sorted(CONFIGS))
+    ap.add_argument("--sweep-iters", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    import sdk_amd as sp
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    torch.cuda.set_device(local_rank)
+    if sp.lib().sp_set_device(local_rank) != 0:
+        raise SystemExit("sp_set_device failed")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    cfg = CONFIGS[args.config]
+    p = sp.Params(cfg)
+    pp = sp.PublicParameters.deserialize(p, synthetic_wire_bytes(p.setup_bytes(), 1))
+    queries = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
+    db = sp.Database(p, rank, world).fill_synthetic(0x123456789)  # util.rs:171-173 static seed
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def step(i):
+        run = sp.QueryRun(p, pp, queries[i % len(queries)])
+        run.sweep(db)
+        if world > 1:
+            run.sync()
+            part = torch.as_tensor(_DevArray(run.partial_ptr(), run.partial_words()), device="cuda")
+            dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI; 8 * (q-1) < 2^31
+            torch.cuda.synchronize()
+            out = run.finish() if rank == 0 else None
+        else:
+            out = run.finish()
+        t = run.timings() if out is not None else None
+        run.free()
+        return out, t
+
+    for i in range(args.warmup):
+        step(i)
+    barrier()
+    t0 = time.perf_counter()
+    stage = np.zeros(4)
+    for i in range(args.steps):
+        out, t = step(i)
+        if t is not None:
+            stage += np.array(t)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
+    run = sp.QueryRun(p, pp, queries[0])
+    sweep_ms = run.bench_sweep(db, args.sweep_iters)
+    run.free()
+    alg_bytes = sweep_algorithmic_bytes(cfg, world)
+    achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "PIR queries/sec (single query, full answer path) on 2^%d items x %d B" %
+                      (cfg["nu_1"] + cfg["nu_2"], cfg["db_item_size"]),
+            "value": args.steps / elapsed,
+            "unit": "queries/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_per_step,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "u64 accumulate of u32xu32 products mod 28-bit primes (u32 NTT butterflies)",
+            "data": "synthetic",
+            "config": {"workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
+                                   "%s" % (args.config, json.dumps(cfg, sort_keys=True),
+                                           p.db_words * 8 / 2**30,
+                                           "unsharded" if world == 1 else "row-sharded dim0/%d per GPU + RCCL reduce" % world),
+                       "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
+                                    "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
+            "roofline": {"bound": "hbm", "kernel": sp.lib().sp_device_count() and ("k_sweep_wide" if cfg["nu_2"] >= 7 else "k_sweep_narrow"),
+                         "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": sweep_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.config, cfg)
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -32,6 +32,10 @@ def build(force=False):
 def lib():
     global _LIB
     if _LIB is None:
+        # libgomp reads this when it is loaded; a 256-thread team on a shared host makes the small
+        # parallel loops of the restatement slower, not faster
+        os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()

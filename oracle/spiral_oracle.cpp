@@ -30,9 +30,11 @@ u64 multiply_uint_mod(u64 a, u64 b, u64 modulus) { return (u64)(((u128)a * (u128
 
 u64 log2_floor(u64 a) { return 63 - (u64)__builtin_clzll(a); }
 
-u64 log2_ceil(u64 a) { return (u64)std::ceil(std::log2((double)a)); }
+// Rust's float -> integer `as` casts saturate: ceil(log2(0.0)) = -inf casts to 0 (relevant for
+// stop_round() when nu_2 == 0); the same cast is undefined behaviour in C++, so spell it out.
+u64 log2_ceil(u64 a) { return a == 0 ? 0 : (u64)std::ceil(std::log2((double)a)); }
 
-static size_t log2_ceil_usize(size_t a) { return (size_t)std::ceil(std::log2((double)a)); }
+static size_t log2_ceil_usize(size_t a) { return a == 0 ? 0 : (size_t)std::ceil(std::log2((double)a)); }
 
 // arith.rs:41-67
 u64 exponentiate_uint_mod(u64 operand, u64 exponent, u64 modulus) {

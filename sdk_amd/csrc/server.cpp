@@ -318,8 +318,9 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
       f.src_row0 = 0;
       f.src_cols = 1;
       launch_ntt_fwd(D.T, f, s);
-      const size_t woff = side == 0 ? pp.off_left + r * 2 * tl
-                                    : (pp.has_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl);
+      // nu_2 == 0: expand_query passes v_w_left for both sides (server.rs:573)
+      const bool use_right = side == 1 && pp.has_right && p.db_dim_2 > 0;
+      const size_t woff = use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl;
       MacDesc m{};
       m.A = pp.all.p + woff * 2 * POLY_LEN;
       m.B = W.exp_dig.p;

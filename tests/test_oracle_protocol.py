@@ -33,6 +33,11 @@ def test_full_protocol_t_exp_right_56(oracle_mod):
     _full_protocol(oracle_mod, FAST56, 301)
 
 
+@pytest.mark.parametrize("nu2", [0, 1])
+def test_full_protocol_shallow_second_dimension(oracle_mod, nu2):
+    _full_protocol(oracle_mod, dict(FAST, nu_2=nu2), 17)
+
+
 def test_full_protocol_two_instances(oracle_mod):
     _full_protocol(oracle_mod, SMALL_INST2, 123)
 
