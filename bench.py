@@ -57,13 +57,6 @@ def sweep_algorithmic_bytes(cfg, shards):
     return T * N * num_per * (dim0 // shards) * 8 + T * N * (dim0 // shards) * 2 * 8 + T * num_per * 4 * N * 8
 
 
-class _DevArray:
-    """Expose a raw device pointer to torch through __cuda_array_interface__ (no copy)."""
-
-    def __init__(self, ptr, n_words):
-        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i4", "data": (ptr, False), "version": 2}
-
-
 def cpu_baseline(cfg_name, cfg):
     """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample."""
     import oracle
@@ -119,6 +112,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
+    from sdk_amd.sharding import partial_tensor, reduce_partials
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -151,8 +145,7 @@ def main():
         run.sweep(db)
         if world > 1:
             run.sync()
-            part = torch.as_tensor(_DevArray(run.partial_ptr(), run.partial_words()), device="cuda")
-            dist.reduce(part, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI; 8 * (q-1) < 2^31
+            reduce_partials(partial_tensor(run), dst=0)  # RCCL ncclSum over xGMI; 8 * (q-1) < 2^31
             torch.cuda.synchronize()
             out = run.finish() if rank == 0 else None
         else:

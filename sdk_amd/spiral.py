@@ -44,6 +44,12 @@ def lib():
         if not os.path.exists(so):
             raise SpiralError(f"{so} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
                               "(hipcc --offload-arch=gfx950); sdk_amd has no CPU fallback")
+        # torch-rocm bundles its own libamdhip64; two HIP runtimes in one process do not share devices
+        # ("No HIP GPUs are available").  Importing torch first makes the loader reuse its copy for us.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(so)
         L.sp_last_error.restype = C.c_char_p
         L.sp_params_from_json.restype = C.c_void_p

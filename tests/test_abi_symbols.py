@@ -1,0 +1,69 @@
+"""The C-ABI library loads on a GPU-less host and exports every symbol include/spiral_hip.h declares;
+host-only entry points (params, sizes, encode, synthetic-word hash) work without a device, and compute
+entry points fail loudly (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "spiral_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(sp_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported():
+    import sdk_amd
+    lib = C.CDLL(sdk_amd.library_path())
+    names = _declared()
+    assert len(names) >= 40
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_host_only_entry_points(oracle_mod):
+    import sdk_amd as sp
+    from conftest import C2, FAST, P2
+    for cfg in (FAST, P2, C2):
+        p, o = sp.Params(cfg), oracle_mod.Params(cfg)
+        for k in ("setup_bytes", "query_bytes", "g", "stop_round", "num_items", "modulus", "modulus_log2"):
+            assert p.get(k) == o.get(k), (k, cfg)
+        assert p.get("response_bytes") == o.response_bytes()
+        for c in range(2):
+            for w in range(4):
+                assert (p.ntt_table(c, w) == o.ntt_table(c, w)).all()
+    # single-quoted preset strings as the reference writes them (util.rs:7-20)
+    p = sp.params_from_json("{'n': 2, 'nu_1': 9, 'nu_2': 6, 'p': 256, 'q2_bits': 20, 's_e': 87.6, 't_gsw': 8, "
+                            "'t_conv': 4, 't_exp_left': 8, 't_exp_right': 56, 'instances': 1, 'db_item_size': 8192 }")
+    assert p.setup_bytes() == 8126496 and p.query_bytes() == 16416
+    with pytest.raises(sp.SpiralError):
+        sp.params_from_json('{"n": 2}')
+    with pytest.raises(sp.SpiralError):
+        sp.params_from_json("not json")
+    # encode (server.rs:470-503) is host code in the product too
+    rng = np.random.default_rng(1)
+    o = oracle_mod.Params(FAST)
+    packed = rng.integers(0, 66974689739603969, 3 * 2 * 2048, dtype=np.uint64)
+    packed[:5] = [0, 1, 66974689739603968, 33487344869801984, 33487344869801985]
+    assert sp.encode(sp.Params(FAST), packed) == o.encode(packed)
+    # synthetic DB word hash: C and numpy agree
+    from sdk_amd.spiral import synth_word, synth_words
+    idx = np.array([0, 1, 2**31, 2**40 + 12345], dtype=np.uint64)
+    assert [int(x) for x in synth_words(77, idx)] == [synth_word(77, int(i)) for i in idx]
+
+
+def test_compute_fails_loudly_without_gpu():
+    import sdk_amd as sp
+    from conftest import FAST
+    if sp.lib().sp_device_count() > 0:
+        pytest.skip("a GPU is present")
+    p = sp.Params(FAST)
+    with pytest.raises(sp.SpiralError):
+        sp.to_ntt(p, np.zeros(2048, dtype=np.uint64))
+    with pytest.raises(sp.SpiralError):
+        sp.Database(p)

@@ -247,26 +247,24 @@ def test_bad_lengths_raise(sp, oracle_mod):
 
 def test_row_sharded_partials_sum_to_full(sp, oracle_mod):
     """Multi-GPU split on one GPU: G shards' partial buffers summed element-wise == unsharded result."""
-    import ctypes as C
     import torch
+    from sdk_amd.sharding import partial_tensor
     cfg, idx = FAST56, 200
     o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
     p = sp.Params(cfg)
     item, db = o.generate_random_db_and_get_item(idx)
     gpp = sp.PublicParameters.deserialize(p, pp)
     expect = o.process_query(pp, q, db)
-    for G in (2, 4):
+    for G in (2, 4, 8):
         shards = [sp.Database(p, s, G).load(db) for s in range(G)]
         runs = [sp.QueryRun(p, gpp, q).sweep(shards[s]) for s in range(G)]
-        words = runs[0].partial_words()
-        total = torch.zeros(words, dtype=torch.int32, device="cuda")
+        total = None
         for r in runs:
             r.sync()
-            buf = torch.empty(words, dtype=torch.int32, device="cuda")
-            C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(buf.data_ptr()), C.c_void_p(r.partial_ptr()),
-                                                           C.c_size_t(words * 4), C.c_int(3))
-            total += buf
+            t = partial_tensor(r)
+            total = t.clone() if total is None else total + t
+        assert int(total.max()) < 2**31 - 1
+        partial_tensor(runs[0]).copy_(total)
         torch.cuda.synchronize()
-        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(runs[0].partial_ptr()), C.c_void_p(total.data_ptr()),
-                                                       C.c_size_t(words * 4), C.c_int(3))
         assert runs[0].finish() == expect
+        assert cl.decode_response(expect) == o.item_to_vec(item)

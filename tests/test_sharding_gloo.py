@@ -1,0 +1,77 @@
+"""N > 1 path on CPU (gloo, world_size 2 and 4): the row-shard split + the one exchange step.
+Each rank computes its shard's partial first-dimension residues with the oracle, the partial buffers are
+summed onto rank 0 by sdk_amd.sharding.reduce_partials (the call bench.py makes over RCCL), and the result
+must equal the unsharded multiply_reg_by_database."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+N = 2048
+Q0, Q1 = 268369921, 249561089
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, dim0, num_per, nz, out_path):
+    sys.path.insert(0, ROOT)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from sdk_amd.sharding import modulus_of_partial_index, partial_layout_index, reduce_partials, shard_rows
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(7)  # same inputs on every rank
+    db = rng.integers(0, Q0, nz * num_per * dim0, dtype=np.uint64) | (rng.integers(0, Q1, nz * num_per * dim0, dtype=np.uint64) << np.uint64(32))
+    qv = rng.integers(0, Q0, nz * dim0 * 2, dtype=np.uint64) | (rng.integers(0, Q1, nz * dim0 * 2, dtype=np.uint64) << np.uint64(32))
+    j0, j1 = shard_rows(dim0, rank, world)
+    nj = j1 - j0
+    db_s = np.ascontiguousarray(db.reshape(nz, num_per, dim0)[:, :, j0:j1])
+    qv_s = np.ascontiguousarray(qv.reshape(nz, dim0, 2)[:, j0:j1, :])
+    part = oracle.sweep_rows(db_s, qv_s, nz, nj, num_per)  # [z][ii][n0_0, n0_1, n1_0, n1_1]
+    # scatter into the library's partial layout [plane][r][crt][z][ii] (plane 0, z < nz)
+    buf = np.zeros(4 * N * num_per, dtype=np.int32)
+    zz, ii = np.meshgrid(np.arange(nz), np.arange(num_per), indexing="ij")
+    for which, (r, crt) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+        buf[partial_layout_index(num_per, 0, r, crt, zz, ii)] = part[:, :, which].astype(np.int32)
+    t = torch.from_numpy(buf)
+    reduce_partials(t, dst=0)
+    if rank == 0:
+        total = t.numpy().astype(np.int64)
+        idx = np.arange(total.size)
+        red = (total % modulus_of_partial_index(idx, num_per)).astype(np.uint64)
+        full = oracle.sweep_rows(db, qv, nz, dim0, num_per)
+        ok = True
+        for which, (r, crt) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+            ok &= bool((red[partial_layout_index(num_per, 0, r, crt, zz, ii)] == full[:, :, which]).all())
+        ok &= int(total.max()) < 2**31
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dim0,num_per", [(2, 64, 4), (4, 512, 8), (2, 512, 128)])
+def test_row_shard_reduce_gloo(tmp_path, world, dim0, num_per):
+    import torch.multiprocessing as mp
+    out = tmp_path / "res.txt"
+    mp.spawn(_worker, args=(world, _free_port(), dim0, num_per, 6, str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
+def test_shard_rows_contract():
+    from sdk_amd.sharding import shard_rows
+    assert shard_rows(512, 0, 8) == (0, 64) and shard_rows(512, 7, 8) == (448, 512)
+    with pytest.raises(ValueError):
+        shard_rows(512, 0, 16)      # int32 partial sums are only overflow-free for <= 8 shards
+    with pytest.raises(ValueError):
+        shard_rows(6, 0, 4)
