@@ -78,6 +78,19 @@ struct MacDesc {
 };
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s);
 
+// ---- fused fold step (server.rs:407-424) ----------------------------------------------------
+// One workgroup per (pair i, plane): out[plane][i] = from_ntt( [G-C | C] * NTT(G^-1([ct_i ; ct_{i+half}])) ),
+// digits -> NTT -> multiply-accumulate -> iNTT -> CRT entirely in registers/LDS.
+//   X: raw cts dense [plane][cur][2][N];  Y: raw cts dense [plane][half][2][N];  mats: this level's 2 x 4t polys
+struct FoldDesc {
+  const u64* X;
+  u64* Y;
+  const u32* mats;
+  int cur, half, planes;
+  int t, bits;
+};
+void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
+
 // dst poly idx[b] += src poly b   (NTT polys, mod q)
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s);
 // polys [dst_off + b] = scalar (1 poly) * polys [src_off + b], b < n_polys   (multiply_poly, poly.rs:351-358)

@@ -29,6 +29,7 @@ struct Workspace {
   u64* h_query = nullptr;
   u64* h_packed = nullptr;
   size_t h_packed_words = 0;
+  long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused
 
   Workspace(const Params& P, DeviceState& D);
   ~Workspace();

@@ -6,6 +6,7 @@
 #include "server.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "pipeline.hpp"
@@ -222,6 +223,7 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
   HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
   q_raw.alloc(2 * POLY_LEN);
+  if (const char* e = getenv("SPIRAL_FUSED_MIN_PAIRS")) fused_min_pairs = atol(e);
 }
 
 Workspace::~Workspace() {
@@ -457,6 +459,23 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
   while (((int)1 << further) < num_cts) further++;
   for (int d = 0; d < further; d++) {
     const int half = cur / 2;
+    // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
+    // the three-kernel form, which parallelises over digits
+    if ((long)np * half >= W.fused_min_pairs && 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64) {
+      FoldDesc fd{};
+      fd.X = X;
+      fd.Y = Y;
+      fd.mats = W.fold_mats.p + (size_t)(further - 1 - d) * 2 * 2 * two_t * 2 * POLY_LEN;
+      fd.cur = cur;
+      fd.half = half;
+      fd.planes = np;
+      fd.t = (int)p.t_gsw;
+      fd.bits = (int)p.bits_per(p.t_gsw);
+      launch_fold_fused(D.T, fd, s);
+      std::swap(X, Y);
+      cur = half;
+      continue;
+    }
     FwdDesc f{};
     f.src = X;
     f.dst = W.fold_dig.p;

@@ -234,6 +234,33 @@ def test_process_query_c1(sp, oracle_mod):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
+@pytest.mark.parametrize("variant", ["0", "1"])
+def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
+    """k_fold_fused (used when a level has >= 256 (pair, plane) units, i.e. at C2 scale) forced on for a
+    small tree, both register-allocation variants: stage output and response bytes must not change."""
+    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", "1")
+    monkeypatch.setenv("SPIRAL_FOLD_VARIANT", variant)
+    cfg, idx = dict(FAST56, nu_2=4), 777
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 33)
+    p = sp.Params(cfg)          # workspaces of this handle read the env at creation
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    v_reg, v_fold = o.expand_query(pp, q)
+    v_neg = o.get_v_folding_neg(v_fold)
+    N = 2048
+    sw = o.dim0 * o.num_per * N
+    raw = o.from_ntt(o.multiply_reg_by_database(db[:sw], v_reg))
+    assert (sp.fold_ciphertexts(p, raw, v_fold, v_neg)[:2 * N] == o.fold_ciphertexts(raw, v_fold, v_neg)[:2 * N]).all()
+    # ragged tree depth (fewer levels than nu_2) through the stage API
+    sub = raw[:4 * 2 * N]
+    assert (sp.fold_ciphertexts(p, sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N])[:2 * N] ==
+            o.fold_ciphertexts(sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N], nu=2)[:2 * N]).all()
+    gdb = sp.Database(p).load(db)
+    resp = sp.process_query(p, gpp, q, gdb)
+    assert resp == o.process_query(pp, q, db)
+    assert cl.decode_response(resp) == o.item_to_vec(item)
+
+
 def test_bad_lengths_raise(sp, oracle_mod):
     o, cl, pp, q = _session(oracle_mod, FAST, 1, 7)
     p = sp.Params(FAST)
