@@ -1,4 +1,5 @@
 // extern "C" surface of libspiral_hip.so (include/spiral_hip.h).
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -180,7 +181,8 @@ sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) {
     d->num_shards = num_shards;
     d->nj = (int)(p.dim0() / num_shards);
     d->j0 = shard * d->nj;
-    d->words.alloc(p.planes() * POLY_LEN * (size_t)d->nj * p.num_per());
+    d->packed = db_can_pack((int)p.num_per(), d->nj) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
+    d->words.alloc((db_bytes((int)p.planes(), (int)p.num_per(), d->nj, d->packed) + 7) / 8);
     const_cast<sp_params*>(h)->device_state();
     out = d.release();
   });
@@ -200,11 +202,11 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     const size_t max_stage = ((size_t)64 << 20) / 8;  // 64 MiB staging
     const int zs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, max_stage / row_words));
     DevBuf<u64> stage((size_t)zs * row_words);
-    u64* plane_base = d->words.p + (size_t)plane * POLY_LEN * d->nj * p.num_per();
     for (int z = 0; z < nz; z += zs) {
       const int cnt = std::min(zs, nz - z);
       HIP_CHECK(hipMemcpy(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8, hipMemcpyHostToDevice));
-      launch_db_relayout(plane_base, stage.p, z0 + z, cnt, (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, 0);
+      launch_db_relayout(d->words.p, plane, stage.p, z0 + z, cnt, (int)p.num_per(), (int)p.dim0(), d->j0, d->nj,
+                         d->packed, 0);
       HIP_CHECK(hipDeviceSynchronize());
     }
   });
@@ -233,7 +235,7 @@ int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
     need(d != nullptr, "null db");
     check_device(d->device);
     const Params& p = d->params->p;
-    launch_db_synth(d->words.p, seed, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, 0);
+    launch_db_synth(d->words.p, seed, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, d->packed, 0);
     HIP_CHECK(hipDeviceSynchronize());
   });
 }
@@ -246,8 +248,9 @@ int sp_db_read_ref(const sp_db_t* d, int plane, int z, int ii, int j0, int count
     need(plane >= 0 && (size_t)plane < p.planes() && z >= 0 && z < N && ii >= 0 && (size_t)ii < p.num_per() && j0 >= 0 &&
              count >= 0 && j0 + count <= d->nj, "bad coordinates");
     check_device(d->device);
-    const u64* base = d->words.p + (((size_t)plane * POLY_LEN + z) * d->nj + j0) * p.num_per() + ii;
-    HIP_CHECK(hipMemcpy2D(out, 8, base, p.num_per() * 8, 8, (size_t)count, hipMemcpyDeviceToHost));
+    DevBuf<u64> tmp((size_t)std::max(count, 1));
+    launch_db_read(tmp.p, d->words.p, plane, z, ii, j0, count, (int)p.num_per(), d->nj, d->packed, 0);
+    HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)count * 8, hipMemcpyDeviceToHost));
   });
 }
 
@@ -616,9 +619,10 @@ int sp_multiply_reg_by_database(const sp_params_t* h, const uint64_t* db, const 
     DevBuf<u64> d_ref(words), d_dev(words), d_q, d_out(num_per * 4 * POLY_LEN);
     DevBuf<u32> d_res(4 * POLY_LEN * num_per);
     HIP_CHECK(hipMemcpyAsync(d_ref.p, db, words * 8, hipMemcpyHostToDevice, W->stream));
-    launch_db_relayout(d_dev.p, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, W->stream);
+    const int packed = db_can_pack((int)num_per, (int)dim0) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
+    launch_db_relayout(d_dev.p, 0, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, packed, W->stream);
     upload_raw(*W, v_firstdim, POLY_LEN * dim0 * 2, d_q);
-    SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0};
+    SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0, packed};
     launch_sweep(W->D->T, d, W->stream);
     launch_sweep_out_to_ref(d_out.p, d_res.p, (int)num_per, W->stream);
     download_raw(*W, d_out.p, num_per * 4 * POLY_LEN, out);

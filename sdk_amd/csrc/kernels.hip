@@ -419,16 +419,34 @@ __global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
   const ModConst m = T.c.mod[c];
   const u32* B = d.B + ((size_t)outer * d.B_outer_stride + (size_t)inner * d.B_inner_stride) * 2 * N + e;
   const long ob = d.out_idx ? (long)d.out_idx[b] : (long)b * d.out_batch_stride;
+  const size_t PW = 2 * N;
   for (int r = 0; r < d.R; r++) {
-    const u32* A = d.A + (size_t)r * d.K * 2 * N + e;
+    const u32* A = d.A + (size_t)r * d.K * PW + e;
     const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
     u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
-    for (int k0 = 0; k0 < d.K; k0 += 128) {  // products < 2^56: 128 terms + carry-in stay < 2^64
-      int k1 = min(k0 + 128, d.K);
-      for (int k = k0; k < k1; k++) {
-        const size_t kb = k < d.split_k ? (size_t)k : (size_t)(d.split_off + (k - d.split_k));
-        acc += (u64)A[(size_t)k * 2 * N] * (u64)B[kb * 2 * N];
+    // two segments of B (k < split_k, k >= split_k), each walked 8 operands at a time with all 16
+    // loads issued before the multiplies: small batches are latency-bound, not bandwidth-bound.
+    // products < 2^56: <= 64 terms between Barrett folds stay < 2^63.
+    for (int seg = 0; seg < 2; seg++) {
+      const int k_lo = seg == 0 ? 0 : d.split_k, k_hi = seg == 0 ? min(d.split_k, d.K) : d.K;
+      const u32* Bs = seg == 0 ? B : B + (size_t)(d.split_off - d.split_k) * PW;
+      int k = k_lo, since = 0;
+      for (; k + 8 <= k_hi; k += 8) {
+        u32 a[8], bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          a[u] = A[(size_t)(k + u) * PW];
+          bb[u] = Bs[(size_t)(k + u) * PW];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += (u64)a[u] * (u64)bb[u];
+        since += 8;
+        if (since >= 64) {
+          acc = reduce64(acc, m);
+          since = 0;
+        }
       }
+      for (; k < k_hi; k++) acc += (u64)A[(size_t)k * PW] * (u64)Bs[(size_t)k * PW];
       acc = reduce64(acc, m);
     }
     d.out[op] = (u32)acc;
@@ -678,6 +696,95 @@ __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
   *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)a03, (u32)a13);  // r=1, crt=1
 }
 
+// PACKED wide sweep: as k_sweep_wide, but each lane streams 28 bytes per ROW PAIR (7 dwords = 8 limbs
+// of 28 bits) instead of 32; limb extraction is 6 v_alignbit + 7 v_and per 16 multiply-accumulates.
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32 u32x3_t __attribute__((ext_vector_type(3), aligned(4)));
+__global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) {
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;  // plane * N + z
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  if (plane >= d.planes) return;
+  const int npairs = d.nj >> 1;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;  // 1792 B = 448 dwords
+  const size_t ustride = (size_t)chunks * 448;
+  const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0;  // ii = 2l  : n0_0, n0_1, n1_0, n1_1
+  u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // ii = 2l+1
+  for (int jb = 0; jb < npairs; jb += 128) {
+    const int je = min(jb + 128, npairs);
+    for (int jp = jb; jp < je; jp++) {
+      const u32* u = base + (size_t)jp * ustride;
+      const u32* p4 = u + lane * 4;
+      const u32* p3 = u + 256 + lane * 3;
+      const u32x4_t va = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p4));
+      const u32x3_t vb = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(p3));
+      const u32 d0 = va.x, d1 = va.y, d2 = va.z, d3 = va.w, d4 = vb.x, d5 = vb.y, d6 = vb.z;
+      const uint4 qa = qrow[2 * jp];      // row 2jp   : (a0_lo, a0_hi, a1_lo, a1_hi)
+      const uint4 qb = qrow[2 * jp + 1];  // row 2jp+1
+      const u32 f0 = d0 & M;
+      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+      const u32 f7 = d6 >> 4;
+      // (row 2jp, ii 2l) = (f0, f1); (2jp, 2l+1) = (f2, f3); (2jp+1, 2l) = (f4, f5); (2jp+1, 2l+1) = (f6, f7)
+      a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
+      a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
+      a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
+      a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;
+    }
+    a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
+    a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
+  }
+  const size_t plane_words = (size_t)4 * N * d.num_per;
+  const size_t zi = (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
+  u32* o = d.out + (size_t)plane * plane_words + zi;
+  const size_t rc = (size_t)N * d.num_per;
+  *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)a00, (u32)a10);  // r=0, crt=0
+  *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)a02, (u32)a12);  // r=0, crt=1
+  *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)a01, (u32)a11);  // r=1, crt=0
+  *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)a03, (u32)a13);  // r=1, crt=1
+}
+
+// Packing helpers shared by the writers of the PACKED format.
+__device__ __forceinline__ void pack_unit_lane(u32* unit, int lane, u64 w00, u64 w01, u64 w10, u64 w11) {
+  // w{row}{iiofs}: limbs f0..f7 = lo/hi of w00, w01, w10, w11
+  const u32 M = 0x0FFFFFFFu;
+  const u32 f0 = (u32)w00 & M, f1 = (u32)(w00 >> 32) & M, f2 = (u32)w01 & M, f3 = (u32)(w01 >> 32) & M;
+  const u32 f4 = (u32)w10 & M, f5 = (u32)(w10 >> 32) & M, f6 = (u32)w11 & M, f7 = (u32)(w11 >> 32) & M;
+  u32* p4 = unit + lane * 4;
+  u32* p3 = unit + 256 + lane * 3;
+  p4[0] = f0 | (f1 << 28);
+  p4[1] = (f1 >> 4) | (f2 << 24);
+  p4[2] = (f2 >> 8) | (f3 << 20);
+  p4[3] = (f3 >> 12) | (f4 << 16);
+  p3[0] = (f4 >> 16) | (f5 << 12);
+  p3[1] = (f5 >> 20) | (f6 << 8);
+  p3[2] = (f6 >> 24) | (f7 << 4);
+}
+__device__ __forceinline__ u64 unpack_word(const u32* unit, int lane, int which) {  // which = row*2 + iiofs
+  const u32* p4 = unit + lane * 4;
+  const u32* p3 = unit + 256 + lane * 3;
+  u32 dd[8] = {p4[0], p4[1], p4[2], p4[3], p3[0], p3[1], p3[2], 0u};
+  u32 f[2];
+  for (int h = 0; h < 2; h++) {
+    const int bit = 28 * (which * 2 + h);
+    const int w = bit >> 5, sh = bit & 31;
+    u64 two = (u64)dd[w] | ((u64)dd[w + 1 < 8 ? w + 1 : 7] << 32);
+    f[h] = (u32)(two >> sh) & 0x0FFFFFFFu;
+  }
+  return (u64)f[0] | ((u64)f[1] << 32);
+}
+
 // NARROW (num_per <= 64): one workgroup per (plane, z).  The nj*num_per words of the row block are
 // contiguous; thread tau reads word tau + 256*s, i.e. fixed ii = tau % num_per and rows
 // j = tau/num_per + s*(256/num_per).  Query limbs for this z are staged in LDS (16 B per row);
@@ -732,10 +839,13 @@ __global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) 
   }
 }
 
-const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_wide" : "k_sweep_narrow"; }
+const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
 
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
-  if (d.num_per >= 128) {
+  if (d.packed) {
+    const long units = (long)d.planes * N * (d.num_per >> 7);
+    hipLaunchKernelGGL(k_sweep_packed, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
+  } else if (d.num_per >= 128) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
     static const int variant = [] {
       const char* e = getenv("SPIRAL_SWEEP_VARIANT");
@@ -778,11 +888,36 @@ __global__ __launch_bounds__(256) void k_db_relayout(u64* dst_plane, const u64* 
     if (ii < num_per && j < nj) dpl[(size_t)j * num_per + ii] = tile[tx][ty + 8 * i];
   }
 }
-void launch_db_relayout(u64* dst_plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
-                        hipStream_t s) {
+// reference layout -> PACKED: one thread per (z, jp, chunk, lane); gathers its 4 words (one-time cost)
+__global__ __launch_bounds__(256) void k_db_relayout_packed(u32* dst, int plane, const u64* src, int z0, int nz,
+                                                            int num_per, int dim0, int j0, int nj) {
+  const int chunks = num_per >> 7, npairs = nj >> 1;
+  const size_t total = (size_t)nz * npairs * chunks * 64;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    size_t t = i >> 6;
+    const int chunk = (int)(t % chunks);
+    t /= chunks;
+    const int jp = (int)(t % npairs);
+    const int zl = (int)(t / npairs);
+    const int ii = chunk * 128 + 2 * lane;
+    const u64* s = src + ((size_t)zl * num_per + ii) * dim0 + j0 + 2 * jp;
+    const u64 w00 = s[0], w10 = s[1], w01 = s[dim0], w11 = s[dim0 + 1];
+    u32* unit = dst + ((((size_t)plane * N + (z0 + zl)) * npairs + jp) * chunks + chunk) * 448;
+    pack_unit_lane(unit, lane, w00, w01, w10, w11);
+  }
+}
+void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
+                        int packed, hipStream_t s) {
   if (nz <= 0) return;
-  hipLaunchKernelGGL(k_db_relayout, dim3((nj + 31) / 32, (num_per + 31) / 32, nz), dim3(256), 0, s, dst_plane, src, z0,
-                     num_per, dim0, j0, nj);
+  if (packed) {
+    hipLaunchKernelGGL(k_db_relayout_packed, dim3(4096), dim3(256), 0, s, reinterpret_cast<u32*>(dst), plane, src, z0,
+                       nz, num_per, dim0, j0, nj);
+  } else {
+    u64* dst_plane = dst + (size_t)plane * N * nj * num_per;
+    hipLaunchKernelGGL(k_db_relayout, dim3((nj + 31) / 32, (num_per + 31) / 32, nz), dim3(256), 0, s, dst_plane, src,
+                       z0, num_per, dim0, j0, nj);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_db_synth(u64* dst, u64 seed, int num_per, int dim0, int j0, int nj,
@@ -797,9 +932,54 @@ __global__ __launch_bounds__(256) void k_db_synth(u64* dst, u64 seed, int num_pe
     dst[i] = synth_word(seed, ref);
   }
 }
-void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, hipStream_t s) {
-  size_t total = (size_t)planes * N * nj * num_per;
-  hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total);
+__global__ __launch_bounds__(256) void k_db_synth_packed(u32* dst, u64 seed, int num_per, int dim0, int j0, int nj,
+                                                         size_t total_lanes) {
+  const int chunks = num_per >> 7, npairs = nj >> 1;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_lanes; i += (size_t)gridDim.x * 256) {
+    const int lane = (int)(i & 63);
+    size_t t = i >> 6;  // unit index = (zp * npairs + jp) * chunks + chunk
+    const int chunk = (int)(t % chunks);
+    const size_t t2 = t / chunks;
+    const int jp = (int)(t2 % npairs);
+    const size_t zp = t2 / npairs;
+    const size_t ii = (size_t)chunk * 128 + 2 * lane;
+    const size_t r0 = (zp * num_per + ii) * dim0 + j0 + 2 * jp;  // (row 2jp, ii)
+    const size_t r1 = r0 + dim0;                                 // (row 2jp, ii+1)
+    pack_unit_lane(dst + t * 448, lane, synth_word(seed, r0), synth_word(seed, r1), synth_word(seed, r0 + 1),
+                   synth_word(seed, r1 + 1));
+  }
+}
+void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, int packed, hipStream_t s) {
+  if (packed) {
+    size_t lanes = (size_t)planes * N * (nj >> 1) * (num_per >> 7) * 64;
+    hipLaunchKernelGGL(k_db_synth_packed, dim3(256 * 32), dim3(256), 0, s, reinterpret_cast<u32*>(dst), seed, num_per,
+                       dim0, j0, nj, lanes);
+  } else {
+    size_t total = (size_t)planes * N * nj * num_per;
+    hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total);
+  }
+}
+
+__global__ void k_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, int count, int num_per, int nj,
+                          int packed) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= count) return;
+  const int jl = jl0 + t;
+  if (packed) {
+    const int chunks = num_per >> 7, npairs = nj >> 1;
+    const int chunk = ii >> 7, lane = (ii & 127) >> 1, iiofs = ii & 1;
+    const u32* unit = reinterpret_cast<const u32*>(db) +
+                      ((((size_t)plane * N + z) * npairs + (jl >> 1)) * chunks + chunk) * 448;
+    out[t] = unpack_word(unit, lane, (jl & 1) * 2 + iiofs);
+  } else {
+    out[t] = db[(((size_t)plane * N + z) * nj + jl) * num_per + ii];
+  }
+}
+void launch_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, int count, int num_per, int nj,
+                    int packed, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_db_read, dim3((count + 63) / 64), dim3(64), 0, s, out, db, plane, z, ii, jl0, count, num_per, nj,
+                     packed);
 }
 
 __global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* in, int num_per) {

@@ -130,6 +130,7 @@ struct sp_db {
   int device = -1;
   int shard = 0, num_shards = 1;
   int j0 = 0, nj = 0;
-  spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii]
+  int packed = 0;                     // 7-byte PACKED device format (kernels.hpp) vs 8-byte words
+  spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii] (or the PACKED unit stream)
   std::mutex mu;
 };

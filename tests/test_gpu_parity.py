@@ -261,6 +261,73 @@ def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
+@pytest.mark.parametrize("num_per_log,dim0_log,shards", [(7, 3, 1), (8, 4, 2), (5, 4, 1)])
+def test_db_device_formats_roundtrip(sp, oracle_mod, num_per_log, dim0_log, shards):
+    """8-byte and 7-byte PACKED device formats: what was loaded (reference layout) / synthesised is what
+    sp_db_read_ref returns, for every shard."""
+    from sdk_amd.spiral import synth_words
+    cfg = dict(FAST, nu_1=dim0_log, nu_2=num_per_log)
+    p = sp.Params(cfg)
+    N, dim0, num_per = 2048, 1 << dim0_log, 1 << num_per_log
+    rng = np.random.default_rng(num_per_log)
+    words = (rng.integers(0, Q0, 4 * N * num_per * dim0, dtype=np.uint64) |
+             (rng.integers(0, Q1, 4 * N * num_per * dim0, dtype=np.uint64) << np.uint64(32)))
+    ref = words.reshape(4, N, num_per, dim0)
+    for s_ in range(shards):
+        db = sp.Database(p, s_, shards).load(words)
+        nj = dim0 // shards
+        for _ in range(40):
+            pl, z, ii = int(rng.integers(4)), int(rng.integers(N)), int(rng.integers(num_per))
+            got = db.read_ref(pl, z, ii, 0, nj)
+            assert (got == ref[pl, z, ii, s_ * nj:(s_ + 1) * nj]).all()
+        db.fill_synthetic(99)
+        for _ in range(20):
+            pl, z, ii = int(rng.integers(4)), int(rng.integers(N)), int(rng.integers(num_per))
+            idx = ((pl * N + z) * num_per + ii) * dim0 + s_ * nj + np.arange(nj, dtype=np.uint64)
+            assert (db.read_ref(pl, z, ii, 0, nj) == synth_words(99, idx)).all()
+
+
+def test_c2_full_size_sampled_parity(sp, oracle_mod):
+    """BASELINE.json configs[1] at full size (2^20 x 256 B, 64 GiB encoded, 56 GiB packed in HBM):
+    the synthetic DB is a pure function of the reference-layout index, so any first-dimension output
+    can be recomputed on the CPU from sp_synth_word and the query slice.  64 sampled (plane, z, ii)
+    outputs x 4 residues against exact integer arithmetic."""
+    import torch
+    from sdk_amd.sharding import partial_tensor
+    from sdk_amd.spiral import synth_words
+    from conftest import C2
+    import bench
+    p = sp.Params(C2)
+    free, total = torch.cuda.mem_get_info()
+    if free < 70 * 2**30:
+        pytest.skip("needs ~60 GiB of free HBM")
+    pp = sp.PublicParameters.deserialize(p, bench.synthetic_wire_bytes(p.setup_bytes(), 1))
+    q = bench.synthetic_wire_bytes(p.query_bytes(), 2)
+    db = sp.Database(p).fill_synthetic(0x123456789)
+    v_reg, _ = sp.expand_query(p, pp, q)
+    run = sp.QueryRun(p, pp, q).sweep(db)
+    run.sync()
+    part = partial_tensor(run)
+    N, dim0, num_per = 2048, 512, 2048
+    vr = v_reg.reshape(N, dim0, 2)
+    rng = np.random.default_rng(11)
+    for _ in range(64):
+        pl, z, ii = int(rng.integers(4)), int(rng.integers(N)), int(rng.integers(num_per))
+        idx = ((pl * N + z) * num_per + ii) * dim0 + np.arange(dim0, dtype=np.uint64)
+        w = synth_words(0x123456789, idx)
+        blo, bhi = [int(x) for x in (w & np.uint64(0xFFFFFFFF))], [int(x) for x in (w >> np.uint64(32))]
+        for r in range(2):
+            alo = [int(x) & 0xFFFFFFFF for x in vr[z, :, r]]
+            ahi = [int(x) >> 32 for x in vr[z, :, r]]
+            e0 = sum(a * b for a, b in zip(alo, blo)) % Q0
+            e1 = sum(a * b for a, b in zip(ahi, bhi)) % Q1
+            g0 = int(part[(((pl * 2 + r) * 2 + 0) * N + z) * num_per + ii])
+            g1 = int(part[(((pl * 2 + r) * 2 + 1) * N + z) * num_per + ii])
+            assert (g0, g1) == (e0, e1), (pl, z, ii, r)
+    # the whole path still runs to a response of the right size at this scale
+    assert len(run.finish()) == p.get("response_bytes")
+
+
 def test_bad_lengths_raise(sp, oracle_mod):
     o, cl, pp, q = _session(oracle_mod, FAST, 1, 7)
     p = sp.Params(FAST)
