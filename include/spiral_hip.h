@@ -78,6 +78,12 @@ void sp_db_free(sp_db_t*);
 int sp_db_load_plane(sp_db_t*, int plane, int z0, int nz, const uint64_t* words);
 /* Whole database in one call: `words` = instances*n*n*N*num_per*dim0 u64 in the reference layout. */
 int sp_db_load(sp_db_t*, const uint64_t* words, size_t n_words);
+/* Build the database on the device from the raw item file: the GPU form of load_db_from_seek
+ * (server.rs:320-357) over an in-memory file image.  `file` holds num_items records of db_item_size
+ * bytes (a shorter file reads as zeros past its end, as the reference's failed seek/short read do);
+ * each record is split into instances*n*n chunks of bytes_per_chunk bytes, log2(p)-bit coefficients,
+ * recenter_mod, forward NTT, packed words -- written straight into the resident layout. */
+int sp_db_load_items(sp_db_t*, const uint8_t* file, size_t file_len);
 /* Synthetic benchmark database generated on the device: reference-layout word index i holds
  * sp_synth_word(seed, i).  (Roofline runs at sizes no host buffer can hold.) */
 int sp_db_fill_synthetic(sp_db_t*, uint64_t seed);

@@ -1585,6 +1585,7 @@ void expand_query(const Params& params, const PublicParameters& pp, const Query&
   std::vector<PolyMatrixNTT> v_reg_inp, v_gsw_inp;
   if (further_dims > 0) {
     coefficient_expansion(v, g, stop_round, params, v_w_left, v_w_right, v_neg1, params.t_gsw * params.db_dim_2);
+    ORACLE_CHECK(2 * std::max(dim0, right_expanded) <= v.size());  // Rust: index out of bounds panic
     for (size_t i = 0; i < dim0; i++) v_reg_inp.push_back(v[2 * i]);
     for (size_t i = 0; i < right_expanded; i++) v_gsw_inp.push_back(v[2 * i + 1]);
   } else {

@@ -230,6 +230,57 @@ int sp_db_load(sp_db_t* d, const uint64_t* words, size_t n_words) {
   return SP_OK;
 }
 
+int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
+  return guarded([&] {
+    need(d && (file || file_len == 0), "null argument");
+    check_device(d->device);
+    sp_params* h = const_cast<sp_params*>(d->params);
+    const Params& p = h->p;
+    DeviceState& D = h->device_state();
+    std::lock_guard<std::mutex> lk(d->mu);
+    size_t logp = 0;
+    while (((u64)1 << logp) < p.pt_modulus) logp++;
+    const size_t chunks = p.planes();
+    const size_t bpc = (p.db_item_size + chunks - 1) / chunks;  // ceil, params.rs:188-193
+    need((bpc * 8 + logp - 1) / logp <= POLY_LEN, "item chunk does not fit one polynomial (server.rs:292)");
+    need(logp >= 1 && logp <= 28, "plaintext modulus out of range");
+    // windows of whole row pairs: the rows' items are contiguous in the file
+    const size_t row_bytes = p.num_per() * p.db_item_size;
+    const int npairs_total = (d->nj + 1) / 2;
+    const size_t max_win = (size_t)512 << 20;
+    const int pairs_per_win = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs_total, max_win / (2 * row_bytes)));
+    DevBuf<uint8_t> win((size_t)pairs_per_win * 2 * row_bytes);
+    for (int jp = 0; jp < npairs_total; jp += pairs_per_win) {
+      const int cnt = std::min(pairs_per_win, npairs_total - jp);
+      const size_t item0 = (size_t)(d->j0 + 2 * jp) * p.num_per();
+      const size_t off = item0 * p.db_item_size;
+      size_t want = (size_t)cnt * 2 * row_bytes;
+      size_t have = off < file_len ? std::min(want, file_len - off) : 0;
+      if (have) HIP_CHECK(hipMemcpy(win.p, file + off, have, hipMemcpyHostToDevice));
+      DbEncodeDesc e{};
+      e.win = win.p;
+      e.win_item0 = item0;
+      e.win_bytes = have;
+      e.file_len = file_len;
+      e.db = d->words.p;
+      e.db_item_size = (int)p.db_item_size;
+      e.bytes_per_chunk = (int)bpc;
+      e.logp = (int)logp;
+      e.pt_modulus = (u32)p.pt_modulus;
+      e.planes = (int)p.planes();
+      e.num_per = (int)p.num_per();
+      e.dim0 = (int)p.dim0();
+      e.j0 = d->j0;
+      e.nj = d->nj;
+      e.packed = d->packed;
+      e.jp0 = jp;
+      e.njp = cnt;
+      launch_db_encode(D.T, e, 0);
+      HIP_CHECK(hipDeviceSynchronize());
+    }
+  });
+}
+
 int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
   return guarded([&] {
     need(d != nullptr, "null db");

@@ -982,6 +982,96 @@ void launch_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, 
                      packed);
 }
 
+// ------------------------------------------------------------------------------------------------
+// database preprocessing (server.rs:277-357) -- grid (max(num_per/2,1), njp, planes)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 item_coeff(const DbEncodeDesc& d, size_t item, int chunk_idx, int z) {
+  // load_item_from_seek: chunk bytes at item*db_item_size + chunk_idx*bytes_per_chunk, logp bits per coefficient
+  const size_t pos = item * (size_t)d.db_item_size + (size_t)chunk_idx * d.bytes_per_chunk;
+  if (pos >= d.file_len) return 0u;
+  const size_t avail = d.file_len - pos;
+  const int bytes_read = (int)(avail < (size_t)d.bytes_per_chunk ? avail : (size_t)d.bytes_per_chunk);
+  const int words_read = (bytes_read * 8 + d.logp - 1) / d.logp;
+  if (z >= words_read) return 0u;
+  const size_t wpos = pos - d.win_item0 * (size_t)d.db_item_size;
+  const int bit = z * d.logp;
+  const int b0 = bit >> 3, sh = bit & 7;
+  u64 acc = 0;
+  const int nb = (sh + d.logp + 7) >> 3;
+  for (int i = 0; i < nb; i++) {
+    const int bi = b0 + i;
+    const u64 byte = (bi < bytes_read && wpos + bi < d.win_bytes) ? (u64)d.win[wpos + bi] : 0ULL;
+    acc |= byte << (8 * i);
+  }
+  return (u32)((acc >> sh) & ((1ULL << d.logp) - 1ULL));
+}
+
+__global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) {
+  __shared__ u32 lds0[LDS_WORDS];
+  __shared__ u32 lds1[LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int qd = blockIdx.x, jp = d.jp0 + blockIdx.y, plane = blockIdx.z;
+  u64 w[4][8];  // [row a * 2 + ii b][k]: words at z = 8 tau + k
+  u32* la = lds0;
+  u32* lb = lds1;
+#pragma unroll 1
+  for (int ab = 0; ab < 4; ab++) {
+    const int a = ab >> 1, b = ab & 1;
+    const int jl = 2 * jp + a, ii = 2 * qd + b;
+    const bool valid = jl < d.nj && ii < d.num_per;
+    const size_t item = (size_t)(d.j0 + jl) * d.num_per + ii;  // i = j * num_per + ii (server.rs:332-333)
+    u32 lo[8], hi[8];
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const ModConst m = T.c.mod[c];
+      u32 v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        u32 x = valid ? item_coeff(d, item, plane, tau + 256 * k) : 0u;
+        // recenter_mod(x, p, Q) reduced mod q_c: values above p/2 are negative
+        v[k] = x > d.pt_modulus / 2 ? m.q - (d.pt_modulus - x) : x;
+      }
+      const u32* fw = T.tw + (size_t)c * 4 * N;
+      ntt_fwd_block(v, tau, la, lb, fw, fw + N, m.q, m.two_q);
+      {
+        u32* tmp = la;
+        la = lb;
+        lb = tmp;
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        if (c == 0)
+          lo[k] = v[k];
+        else
+          hi[k] = v[k];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) w[ab][k] = (u64)lo[k] | ((u64)hi[k] << 32);
+  }
+  const int jl0 = 2 * jp, ii0 = 2 * qd;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int z = 8 * tau + k;
+    if (d.packed) {
+      const int chunks = d.num_per >> 7, npairs = d.nj >> 1;
+      u32* unit = reinterpret_cast<u32*>(d.db) +
+                  ((((size_t)plane * N + z) * npairs + jp) * chunks + (ii0 >> 7)) * 448;
+      pack_unit_lane(unit, (ii0 & 127) >> 1, w[0][k], w[1][k], w[2][k], w[3][k]);
+    } else {
+#pragma unroll
+      for (int ab = 0; ab < 4; ab++) {
+        const int jl = jl0 + (ab >> 1), ii = ii0 + (ab & 1);
+        if (jl < d.nj && ii < d.num_per) d.db[(((size_t)plane * N + z) * d.nj + jl) * d.num_per + ii] = w[ab][k];
+      }
+    }
+  }
+}
+void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s) {
+  if (d.njp <= 0) return;
+  hipLaunchKernelGGL(k_db_encode, dim3((d.num_per + 1) / 2, d.njp, d.planes), dim3(256), 0, s, T, d);
+}
+
 __global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* in, int num_per) {
   // out[ii][r][crt][z] <- in[r][crt][z][ii]
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;

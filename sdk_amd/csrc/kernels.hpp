@@ -151,6 +151,23 @@ void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int 
 // read back words (plane, z, ii, j_local0 .. +count) of either device format into out[count] (device)
 void launch_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, int count, int num_per, int nj,
                     int packed, hipStream_t s);
+// ---- database preprocessing on the device (server.rs:277-357 load_item_from_seek / load_db_from_seek) ----
+// One workgroup per 2x2 quad of items {rows 2jp, 2jp+1} x {ii 2q, 2q+1} of one plane: plaintext bytes ->
+// logp-bit coefficients (util.rs:289-301) -> recenter_mod (arith.rs:415-427) -> forward NTT mod q0, q1 ->
+// lo | hi << 32 words written straight into the resident format (8-byte or PACKED).
+struct DbEncodeDesc {
+  const uint8_t* win;     // device window of the raw item file
+  size_t win_item0;       // index of the first item in the window
+  size_t win_bytes;       // bytes present in the window
+  size_t file_len;        // total length of the raw file (reads past it yield zeros, server.rs:300-309)
+  u64* db;
+  int db_item_size, bytes_per_chunk, logp;
+  u32 pt_modulus;
+  int planes, num_per, dim0, j0, nj, packed;
+  int jp0, njp;           // local row pairs [jp0, jp0 + njp) to encode
+};
+void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s);
+
 // sweep-native out [plane][r][crt][z][ii] -> reference out[ii].data[r*2N + crt*N + z] (u64) for one plane
 void launch_sweep_out_to_ref(u64* out, const u32* in, int num_per, hipStream_t s);
 

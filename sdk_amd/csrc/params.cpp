@@ -239,6 +239,10 @@ Params Params::from_json(const std::string& json) {  // util.rs:224-263
   if (p.db_dim_1 > 20 || p.db_dim_2 > 20) throw std::runtime_error("params: db dimensions out of range");
   p.finish();
   if (p.expand_queries && ((size_t)1 << p.g()) > p.poly_len) throw std::runtime_error("params: query does not fit one polynomial");
+  // expand_query reads v[2i] for i < dim0 and v[2i+1] for i < t_gsw*nu_2 out of 2^g expanded ciphertexts
+  // (server.rs:566-571); the reference panics (index out of bounds) when they do not fit
+  if (p.expand_queries && p.db_dim_2 > 0 && 2 * std::max(p.dim0(), p.t_gsw * p.db_dim_2) > ((size_t)1 << p.g()))
+    throw std::runtime_error("params: 2*max(2^nu_1, t_gsw*nu_2) exceeds 2^g expanded ciphertexts (server.rs:566-571)");
   return p;
 }
 

@@ -368,6 +368,12 @@ class Database:
         _chk(lib().sp_db_load_plane(_vp(self.h), C.c_int(plane), C.c_int(z0), C.c_int(nz), _p(w)))
         return self
 
+    def load_items(self, blob):
+        """GPU form of load_db_from_seek (server.rs:320-357): `blob` = num_items records of db_item_size bytes."""
+        b = np.frombuffer(blob, dtype=np.uint8) if not isinstance(blob, np.ndarray) else np.ascontiguousarray(blob, dtype=np.uint8)
+        _chk(lib().sp_db_load_items(_vp(self.h), _p(b, u8p), C.c_size_t(b.size)))
+        return self
+
     def fill_synthetic(self, seed):
         _chk(lib().sp_db_fill_synthetic(_vp(self.h), C.c_uint64(seed)))
         return self

@@ -287,6 +287,74 @@ def test_db_device_formats_roundtrip(sp, oracle_mod, num_per_log, dim0_log, shar
             assert (db.read_ref(pl, z, ii, 0, nj) == synth_words(99, idx)).all()
 
 
+@pytest.mark.parametrize("cfg,short", [(dict(FAST, db_item_size=256), 0), (dict(FAST, nu_1=2, nu_2=7, db_item_size=1000), 0),
+                                       (dict(FAST, nu_1=3, nu_2=1, db_item_size=8192), 0),
+                                       (dict(FAST, nu_1=2, nu_2=7, db_item_size=512), 3000),
+                                       (dict(FAST, nu_1=3, nu_2=0, db_item_size=300, p=16), 100)],
+                         ids=["narrow", "packed-ragged-chunk", "full-poly", "packed-short-file", "p16-nu2_0"])
+def test_db_preprocessing_on_gpu(sp, oracle_mod, cfg, short):
+    """sp_db_load_items == load_db_from_seek (server.rs:320-357): every word of the resident database equals
+    the CPU restatement's, incl. ragged chunks, a file shorter than the database, and p != 256."""
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    rng = np.random.default_rng(o.db_item_size)
+    blob = rng.integers(0, 256, o.num_items * o.db_item_size - short, dtype=np.uint8).tobytes()
+    exp = o.load_db_from_bytes(blob).reshape(4, 2048, o.num_per, o.dim0)
+    db = sp.Database(p).load_items(blob)
+    for pl in range(4):
+        for z in (0, 1, 777, 2047):
+            for ii in range(0, o.num_per, max(1, o.num_per // 8)):
+                assert (db.read_ref(pl, z, ii, 0, o.dim0) == exp[pl, z, ii]).all(), (pl, z, ii)
+    # and sharded
+    db2 = sp.Database(p, 1, 2).load_items(blob)
+    assert (db2.read_ref(3, 5, o.num_per - 1, 0, o.dim0 // 2) == exp[3, 5, o.num_per - 1, o.dim0 // 2:]).all()
+
+
+def test_db_preprocessing_then_query_decodes(sp, oracle_mod):
+    cfg = dict(FAST, nu_1=6, nu_2=7, db_item_size=256)
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    with pytest.raises(sp.SpiralError):
+        sp.Params(dict(FAST, nu_1=3, nu_2=7))   # the reference would index out of bounds (server.rs:566-571)
+    rng = np.random.default_rng(3)
+    blob = rng.integers(0, 256, o.num_items * o.db_item_size, dtype=np.uint8).tobytes()
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(8)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    db = sp.Database(p).load_items(blob)
+    for idx in (0, 513, o.num_items - 1):
+        q = cl.generate_query(idx, 9 + idx)
+        resp = sp.process_query(p, gpp, q, db)
+        if idx == 513:
+            assert resp == o.process_query(pp, q, o.load_db_from_bytes(blob))
+        got = cl.decode_response(resp)
+        item = blob[idx * 256:(idx + 1) * 256]
+        assert all(got[t * 64:(t + 1) * 64] == item[t * 64:(t + 1) * 64] for t in range(4))
+
+
+def test_c2_full_size_decodes_planted_items(sp, oracle_mod):
+    """BASELINE.json configs[1] end to end at full size: 2^20 random 256-byte items preprocessed on the GPU
+    (56 GiB resident), a real query from the oracle client, the HIP response decoded by the oracle client
+    must be the queried item's bytes."""
+    import torch
+    from conftest import C2
+    if torch.cuda.mem_get_info()[0] < 70 * 2**30:
+        pytest.skip("needs ~60 GiB of free HBM")
+    o = oracle_mod.Params(C2)
+    p = sp.Params(C2)
+    rng = np.random.default_rng(2024)
+    blob = rng.integers(0, 256, o.num_items * 256, dtype=np.uint8)
+    db = sp.Database(p).load_items(blob)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(77)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    for idx in (0, 123456, o.num_items - 1):
+        resp = sp.process_query(p, gpp, cl.generate_query(idx, 1000 + idx), db)
+        got = cl.decode_response(resp)
+        item = blob[idx * 256:(idx + 1) * 256].tobytes()
+        assert all(got[t * 64:(t + 1) * 64] == item[t * 64:(t + 1) * 64] for t in range(4)), idx
+
+
 def test_c2_full_size_sampled_parity(sp, oracle_mod):
     """BASELINE.json configs[1] at full size (2^20 x 256 B, 64 GiB encoded, 56 GiB packed in HBM):
     the synthetic DB is a pure function of the reference-layout index, so any first-dimension output
