@@ -112,7 +112,8 @@ def main():
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
-    from sdk_amd.sharding import partial_tensor, reduce_partials
+    from sdk_amd.sharding import (gather_local, local_cts_tensor, partial_tensor, reduce_partials,
+                                  reduce_scatter_partials)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -140,15 +141,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    distributed_fold = world > 1 and (1 << cfg["nu_2"]) >= world and os.environ.get("SPIRAL_MULTIGPU", "scatter") == "scatter"
+
     def step(i):
         run = sp.QueryRun(p, pp, queries[i % len(queries)])
-        run.sweep(db)
-        if world > 1:
+        if distributed_fold:
+            # row-sharded sweep -> RCCL reduce-scatter over columns -> every rank folds its columns ->
+            # gather of one ciphertext per plane per rank -> rank 0 folds the last log2(N) levels
+            run.sweep_scatter(db, world)
             run.sync()
-            reduce_partials(partial_tensor(run), dst=0)  # RCCL ncclSum over xGMI; 8 * (q-1) < 2^31
+            mine = reduce_scatter_partials(partial_tensor(run), rank, world)  # 8 * (q-1) < 2^31
+            torch.cuda.synchronize()
+            run.fold_local(mine.data_ptr(), world)
+            run.sync()
+            gathered = gather_local(local_cts_tensor(run), rank, world, dst=0)
+            torch.cuda.synchronize()
+            out = run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
+        elif world > 1:
+            run.sweep(db)
+            run.sync()
+            reduce_partials(partial_tensor(run), dst=0)  # RCCL ncclSum over xGMI onto rank 0
             torch.cuda.synchronize()
             out = run.finish() if rank == 0 else None
         else:
+            run.sweep(db)
             out = run.finish()
         t = run.timings() if out is not None else None
         run.free()
@@ -196,7 +212,7 @@ def main():
             "config": {"workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
                                    "%s" % (args.config, json.dumps(cfg, sort_keys=True),
                                            p.db_words * 8 / 2**30,
-                                           "unsharded" if world == 1 else "row-sharded dim0/%d per GPU + RCCL reduce" % world),
+                                           "unsharded" if world == 1 else ("row-sharded dim0/%d per GPU + RCCL %s" % (world, "reduce-scatter, distributed fold, gather" if distributed_fold else "reduce to rank 0"))),
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
             "roofline": {"bound": "hbm", "kernel": sp.lib().sp_device_count() and ("k_sweep_wide" if cfg["nu_2"] >= 7 else "k_sweep_narrow"),

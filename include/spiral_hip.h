@@ -124,6 +124,19 @@ int sp_process_query_batch(const sp_params_t*, const sp_pp_t* const* pps, const 
  *            8 shards * (q-1) < 2^31) and, on the rank that finishes, writes the sum back.
  *   finish : % q, from_ntt, fold_ciphertexts, pack, encode                (server.rs:707-740)
  * All three enqueue on the query's HIP stream; sp_query_sync() waits for it. */
+/* Distributed-fold variant (what bench.py uses for N > 1), G = number of row shards = ranks, a power of two:
+ *   sweep_scatter : as sweep, but the partial buffer is column-interleaved: chunk g (contiguous,
+ *                   partial_words/G u32) holds columns ii = g mod G as [plane][r][crt][z][ii / G]
+ *   ...           : caller reduce-scatters the partial buffers (RCCL ncclSum, u32): rank g receives chunk g
+ *   fold_local    : % q, from_ntt and the top nu_2 - log2(G) fold levels on this rank's columns
+ *                   -> planes 2x1 raw cts at sp_query_local_cts_ptr() (DEVICE, local_cts_words u64)
+ *   ...           : caller gathers the G local results on the finishing rank: [g][plane][2][N]
+ *   finish_gathered: the last log2(G) fold levels (leaf g = rank g), pack, encode. */
+int sp_query_sweep_scatter(sp_query_t*, const sp_db_t*, int G);
+int sp_query_fold_local(sp_query_t*, const void* reduced_chunk_dev, int G);
+void* sp_query_local_cts_ptr(sp_query_t*);
+size_t sp_query_local_cts_words(const sp_query_t*);
+int sp_query_finish_gathered(sp_query_t*, const void* gathered_dev, int G, uint8_t* out, size_t out_cap, size_t* out_len);
 sp_query_t* sp_query_begin(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len);
 int sp_query_sweep(sp_query_t*, const sp_db_t*);
 void* sp_query_partial_ptr(sp_query_t*);

@@ -424,6 +424,60 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
   });
 }
 
+int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
+  return guarded([&] {
+    need(q && db, "null argument");
+    need(q->state == 1, "sp_query_sweep_scatter: query not in 'begun' state");
+    need(db->params == q->params, "db was created for different params");
+    const Params& p = q->params->p;
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
+         "G must be a power of two <= num_per and equal to the db's num_shards");
+    check_device(db->device);
+    Workspace& W = *q->ws;
+    W.out_G = G;
+    run_sweep(W, *db);
+    W.out_G = 1;
+    HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
+    q->state = 2;
+  });
+}
+
+int sp_query_fold_local(sp_query_t* q, const void* reduced_chunk, int G) {
+  return guarded([&] {
+    need(q && reduced_chunk, "null argument");
+    need(q->state == 2, "sp_query_fold_local: sweep has not run");
+    const Params& p = q->params->p;
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per(), "bad G");
+    run_fold_local(*q->ws, (const u32*)reduced_chunk, G);
+    q->state = 4;
+  });
+}
+void* sp_query_local_cts_ptr(sp_query_t* q) { return q && q->ws ? (void*)q->ws->final_cts.p : nullptr; }
+size_t sp_query_local_cts_words(const sp_query_t* q) { return q ? q->params->p.planes() * 2 * POLY_LEN : 0; }
+
+int sp_query_finish_gathered(sp_query_t* q, const void* gathered, int G, uint8_t* out, size_t out_cap, size_t* out_len) {
+  return guarded([&] {
+    need(q && gathered && out && out_len, "null argument");
+    need(q->state == 4, "sp_query_finish_gathered: local fold has not run");
+    const Params& p = q->params->p;
+    need(out_cap >= p.response_bytes(), "output buffer smaller than response_bytes");
+    Workspace& W = *q->ws;
+    run_finish_gathered(W, *q->pp, (const u64*)gathered, G);
+    HIP_CHECK(hipStreamSynchronize(W.stream));
+    *out_len = encode_response(p, W.h_packed, out);
+    float t = 0;
+    HIP_CHECK(hipEventElapsedTime(&t, W.ev[0], W.ev[1]));
+    q->ms[0] = t;
+    HIP_CHECK(hipEventElapsedTime(&t, W.ev[1], W.ev[2]));
+    q->ms[1] = t;
+    HIP_CHECK(hipEventElapsedTime(&t, W.ev[2], W.ev[3]));
+    q->ms[2] = t;
+    HIP_CHECK(hipEventElapsedTime(&t, W.ev[3], W.ev[4]));
+    q->ms[3] = t;
+    q->state = 3;
+  });
+}
+
 void* sp_query_partial_ptr(sp_query_t* q) { return q && q->ws ? (void*)q->ws->sweep_out.p : nullptr; }
 size_t sp_query_partial_words(const sp_query_t* q) {
   if (!q) return 0;
@@ -673,7 +727,7 @@ int sp_multiply_reg_by_database(const sp_params_t* h, const uint64_t* db, const 
     const int packed = db_can_pack((int)num_per, (int)dim0) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
     launch_db_relayout(d_dev.p, 0, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, packed, W->stream);
     upload_raw(*W, v_firstdim, POLY_LEN * dim0 * 2, d_q);
-    SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0, packed};
+    SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0, packed, 1};
     launch_sweep(W->D->T, d, W->stream);
     launch_sweep_out_to_ref(d_out.p, d_res.p, (int)num_per, W->stream);
     download_raw(*W, d_out.p, num_per * 4 * POLY_LEN, out);
@@ -816,7 +870,10 @@ int sp_fold_ciphertexts(const sp_params_t* h, uint64_t* cts, size_t num_per, con
         HIP_CHECK(hipMemcpyAsync(row + two_t * 2 * POLY_LEN, dF.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
       }
     HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
-    u64* res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per);
+    const long saved = W->fused_min_pairs;
+    W->fused_min_pairs = 1L << 60;  // the stage export honours the caller's v_folding_neg: generic path
+    u64* res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
+    W->fused_min_pairs = saved;
     download_raw(*W, res, 2 * POLY_LEN, cts);
   });
 }

@@ -614,6 +614,35 @@ void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipS
 // operands of v_mad_u64_u32); no cross-lane traffic at all.  Products are < 2^56, so 256 rows are
 // accumulated in u64 between Barrett folds (the reference uses u128 and one % at the end; the
 // residues are identical).
+// flat index of output (plane, rc = r*2+crt, z, ii) in the (possibly column-interleaved) partial buffer
+__device__ __forceinline__ size_t sweep_out_index(const SweepDesc& d, int plane, int rc, int z, int ii) {
+  const int G = d.out_G > 1 ? d.out_G : 1;
+  const int npl = d.num_per / G;
+  const size_t chunk_words = (size_t)d.planes * 4 * N * npl;
+  return (size_t)(ii % G) * chunk_words + (((size_t)plane * 4 + rc) * N + z) * npl + (ii / G);
+}
+__device__ __forceinline__ void sweep_store_pair(const SweepDesc& d, int plane, int z, int ii0, u32 r0c0_a, u32 r0c0_b,
+                                                 u32 r0c1_a, u32 r0c1_b, u32 r1c0_a, u32 r1c0_b, u32 r1c1_a,
+                                                 u32 r1c1_b) {
+  if (d.out_G <= 1) {
+    const size_t rc = (size_t)N * d.num_per;
+    u32* o = d.out + (size_t)plane * 4 * rc + (size_t)z * d.num_per + ii0;
+    *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2(r0c0_a, r0c0_b);
+    *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2(r0c1_a, r0c1_b);
+    *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2(r1c0_a, r1c0_b);
+    *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2(r1c1_a, r1c1_b);
+  } else {
+    d.out[sweep_out_index(d, plane, 0, z, ii0)] = r0c0_a;
+    d.out[sweep_out_index(d, plane, 0, z, ii0 + 1)] = r0c0_b;
+    d.out[sweep_out_index(d, plane, 1, z, ii0)] = r0c1_a;
+    d.out[sweep_out_index(d, plane, 1, z, ii0 + 1)] = r0c1_b;
+    d.out[sweep_out_index(d, plane, 2, z, ii0)] = r1c0_a;
+    d.out[sweep_out_index(d, plane, 2, z, ii0 + 1)] = r1c0_b;
+    d.out[sweep_out_index(d, plane, 3, z, ii0)] = r1c1_a;
+    d.out[sweep_out_index(d, plane, 3, z, ii0 + 1)] = r1c1_b;
+  }
+}
+
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
   const int lane = threadIdx.x & 63;
@@ -686,14 +715,9 @@ __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
     a13 = reduce64(a13, m1);
   }
   // out[plane][r][crt][z][ii]
-  const size_t plane_words = (size_t)4 * N * d.num_per;
-  const size_t zi = (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
-  u32* o = d.out + (size_t)plane * plane_words + zi;
-  const size_t rc = (size_t)N * d.num_per;
-  *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)a00, (u32)a10);  // r=0, crt=0
-  *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)a02, (u32)a12);  // r=0, crt=1
-  *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)a01, (u32)a11);  // r=1, crt=0
-  *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)a03, (u32)a13);  // r=1, crt=1
+  // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
+  sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                   (u32)a03, (u32)a13);
 }
 
 // PACKED wide sweep: as k_sweep_wide, but each lane streams 28 bytes per ROW PAIR (7 dwords = 8 limbs
@@ -745,14 +769,9 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
     a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
     a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
   }
-  const size_t plane_words = (size_t)4 * N * d.num_per;
-  const size_t zi = (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
-  u32* o = d.out + (size_t)plane * plane_words + zi;
-  const size_t rc = (size_t)N * d.num_per;
-  *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)a00, (u32)a10);  // r=0, crt=0
-  *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)a02, (u32)a12);  // r=0, crt=1
-  *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)a01, (u32)a11);  // r=1, crt=0
-  *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)a03, (u32)a13);  // r=1, crt=1
+  // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
+  sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                   (u32)a03, (u32)a13);
 }
 
 // Packing helpers shared by the writers of the PACKED format.
@@ -835,7 +854,7 @@ __global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) 
     const u32 r = reduce64(sacc, which < 2 ? m0 : m1);
     // which: 0 n0_0 (r0,c0)  1 n0_1 (r1,c0)  2 n1_0 (r0,c1)  3 n1_1 (r1,c1)
     const int rr = which & 1, cc = which >> 1;
-    d.out[(((size_t)plane * 2 + rr) * 2 + cc) * N * d.num_per + (size_t)z * d.num_per + ii] = r;
+    d.out[sweep_out_index(d, plane, rr * 2 + cc, z, ii)] = r;
   }
 }
 

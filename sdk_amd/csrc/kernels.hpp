@@ -136,6 +136,9 @@ struct SweepDesc {
   u32* out;
   int planes, num_per, dim0, j0, nj;
   int packed;
+  // out_G > 1: column-interleaved output for the multi-GPU reduce-scatter -- chunk g = ii % out_G holds
+  // [plane][r][crt][z][ii / out_G]; chunks are contiguous (chunk g goes to rank g)
+  int out_G;
 };
 inline bool db_can_pack(int num_per, int nj) { return num_per >= 128 && (nj % 2) == 0; }
 inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {

@@ -29,6 +29,7 @@ struct Workspace {
   u64* h_query = nullptr;
   u64* h_packed = nullptr;
   size_t h_packed_words = 0;
+  int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
   long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused
 
   Workspace(const Params& P, DeviceState& D);
@@ -46,7 +47,9 @@ void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int
 void run_folding_neg(Workspace& W);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
 void run_sweep(Workspace& W, const sp_db& db);
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts);
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
+void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
+void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G);
 void run_fold_all(Workspace& W, bool premod);
 void run_pack(Workspace& W, const sp_pp& pp);
 void run_finish(Workspace& W, const sp_pp& pp, bool premod);

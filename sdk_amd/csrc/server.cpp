@@ -443,13 +443,13 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
 void run_sweep(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
-  SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), db.j0, db.nj, db.packed};
+  SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
   launch_sweep(W.D->T, d, W.stream);
 }
 
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
@@ -457,6 +457,8 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
   int cur = num_cts;
   int further = 0;
   while (((int)1 << further) < num_cts) further++;
+  // level d uses GSW ciphertext v_folding[top - d]; a whole tree has top = further - 1 (server.rs:413,420)
+  const int top_idx = top < 0 ? further - 1 : top;
   for (int d = 0; d < further; d++) {
     const int half = cur / 2;
     // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
@@ -465,7 +467,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
       FoldDesc fd{};
       fd.X = X;
       fd.Y = Y;
-      fd.mats = W.fold_mats.p + (size_t)(further - 1 - d) * 2 * 2 * two_t * 2 * POLY_LEN;
+      fd.mats = W.fold_mats.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN;
       fd.cur = cur;
       fd.half = half;
       fd.planes = np;
@@ -489,7 +491,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts) {
     f.src_cols = 1;
     launch_ntt_fwd(D.T, f, s);
     MacDesc m{};
-    m.A = W.fold_mats.p + (size_t)(further - 1 - d) * 2 * 2 * two_t * 2 * POLY_LEN;
+    m.A = W.fold_mats.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN;
     m.B = W.fold_dig.p;
     m.out = W.fold_ntt.p;
     m.R = 2;
@@ -584,7 +586,7 @@ void run_fold_all(Workspace& W, bool premod) {
     inv.n_polys = np * (int)p.num_per() * 2;
     inv.premod = premod ? 1 : 0;
     launch_ntt_inv(D.T, inv, s);
-    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per());
+    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
     if (p.num_per() == 1) {
       HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
     } else {
@@ -636,6 +638,54 @@ size_t encode_response(const Params& p, const u64* packed, uint8_t* out) {
   }
   memcpy(out, words.data(), total);
   return total;
+}
+
+// ---- distributed fold (multi-GPU reduce-scatter path) ------------------------------------------------
+// This rank's reduced chunk holds columns ii = g + G*i (i < num_per/G) of every plane:
+// [plane][r][crt][z][i].  Folding them uses the top nu_2 - log2(G) selector bits.
+void run_fold_local(Workspace& W, const u32* reduced_chunk, int G) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  W.ensure_finish();
+  const int npl = (int)p.num_per() / G;
+  const size_t pg = W.plane_group();
+  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
+    const int np = (int)std::min(pg, p.planes() - pg0);
+    InvDesc inv{};
+    inv.src = reduced_chunk + pg0 * 4 * POLY_LEN * npl;
+    inv.sweep_np = npl;
+    inv.dst = W.foldX.p;
+    inv.n_polys = np * npl * 2;
+    inv.premod = 1;
+    launch_ntt_inv(D.T, inv, s);
+    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
+    HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  }
+}
+
+// gathered: [G][planes][2][N] raw cts (rank g's local results).  Leaf g of the remaining tree is rank g.
+void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G) {
+  const Params& p = *W.P;
+  hipStream_t s = W.stream;
+  W.ensure_finish();
+  const size_t ctw = 2 * POLY_LEN;
+  const int planes = (int)p.planes();
+  W.foldX.ensure((size_t)planes * G * ctw);
+  W.foldY.ensure((size_t)planes * std::max(G / 2, 1) * ctw);
+  // [g][plane] -> [plane][g]
+  HIP_CHECK(hipMemcpy2DAsync(W.foldX.p, (size_t)G * ctw * 8, gathered, ctw * 8, ctw * 8, (size_t)planes, hipMemcpyDeviceToDevice, s));
+  for (int g = 1; g < G; g++)
+    HIP_CHECK(hipMemcpy2DAsync(W.foldX.p + (size_t)g * ctw, (size_t)G * ctw * 8, gathered + (size_t)g * planes * ctw, ctw * 8,
+                               ctw * 8, (size_t)planes, hipMemcpyDeviceToDevice, s));
+  int lg = 0;
+  while ((1 << lg) < G) lg++;
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, planes, G, lg - 1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, (size_t)planes * ctw * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  HIP_CHECK(hipEventRecord(W.ev[3], s));
+  run_pack(W, pp);
+  HIP_CHECK(hipMemcpyAsync(W.h_packed, W.pack_raw.p, W.h_packed_words * sizeof(u64), hipMemcpyDeviceToHost, s));
+  HIP_CHECK(hipEventRecord(W.ev[4], s));
 }
 
 void run_finish(Workspace& W, const sp_pp& pp, bool premod) {

@@ -36,6 +36,57 @@ def reduce_partials(partial, dst=0):
     return partial
 
 
+class _DevArray64:
+    def __init__(self, ptr, n_words):
+        self.__cuda_array_interface__ = {"shape": (n_words,), "typestr": "<i8", "data": (ptr, False), "version": 2}
+
+
+def local_cts_tensor(run):
+    """Zero-copy torch view (int64, cuda) of a QueryRun's locally folded ciphertexts [plane][2][N]."""
+    import torch
+    return torch.as_tensor(_DevArray64(run.local_cts_ptr(), run.local_cts_words()), device="cuda")
+
+
+def reduce_scatter_partials(partial, rank, world):
+    """Column-interleaved partial buffer (G = world contiguous chunks) -> this rank's summed chunk.
+    nccl (= RCCL): one reduce_scatter; gloo (CPU tests) has no reduce_scatter: all_reduce + slice."""
+    import torch
+    import torch.distributed as dist
+    chunk = partial.numel() // world
+    if dist.get_backend() == "nccl":
+        mine = torch.empty(chunk, dtype=partial.dtype, device=partial.device)
+        dist.reduce_scatter_tensor(mine, partial, op=dist.ReduceOp.SUM)
+        return mine
+    dist.all_reduce(partial, op=dist.ReduceOp.SUM)
+    return partial[rank * chunk:(rank + 1) * chunk].clone()
+
+
+def gather_local(local, rank, world, dst=0):
+    """The G locally folded results -> one [g][...] tensor on `dst` (None elsewhere)."""
+    import torch
+    import torch.distributed as dist
+    out = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous()) if dist.get_backend() == "nccl" else \
+        dist.all_gather(list(out.view(world, -1).unbind(0)), local.contiguous())
+    return out if rank == dst else None
+
+
+def scatter_layout_index(num_per, planes, G, plane, r, crt, z, ii, N=2048):
+    """flat index of output (plane, r, crt, z, ii) in the column-interleaved partial buffer
+    (kernels.hip sweep_out_index): chunk ii % G, then [plane][r][crt][z][ii // G]"""
+    npl = num_per // G
+    chunk_words = planes * 4 * N * npl
+    return (ii % G) * chunk_words + (((plane * 2 + r) * 2 + crt) * N + z) * npl + ii // G
+
+
+def fold_schedule(nu_2, G):
+    """Which GSW selector bits each phase consumes: local phase folds nu_2 - log2(G) levels with
+    v_folding[nu_2-1 .. log2 G]; the final phase folds log2(G) levels with v_folding[log2 G - 1 .. 0]."""
+    lg = G.bit_length() - 1
+    assert 1 << lg == G and lg <= nu_2
+    return list(range(nu_2 - 1, lg - 1, -1)), list(range(lg - 1, -1, -1))
+
+
 def partial_layout_index(num_per, plane, r, crt, z, ii, N=2048):
     return (((plane * 2 + r) * 2 + crt) * N + z) * num_per + ii
 

@@ -433,6 +433,31 @@ class QueryRun:
         _chk(lib().sp_query_sweep(_vp(self.h), _vp(db.h)))
         return self
 
+    def sweep_scatter(self, db, G):
+        """sweep with the column-interleaved partial layout of the distributed-fold path"""
+        _chk(lib().sp_query_sweep_scatter(_vp(self.h), _vp(db.h), C.c_int(G)))
+        return self
+
+    def fold_local(self, reduced_chunk_ptr, G):
+        _chk(lib().sp_query_fold_local(_vp(self.h), C.c_void_p(reduced_chunk_ptr), C.c_int(G)))
+        return self
+
+    def local_cts_ptr(self):
+        lib().sp_query_local_cts_ptr.restype = C.c_void_p
+        return int(lib().sp_query_local_cts_ptr(_vp(self.h)))
+
+    def local_cts_words(self):
+        lib().sp_query_local_cts_words.restype = C.c_size_t
+        return int(lib().sp_query_local_cts_words(_vp(self.h)))
+
+    def finish_gathered(self, gathered_ptr, G):
+        n = self.params.get("response_bytes")
+        out = np.zeros(n, dtype=np.uint8)
+        ln = C.c_size_t(0)
+        _chk(lib().sp_query_finish_gathered(_vp(self.h), C.c_void_p(gathered_ptr), C.c_int(G), _p(out, u8p),
+                                            C.c_size_t(n), C.byref(ln)))
+        return out[:ln.value].tobytes()
+
     def sync(self):
         _chk(lib().sp_query_sync(_vp(self.h)))
 

@@ -266,7 +266,7 @@ def test_db_device_formats_roundtrip(sp, oracle_mod, num_per_log, dim0_log, shar
     """8-byte and 7-byte PACKED device formats: what was loaded (reference layout) / synthesised is what
     sp_db_read_ref returns, for every shard."""
     from sdk_amd.spiral import synth_words
-    cfg = dict(FAST, nu_1=dim0_log, nu_2=num_per_log)
+    cfg = dict(FAST, nu_1=dim0_log, nu_2=num_per_log, t_gsw=2)
     p = sp.Params(cfg)
     N, dim0, num_per = 2048, 1 << dim0_log, 1 << num_per_log
     rng = np.random.default_rng(num_per_log)
@@ -287,9 +287,9 @@ def test_db_device_formats_roundtrip(sp, oracle_mod, num_per_log, dim0_log, shar
             assert (db.read_ref(pl, z, ii, 0, nj) == synth_words(99, idx)).all()
 
 
-@pytest.mark.parametrize("cfg,short", [(dict(FAST, db_item_size=256), 0), (dict(FAST, nu_1=2, nu_2=7, db_item_size=1000), 0),
+@pytest.mark.parametrize("cfg,short", [(dict(FAST, db_item_size=256), 0), (dict(FAST, nu_1=2, nu_2=7, t_gsw=2, db_item_size=1000), 0),
                                        (dict(FAST, nu_1=3, nu_2=1, db_item_size=8192), 0),
-                                       (dict(FAST, nu_1=2, nu_2=7, db_item_size=512), 3000),
+                                       (dict(FAST, nu_1=2, nu_2=7, t_gsw=2, db_item_size=512), 3000),
                                        (dict(FAST, nu_1=3, nu_2=0, db_item_size=300, p=16), 100)],
                          ids=["narrow", "packed-ragged-chunk", "full-poly", "packed-short-file", "p16-nu2_0"])
 def test_db_preprocessing_on_gpu(sp, oracle_mod, cfg, short):
@@ -394,6 +394,41 @@ def test_c2_full_size_sampled_parity(sp, oracle_mod):
             assert (g0, g1) == (e0, e1), (pl, z, ii, r)
     # the whole path still runs to a response of the right size at this scale
     assert len(run.finish()) == p.get("response_bytes")
+
+
+@pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4)],
+                         ids=["narrow-G2", "narrow-G8", "packed-G4"])
+def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G):
+    """The N > 1 bench path (sweep_scatter -> reduce-scatter -> fold_local -> gather -> finish_gathered) with
+    the G ranks played one after another on one GPU; the collective is replaced by a torch sum/slice."""
+    import torch
+    from sdk_amd.sharding import local_cts_tensor, partial_tensor
+    idx = 77
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    expect = o.process_query(pp, q, db)
+    shards = [sp.Database(p, s, G).load(db) for s in range(G)]
+    runs = [sp.QueryRun(p, gpp, q).sweep_scatter(shards[s], G) for s in range(G)]
+    total = None
+    for r in runs:
+        r.sync()
+        t = partial_tensor(r)
+        total = t.clone() if total is None else total + t
+    chunk = total.numel() // G
+    locals_ = []
+    for g, r in enumerate(runs):
+        mine = total[g * chunk:(g + 1) * chunk].contiguous()
+        torch.cuda.synchronize()
+        r.fold_local(mine.data_ptr(), G)
+        r.sync()
+        locals_.append(local_cts_tensor(r).clone())
+    gathered = torch.cat(locals_).contiguous()
+    torch.cuda.synchronize()
+    resp = runs[0].finish_gathered(gathered.data_ptr(), G)
+    assert resp == expect
+    assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
 def test_bad_lengths_raise(sp, oracle_mod):

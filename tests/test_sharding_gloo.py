@@ -68,6 +68,81 @@ def test_row_shard_reduce_gloo(tmp_path, world, dim0, num_per):
     assert out.read_text() == "ok"
 
 
+def _worker_dist_fold(rank, world, port, out_path):
+    """The distributed-fold algorithm of bench.py (N > 1) with the oracle standing in for the kernels."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["OMP_NUM_THREADS"] = "2"
+    import torch
+    import torch.distributed as dist
+    import oracle
+    from conftest import FAST
+    from sdk_amd.sharding import (fold_schedule, gather_local, reduce_scatter_partials, scatter_layout_index,
+                                  shard_rows)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = dict(FAST, nu_2=3)
+    o = oracle.Params(cfg)
+    cl = oracle.Client(o)
+    pp = cl.generate_keys(5)
+    idx = 333
+    q = cl.generate_query(idx, 6)
+    item, db = o.generate_random_db_and_get_item(idx)
+    v_reg, v_fold = o.expand_query(pp, q)
+    v_neg = o.get_v_folding_neg(v_fold)
+    dim0, num_per, planes, nu2 = o.dim0, o.num_per, 4, o.db_dim_2
+    j0, j1 = shard_rows(dim0, rank, world)
+    nj = j1 - j0
+    npl = num_per // world
+    buf = np.zeros(planes * 4 * N * num_per, dtype=np.int32)
+    zz, ii = np.meshgrid(np.arange(N), np.arange(num_per), indexing="ij")
+    dbp = db.reshape(planes, N, num_per, dim0)
+    qv = v_reg.reshape(N, dim0, 2)
+    for pl in range(planes):
+        part = oracle.sweep_rows(np.ascontiguousarray(dbp[pl][:, :, j0:j1]), np.ascontiguousarray(qv[:, j0:j1, :]), N, nj, num_per)
+        for which, (r, crt) in enumerate([(0, 0), (1, 0), (0, 1), (1, 1)]):
+            buf[scatter_layout_index(num_per, planes, world, pl, r, crt, zz, ii)] = part[:, :, which].astype(np.int32)
+    mine = reduce_scatter_partials(torch.from_numpy(buf), rank, world).numpy().astype(np.int64)
+    mine = mine.reshape(planes, 2, 2, N, npl)
+    mine[:, :, 0] %= Q0
+    mine[:, :, 1] %= Q1
+    local_idx, final_idx = fold_schedule(nu2, world)
+    W = 2 * 2 * o.t_gsw * 2 * N  # words per GSW ct
+    lg = world.bit_length() - 1
+    local = []
+    for pl in range(planes):
+        # ct i of this rank = column g + G*i : NTT form [r][crt][z]
+        cts_ntt = np.ascontiguousarray(mine[pl].transpose(3, 0, 1, 2)).astype(np.uint64).reshape(-1)
+        raw = o.from_ntt(cts_ntt)
+        k = len(local_idx)
+        if k:
+            raw = o.fold_ciphertexts(raw, v_fold[lg * W:nu2 * W], v_neg[lg * W:nu2 * W], nu=k)
+        local.append(raw[:2 * N])
+    gathered = gather_local(torch.from_numpy(np.concatenate(local).astype(np.int64)), rank, world, dst=0)
+    if rank == 0:
+        g = gathered.numpy().astype(np.uint64).reshape(world, planes, 2 * N)
+        ok = True
+        slice_words = dim0 * num_per * N
+        for pl in range(planes):
+            cts = np.ascontiguousarray(g[:, pl]).reshape(-1)
+            res = o.fold_ciphertexts(cts, v_fold[:lg * W], v_neg[:lg * W], nu=lg)[:2 * N] if lg else cts[:2 * N]
+            full = o.from_ntt(o.multiply_reg_by_database(db[pl * slice_words:(pl + 1) * slice_words], v_reg))
+            exp = o.fold_ciphertexts(full, v_fold, v_neg)[:2 * N]
+            ok &= bool((res == exp).all())
+        with open(out_path, "w") as f:
+            f.write("ok" if ok else "mismatch")
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_distributed_fold_gloo(tmp_path, world):
+    """reduce-scatter over columns + local fold + gather + final fold == the single-process fold tree."""
+    import torch.multiprocessing as mp
+    out = tmp_path / "res.txt"
+    mp.spawn(_worker_dist_fold, args=(world, _free_port(), str(out)), nprocs=world, join=True)
+    assert out.read_text() == "ok"
+
+
 def test_shard_rows_contract():
     from sdk_amd.sharding import shard_rows
     assert shard_rows(512, 0, 8) == (0, 64) and shard_rows(512, 7, 8) == (448, 512)
