@@ -1520,6 +1520,61 @@ PolyMatrixNTT pack(const Params& params, const std::vector<PolyMatrixRaw>& v_ct,
   return result;
 }
 
+// /root/reference/lib/server/src/compute/pack.rs:46-99
+PolyMatrixNTT pack_v1(const Params& params, const std::vector<PolyMatrixRaw>& v_ct, const std::vector<PolyMatrixNTT>& v_w) {
+  ORACLE_CHECK(v_ct.size() >= params.n * params.n);
+  ORACLE_CHECK(v_w.size() == 2);
+  ORACLE_CHECK(v_ct[0].rows == 2 && v_ct[0].cols == 1);
+  ORACLE_CHECK(v_w[0].rows == params.n + 1 && v_w[0].cols == params.t_conv);
+  const PolyMatrixNTT& w_key = v_w[0];
+  const PolyMatrixNTT& w_shift = v_w[1];
+  PolyMatrixNTT result(&params, params.n + 1, params.n);
+  PolyMatrixRaw ginv(&params, params.t_conv, 1);
+  PolyMatrixNTT ginv_nttd(&params, params.t_conv, 1);
+  PolyMatrixRaw ct_1(&params, 1, 1), ct_2(&params, 1, 1);
+  PolyMatrixNTT ct_2_ntt(&params, 1, 1);
+  for (size_t c = 0; c < params.n; c++) {
+    PolyMatrixNTT v_int(&params, params.n + 1, 1);
+    for (size_t r = 0; r < params.n; r++) {
+      const PolyMatrixRaw& ct = v_ct[r * params.n + c];
+      memcpy(ct_1.get_poly(0, 0), ct.get_poly(0, 0), params.poly_len * 8);
+      memcpy(ct_2.get_poly(0, 0), ct.get_poly(1, 0), params.poly_len * 8);
+      to_ntt(ct_2_ntt, ct_2);
+      gadget_invert(ginv, ct_1);
+      to_ntt(ginv_nttd, ginv);
+      PolyMatrixNTT prod(&params, params.n + 1, 1);
+      multiply(prod, w_key, ginv_nttd);
+      add_into_at(prod, ct_2_ntt, 1, 0);
+      for (size_t sft = 0; sft < r; sft++) {  // shift until correct position
+        PolyMatrixNTT prod_ct_1 = prod.submatrix(0, 0, 1, 1);
+        PolyMatrixNTT prod_ct_rest = prod.submatrix(1, 0, prod.rows - 1, 1);
+        PolyMatrixRaw g2(&params, params.t_conv, 1);
+        gadget_invert(g2, from_ntt_alloc(prod_ct_1));
+        PolyMatrixNTT shifted_part_1 = mul_alloc(w_shift, to_ntt_alloc(g2));
+        // shift_rows_by_one (poly.rs:340-349): last row first
+        PolyMatrixNTT rot = prod_ct_rest;
+        if (prod_ct_rest.rows > 1) {
+          rot = PolyMatrixNTT(&params, prod_ct_rest.rows, 1);
+          rot.copy_into(prod_ct_rest.submatrix(prod_ct_rest.rows - 1, 0, 1, 1), 0, 0);
+          rot.copy_into(prod_ct_rest.submatrix(0, 0, prod_ct_rest.rows - 1, 1), 1, 0);
+        }
+        prod = add_alloc(shifted_part_1, rot.pad_top(1));
+      }
+      add_into(v_int, prod);
+    }
+    result.copy_into(v_int, 0, c);
+  }
+  return result;
+}
+
+// pack.rs:101-113
+PolyMatrixNTT pack_dispatch(const Params& params, const std::vector<PolyMatrixRaw>& v_ct, const std::vector<PolyMatrixNTT>& v_w) {
+  if (params.version == 0) return pack(params, v_ct, v_w);
+  ORACLE_CHECK(params.version == 1);
+  std::vector<PolyMatrixNTT> two(v_w.begin(), v_w.begin() + 2);
+  return pack_v1(params, v_ct, two);
+}
+
 // server.rs:470-503
 std::vector<uint8_t> encode(const Params& params, const std::vector<PolyMatrixRaw>& v_packed_ct) {
   u64 q1 = 4 * params.pt_modulus;
@@ -1636,7 +1691,8 @@ std::vector<uint8_t> process_query(const Params& params, const PublicParameters&
       fold_ciphertexts(params, intermediate_raw, v_folding, v_folding_neg);
       v_ct.push_back(intermediate_raw[0]);
     }
-    PolyMatrixNTT packed_ct = pack(params, v_ct, v_packing);
+    // spiral-rs packs with version 0 only (server.rs:734); version 1 follows lib/server (pack.rs:101-113)
+    PolyMatrixNTT packed_ct = pack_dispatch(params, v_ct, v_packing);
     v_packed_ct[instance] = from_ntt_alloc(packed_ct);
   }
   return encode(params, v_packed_ct);

@@ -260,6 +260,12 @@ void fold_ciphertexts(const Params& params, std::vector<PolyMatrixRaw>& v_cts,
                       const std::vector<PolyMatrixNTT>& v_folding_neg);  // server.rs:388-427
 PolyMatrixNTT pack(const Params& params, const std::vector<PolyMatrixRaw>& v_ct,
                    const std::vector<PolyMatrixNTT>& v_w);  // server.rs:429-468
+// lib/server/src/compute/pack.rs:46-99 (packing version 1: one key-switch matrix + one row-shift matrix);
+// pack_dispatch = pack.rs:101-113
+PolyMatrixNTT pack_v1(const Params& params, const std::vector<PolyMatrixRaw>& v_ct,
+                      const std::vector<PolyMatrixNTT>& v_w);
+PolyMatrixNTT pack_dispatch(const Params& params, const std::vector<PolyMatrixRaw>& v_ct,
+                            const std::vector<PolyMatrixNTT>& v_w);
 std::vector<uint8_t> encode(const Params& params,
                             const std::vector<PolyMatrixRaw>& v_packed_ct);  // server.rs:470-503
 std::vector<PolyMatrixNTT> get_v_folding_neg(const Params& params,

@@ -483,6 +483,33 @@ void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off
   hipLaunchKernelGGL(k_scalar_mul, dim3(2 * N / 256, n_polys), dim3(256), 0, s, T, base, dst_off, src_off, scalar);
 }
 
+__global__ __launch_bounds__(256) void k_add_polys_idx(DevTables T, u32* dst, const int* di, const u32* a, const int* ai,
+                                                        const u32* b, const int* bi) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int k = blockIdx.y;
+  dst[(size_t)di[k] * 2 * N + e] = add_mod(a[(size_t)ai[k] * 2 * N + e], b[(size_t)bi[k] * 2 * N + e], T.c.mod[c].q);
+}
+void launch_add_polys_idx(const DevTables& T, u32* dst, const int* di, const u32* a, const int* ai, const u32* b,
+                          const int* bi, int count, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_add_polys_idx, dim3(2 * N / 256, count), dim3(256), 0, s, T, dst, di, a, ai, b, bi);
+}
+
+__global__ __launch_bounds__(256) void k_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index over [z][j]
+  if (i >= (size_t)N * dim0) return;
+  const int j = (int)(i % dim0);
+  const int z = (int)(i / dim0);
+  const u32* p = row0_ntt + (size_t)j * 2 * N;
+  qv[2 * i] = (u64)p[z] | ((u64)p[N + z] << 32);
+  qv[2 * i + 1] = wire[i];
+}
+void launch_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0, hipStream_t s) {
+  size_t total = (size_t)N * dim0;
+  hipLaunchKernelGGL(k_interleave_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qv, row0_ntt, wire, dim0);
+}
+
 __global__ __launch_bounds__(256) void k_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src,
                                                     const int* src_idx, int src_row_stride, int R) {
   const int e = blockIdx.x * 256 + threadIdx.x;

@@ -96,6 +96,12 @@ void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u3
 // polys [dst_off + b] = scalar (1 poly) * polys [src_off + b], b < n_polys   (multiply_poly, poly.rs:351-358)
 void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off, const u32* scalar, int n_polys,
                        hipStream_t s);
+// dst poly di[k] = a poly ai[k] + b poly bi[k]  (mod q), k < count; a/b/dst may alias
+void launch_add_polys_idx(const DevTables& T, u32* dst, const int* di, const u32* a, const int* ai, const u32* b,
+                          const int* bi, int count, hipStream_t s);
+// direct-upload queries (client.rs:105-128): qv[z][j][0] = lo | hi << 32 of NTT poly j (dense [dim0] polys),
+// qv[z][j][1] = wire[z*dim0 + j]
+void launch_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0, hipStream_t s);
 // gather copy of NTT polys: dst poly (dst_idx[b] + r*dst_row_stride) = src poly (src_idx[b] + r*src_row_stride), r < R
 void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
                        int src_row_stride, int R, int batch, hipStream_t s);

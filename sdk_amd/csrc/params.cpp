@@ -237,6 +237,9 @@ Params Params::from_json(const std::string& json) {  // util.rs:224-263
   if (p.pt_modulus < 2 || (p.pt_modulus & (p.pt_modulus - 1))) throw std::runtime_error("params: p must be a power of two");
   if (p.t_gsw == 0 || p.t_conv == 0 || p.t_exp_left == 0 || p.t_exp_right == 0) throw std::runtime_error("params: zero gadget dimension");
   if (p.db_dim_1 > 20 || p.db_dim_2 > 20) throw std::runtime_error("params: db dimensions out of range");
+  if (p.version > 1) throw std::runtime_error("params: unknown packing version (pack.rs:110-112)");
+  if (p.version == 1 && p.n != 2)
+    throw std::runtime_error("params: version 1 needs n == 2 (client.rs:221 reads n packing matrices, params.rs:149 sizes 2)");
   p.finish();
   if (p.expand_queries && ((size_t)1 << p.g()) > p.poly_len) throw std::runtime_error("params: query does not fit one polynomial");
   // expand_query reads v[2i] for i < dim0 and v[2i+1] for i < t_gsw*nu_2 out of 2^g expanded ciphertexts

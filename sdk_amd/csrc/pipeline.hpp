@@ -24,7 +24,9 @@ struct Workspace {
   DevBuf<u32> sweep_out;  // [plane][r][crt][z][ii]
   // fold / pack
   DevBuf<u64> foldX, foldY, final_cts, pack_raw;
-  DevBuf<u32> fold_dig, fold_ntt, pack_dig, pack_ct2, pack_res;
+  DevBuf<u32> fold_dig, fold_ntt, pack_dig, pack_ct2, pack_res, pack_v1_P, pack_v1_P2;
+  DevBuf<u64> pack_v1_raw, du_raw, du_wire;
+  DevBuf<u32> du_ntt;
   // host staging (pinned)
   u64* h_query = nullptr;
   u64* h_packed = nullptr;
@@ -45,6 +47,7 @@ struct Workspace {
 void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds);
 void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
 void run_folding_neg(Workspace& W);
+void run_begin_direct(Workspace& W, const uint8_t* query);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
 void run_sweep(Workspace& W, const sp_db& db);
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);

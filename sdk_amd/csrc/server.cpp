@@ -171,6 +171,26 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
     D->pack_out = put(out);
     D->pack_row = put(row);
   }
+  if (P.version == 1 && P.n == 2) {
+    std::vector<int> row1, ssrc, rd, ra, rb, sd, sa, sb;
+    const int ne = (int)P.instances * 2;
+    for (int b = 0; b < ne * 2; b++) row1.push_back(b * 3 + 1);
+    for (int e = 0; e < ne; e++) {
+      const int inst = e / 2, c = e % 2, b0 = e * 2, b1 = e * 2 + 1;
+      ssrc.push_back(b1 * 3);
+      rd.push_back(e * 3 + 1); ra.push_back(e * 3 + 1); rb.push_back(b1 * 3 + 2);
+      rd.push_back(e * 3 + 2); ra.push_back(e * 3 + 2); rb.push_back(b1 * 3 + 1);
+      for (int rr = 0; rr < 3; rr++) {
+        sd.push_back(inst * 6 + rr * 2 + c);
+        sa.push_back(b0 * 3 + rr);
+        sb.push_back(e * 3 + rr);
+      }
+    }
+    D->v1_row1 = put(row1);
+    D->v1_shift_src = put(ssrc);
+    D->v1_rot_dst = put(rd); D->v1_rot_a = put(ra); D->v1_rot_b = put(rb);
+    D->v1_sum_dst = put(sd); D->v1_sum_a = put(sa); D->v1_sum_b = put(sb);
+  }
   D->lists.alloc(std::max<size_t>(L.size(), 1));
   if (!L.empty()) HIP_CHECK(hipMemcpy(D->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
   return D;
@@ -412,12 +432,59 @@ void run_folding_neg(Workspace& W) {
   launch_folding_neg(W.D->T, W.fold_mats.p, W.D->gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), W.stream);
 }
 
+// Non-expanded ("direct_upload") queries: Query::deserialize (client.rs:315-327) regenerates the public
+// halves from the seed -- row 0 of each of the dim0 Regev cts (interleave_rng_data, client.rs:105-128), then
+// row 0 of each GSW matrix -- and process_query uses v_buf / v_ct.ntt() as they are (server.rs:666-679).
+void run_begin_direct(Workspace& W, const uint8_t* query) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const size_t dim0 = p.dim0(), nu2 = p.db_dim_2, two_t = 2 * p.t_gsw;
+  const size_t n_reg = dim0 * POLY_LEN;
+  const size_t gsw_polys = nu2 * 2 * two_t;
+  const size_t n_rng = n_reg + nu2 * two_t * POLY_LEN;
+  std::vector<u64> ks(n_rng);
+  chacha20_keystream_u64(query, ks.data(), n_rng);
+  for (auto& x : ks) x = p.modulus - (x % p.modulus);  // get_inv_from_rng, client.rs:47-49
+  const uint8_t* wire = query + SEED_LENGTH;
+  // raw image: [dim0 reg row-0 polys][nu2 GSW matrices 2 x 2t]
+  std::vector<u64> raw((dim0 + gsw_polys) * POLY_LEN);
+  memcpy(raw.data(), ks.data(), n_reg * 8);
+  const uint8_t* wire_gsw = wire + n_reg * 8;
+  for (size_t d = 0; d < nu2; d++) {
+    u64* m = raw.data() + (dim0 + d * 2 * two_t) * POLY_LEN;
+    memcpy(m, ks.data() + n_reg + d * two_t * POLY_LEN, two_t * POLY_LEN * 8);                 // row 0
+    memcpy(m + two_t * POLY_LEN, wire_gsw + d * two_t * POLY_LEN * 8, two_t * POLY_LEN * 8);     // row 1
+  }
+  W.du_raw.ensure(raw.size());
+  W.du_wire.ensure(n_reg);
+  W.du_ntt.ensure((dim0 + gsw_polys) * 2 * POLY_LEN);
+  W.qv.ensure(POLY_LEN * dim0 * 2);
+  W.fold_mats.ensure(std::max<size_t>(nu2, 1) * 2 * 2 * two_t * 2 * POLY_LEN);
+  HIP_CHECK(hipMemcpyAsync(W.du_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice, s));
+  HIP_CHECK(hipMemcpyAsync(W.du_wire.p, wire, n_reg * 8, hipMemcpyHostToDevice, s));
+  FwdDesc f{W.du_raw.p, nullptr, W.du_ntt.p, (int)(dim0 + gsw_polys), 1, 1, 1, 64, 1, 0, 1};
+  launch_ntt_fwd(D.T, f, s);
+  launch_interleave_query(W.qv.p, W.du_ntt.p, W.du_wire.p, (int)dim0, s);
+  const u32* gsw = W.du_ntt.p + dim0 * 2 * POLY_LEN;
+  for (size_t d = 0; d < nu2; d++)
+    for (size_t r = 0; r < 2; r++)
+      HIP_CHECK(hipMemcpyAsync(W.fold_mats.p + ((d * 2 + r) * 2 * two_t + two_t) * 2 * POLY_LEN,
+                               gsw + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32),
+                               hipMemcpyDeviceToDevice, s));
+  run_folding_neg(W);
+  HIP_CHECK(hipStreamSynchronize(s));  // the host staging vectors go out of scope
+}
+
 // Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
-  if (!p.expand_queries) throw ArgError("direct_upload (non-expanded) queries are not supported by this build");
   if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
+  if (!p.expand_queries) {
+    run_begin_direct(W, query);
+    return;
+  }
   if (p.db_dim_2 == 0 && p.t_exp_left != p.t_exp_right) throw ArgError("nu_2 == 0 requires t_exp_left == t_exp_right (server.rs:573)");
   W.ensure_expand();
   hipStream_t s = W.stream;
@@ -519,9 +586,68 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
   return X;
 }
 
+// packing version 1 (lib/server/src/compute/pack.rs:46-99), n == 2: prod = w_key*G^-1(ct_1) + e_1*ct_2;
+// the r = 1 ciphertexts are moved down one row with w_shift; column c = prod(r=0) + shifted prod(r=1).
+static void run_pack_v1(Workspace& W, const sp_pp& pp) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  const int* L = D.lists.p;
+  const int tc = (int)p.t_conv;
+  const int nb = (int)p.planes();         // (inst, c, r)
+  const int ne = (int)p.instances * 2;    // (inst, c)
+  const size_t PW = 2 * POLY_LEN;
+  W.pack_v1_P.ensure((size_t)nb * 3 * PW);
+  W.pack_v1_P2.ensure((size_t)ne * 3 * PW);
+  W.pack_v1_raw.ensure((size_t)ne * POLY_LEN);
+  const u32* w_key = pp.all.p + (pp.off_packing + 0 * 3 * tc) * PW;
+  const u32* w_shift = pp.all.p + (pp.off_packing + 1 * 3 * tc) * PW;
+  FwdDesc f{};
+  f.src = W.final_cts.p;
+  f.src_idx = L + D.pack_src_ct;
+  f.dst = W.pack_dig.p;
+  f.n_out = nb * tc;
+  f.rdim = 1; f.cols = 1; f.t = tc; f.bits = (int)p.bits_per(tc);
+  f.src_batch_stride = 2; f.src_row0 = 0; f.src_cols = 1;
+  launch_ntt_fwd(D.T, f, s);
+  MacDesc m{};
+  m.A = w_key; m.B = W.pack_dig.p; m.out = W.pack_v1_P.p;
+  m.R = 3; m.K = tc; m.batch_inner = nb; m.batch_outer = 1; m.B_inner_stride = tc; m.split_k = tc;
+  m.out_batch_stride = 3; m.out_row_stride = 1;
+  launch_mac(D.T, m, s);
+  FwdDesc f2 = f;
+  f2.dst = W.pack_ct2.p; f2.n_out = nb; f2.t = 1; f2.bits = 64; f2.src_row0 = 1;
+  launch_ntt_fwd(D.T, f2, s);
+  launch_add_poly_into(D.T, W.pack_v1_P.p, L + D.v1_row1, W.pack_ct2.p, nb, s);  // add_into_at(prod, ct_2_ntt, 1, 0)
+  // one shift for the r = 1 elements
+  InvDesc inv{};
+  inv.src = W.pack_v1_P.p; inv.idx = L + D.v1_shift_src; inv.polys_per_idx = 1;
+  inv.idx_stride = (long)PW; inv.poly_stride = (long)PW; inv.crt_stride = POLY_LEN; inv.z_stride = 1;
+  inv.dst = W.pack_v1_raw.p; inv.n_polys = ne;
+  launch_ntt_inv(D.T, inv, s);
+  FwdDesc f3{};
+  f3.src = W.pack_v1_raw.p; f3.dst = W.pack_dig.p; f3.n_out = ne * tc;
+  f3.rdim = 1; f3.cols = 1; f3.t = tc; f3.bits = (int)p.bits_per(tc);
+  f3.src_batch_stride = 1; f3.src_row0 = 0; f3.src_cols = 1;
+  launch_ntt_fwd(D.T, f3, s);
+  MacDesc m2 = m;
+  m2.A = w_shift; m2.out = W.pack_v1_P2.p; m2.batch_inner = ne;
+  launch_mac(D.T, m2, s);
+  launch_add_polys_idx(D.T, W.pack_v1_P2.p, L + D.v1_rot_dst, W.pack_v1_P2.p, L + D.v1_rot_a, W.pack_v1_P.p, L + D.v1_rot_b, 2 * ne, s);
+  launch_add_polys_idx(D.T, W.pack_res.p, L + D.v1_sum_dst, W.pack_v1_P.p, L + D.v1_sum_a, W.pack_v1_P2.p, L + D.v1_sum_b, 3 * ne, s);
+  InvDesc inv2{};
+  inv2.src = W.pack_res.p; inv2.poly_stride = (long)PW; inv2.crt_stride = POLY_LEN; inv2.z_stride = 1;
+  inv2.dst = W.pack_raw.p; inv2.n_polys = (int)(p.instances * 3 * 2);
+  launch_ntt_inv(D.T, inv2, s);
+}
+
 // pack (server.rs:429-468) for all instances, then .raw() (server.rs:736) into pack_raw
 void run_pack(Workspace& W, const sp_pp& pp) {
   const Params& p = *W.P;
+  if (p.version == 1) {
+    run_pack_v1(W, pp);
+    return;
+  }
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
   const int* L = D.lists.p;

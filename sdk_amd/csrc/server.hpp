@@ -96,6 +96,11 @@ struct DeviceState {
   size_t pack_src_ct = 0;    // plane index inst*n*n + r*n + c
   size_t pack_out = 0;       // result poly index inst*(n+1)*n + c           (per (inst,c))
   size_t pack_row = 0;       // result poly index inst*(n+1)*n + (1+r)*n + c (per b)
+  // packing version 1 (lib/server/src/compute/pack.rs:46-99), n == 2: b = (inst*2 + c)*2 + r; e = inst*2 + c
+  size_t v1_row1 = 0;        // [b]  poly index b*3 + 1 in the prod buffer
+  size_t v1_shift_src = 0;   // [e]  poly index of prod[b(r=1)][0]
+  size_t v1_rot_dst = 0, v1_rot_a = 0, v1_rot_b = 0;  // [2e] P2[e][1] += P[b1][2], P2[e][2] += P[b1][1]
+  size_t v1_sum_dst = 0, v1_sum_a = 0, v1_sum_b = 0;  // [3e] result[inst][rr][c] = P[b0][rr] + P2[e][rr]
 };
 
 struct Workspace;

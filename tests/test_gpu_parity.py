@@ -221,6 +221,28 @@ def test_process_query_bytes_and_decode(sp, oracle_mod, cfg, idx):
     assert sp.process_query(p, gpp, q2, gdb) == o.process_query(pp, q2, db)
 
 
+NO_EXPANSION = {"direct_upload": 1, "n": 5, "nu_1": 6, "nu_2": 3, "p": 65536, "q2_bits": 27, "t_gsw": 3, "t_conv": 56,
+                "t_exp_left": 56, "t_exp_right": 56}   # get_no_expansion_testing_params, util.rs:139-153
+
+
+@pytest.mark.parametrize("cfg,idx", [(dict(FAST, version=1), 200), (dict(FAST56, version=1), 300),
+                                     (dict(FAST, version=1, instances=2, db_item_size=16384), 5),
+                                     (dict(FAST, direct_upload=1), 100), (NO_EXPANSION, 400),
+                                     (dict(FAST, direct_upload=1, version=1, nu_2=0), 33)],
+                         ids=["v1", "v1-t56", "v1-inst2", "direct", "direct-n5-p65536", "direct-v1-nu2_0"])
+def test_process_query_next_rows(sp, oracle_mod, cfg, idx):
+    """packing version 1 (lib/server/src/compute/pack.rs:46-99, e2e-tests/params/v1.json) and
+    non-expanded 'direct_upload' queries (server.rs:666-679, client.rs:105-128, 315-327)."""
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 17)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    resp = sp.process_query(p, gpp, sp.Query.deserialize(p, q), gdb)
+    assert resp == o.process_query(pp, q, db)
+    assert cl.decode_response(resp) == o.item_to_vec(item)
+
+
 def test_process_query_c1(sp, oracle_mod):
     """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
     idx = 12345
