@@ -57,6 +57,18 @@ def sweep_algorithmic_bytes(cfg, shards):
     return T * N * num_per * (dim0 // shards) * 8 + T * N * (dim0 // shards) * 2 * 8 + T * num_per * 4 * N * 8
 
 
+def pmc_traffic(cfg_name, world):
+    """HBM bytes per sweep launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled per the
+    gfx950 correction + WRITE_SIZE); bench.py cannot collect counters itself.  None when no matching record."""
+    if cfg_name != "c2" or world != 1:
+        return None
+    path = os.path.join(ROOT, "profiles", "r01_pmc_sweep_c2_packed.json")
+    try:
+        return json.load(open(path))["hbm_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(cfg_name, cfg):
     """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample."""
     import oracle
@@ -215,10 +227,13 @@ def main():
                                            "unsharded" if world == 1 else ("row-sharded dim0/%d per GPU + RCCL %s" % (world, "reduce-scatter, distributed fold, gather" if distributed_fold else "reduce to rank 0"))),
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
-            "roofline": {"bound": "hbm", "kernel": sp.lib().sp_device_count() and ("k_sweep_wide" if cfg["nu_2"] >= 7 else "k_sweep_narrow"),
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": sweep_ms},
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, world),
+                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": sweep_ms,
+                         "note": "achieved = algorithmic bytes (reference 8-byte words) / HIP-event time of the sweep "
+                                 "launch; the resident database is bit-packed to 7 bytes per word, so HBM traffic "
+                                 "(PMC, profiles/r01_pmc_sweep_c2_packed.json) is below the algorithmic bytes"},
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)

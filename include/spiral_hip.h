@@ -84,6 +84,11 @@ int sp_db_load(sp_db_t*, const uint64_t* words, size_t n_words);
  * each record is split into instances*n*n chunks of bytes_per_chunk bytes, log2(p)-bit coefficients,
  * recenter_mod, forward NTT, packed words -- written straight into the resident layout. */
 int sp_db_load_items(sp_db_t*, const uint8_t* file, size_t file_len);
+/* Upsert one item in place (the /write path: lib/server/src/db/loading.rs:317-359 update_item_raw over a
+ * densified bucket; sp_db_create starts from the empty bucket = all-zero polynomials, which is what the
+ * reference's SparseDb yields for absent rows).  `data` is zero-padded to db_item_size.  On a row shard
+ * that does not hold the item's row the call is a no-op. */
+int sp_db_update_item(sp_db_t*, size_t item_idx, const uint8_t* data, size_t len);
 /* Synthetic benchmark database generated on the device: reference-layout word index i holds
  * sp_synth_word(seed, i).  (Roofline runs at sizes no host buffer can hold.) */
 int sp_db_fill_synthetic(sp_db_t*, uint64_t seed);

@@ -183,6 +183,7 @@ sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) {
     d->j0 = shard * d->nj;
     d->packed = db_can_pack((int)p.num_per(), d->nj) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
     d->words.alloc((db_bytes((int)p.planes(), (int)p.num_per(), d->nj, d->packed) + 7) / 8);
+    HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();
   });
@@ -275,9 +276,54 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
       e.packed = d->packed;
       e.jp0 = jp;
       e.njp = cnt;
+      e.only_item = -1;
       launch_db_encode(D.T, e, 0);
       HIP_CHECK(hipDeviceSynchronize());
     }
+  });
+}
+
+int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t len) {
+  return guarded([&] {
+    need(d && (data || len == 0), "null argument");
+    check_device(d->device);
+    sp_params* h = const_cast<sp_params*>(d->params);
+    const Params& p = h->p;
+    need(item_idx < p.num_items(), "item index out of range");
+    need(len <= p.db_item_size, "item longer than db_item_size");
+    const size_t j = item_idx / p.num_per(), ii = item_idx % p.num_per();
+    if ((int)j < d->j0 || (int)j >= d->j0 + d->nj) return;  // row lives on another shard
+    DeviceState& D = h->device_state();
+    std::lock_guard<std::mutex> lk(d->mu);
+    size_t logp = 0;
+    while (((u64)1 << logp) < p.pt_modulus) logp++;
+    const size_t chunks = p.planes();
+    const size_t bpc = (p.db_item_size + chunks - 1) / chunks;
+    DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
+    HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
+    if (len) HIP_CHECK(hipMemcpy(win.p, data, len, hipMemcpyHostToDevice));
+    DbEncodeDesc e{};
+    e.win = win.p;
+    e.win_item0 = item_idx;
+    e.win_bytes = p.db_item_size;
+    e.file_len = (item_idx + 1) * p.db_item_size;  // the record itself is complete (zero padded)
+    e.db = d->words.p;
+    e.db_item_size = (int)p.db_item_size;
+    e.bytes_per_chunk = (int)bpc;
+    e.logp = (int)logp;
+    e.pt_modulus = (u32)p.pt_modulus;
+    e.planes = (int)p.planes();
+    e.num_per = (int)p.num_per();
+    e.dim0 = (int)p.dim0();
+    e.j0 = d->j0;
+    e.nj = d->nj;
+    e.packed = d->packed;
+    e.jp0 = (int)(j - d->j0) / 2;
+    e.njp = 1;
+    e.only_item = (long)item_idx;
+    e.only_q = (int)(ii / 2);
+    launch_db_encode(D.T, e, 0);
+    HIP_CHECK(hipDeviceSynchronize());
   });
 }
 

@@ -1056,7 +1056,8 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
   __shared__ u32 lds0[LDS_WORDS];
   __shared__ u32 lds1[LDS_WORDS];
   const int tau = threadIdx.x;
-  const int qd = blockIdx.x, jp = d.jp0 + blockIdx.y, plane = blockIdx.z;
+  const int qd = d.only_item >= 0 ? d.only_q : blockIdx.x;
+  const int jp = d.jp0 + blockIdx.y, plane = blockIdx.z;
   u64 w[4][8];  // [row a * 2 + ii b][k]: words at z = 8 tau + k
   u32* la = lds0;
   u32* lb = lds1;
@@ -1066,6 +1067,26 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
     const int jl = 2 * jp + a, ii = 2 * qd + b;
     const bool valid = jl < d.nj && ii < d.num_per;
     const size_t item = (size_t)(d.j0 + jl) * d.num_per + ii;  // i = j * num_per + ii (server.rs:332-333)
+    if (d.only_item >= 0 && (long)item != d.only_item) {
+      // keep the neighbour's resident words
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int z = 8 * tau + k;
+        u64 cur = 0;
+        if (valid) {
+          if (d.packed) {
+            const int chunks = d.num_per >> 7, npairs = d.nj >> 1;
+            const u32* unit = reinterpret_cast<const u32*>(d.db) +
+                              ((((size_t)plane * N + z) * npairs + jp) * chunks + (ii >> 7)) * 448;
+            cur = unpack_word(unit, (ii & 127) >> 1, a * 2 + b);
+          } else {
+            cur = d.db[(((size_t)plane * N + z) * d.nj + jl) * d.num_per + ii];
+          }
+        }
+        w[ab][k] = cur;
+      }
+      continue;
+    }
     u32 lo[8], hi[8];
 #pragma unroll 1
     for (int c = 0; c < 2; c++) {
@@ -1115,7 +1136,8 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
 }
 void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s) {
   if (d.njp <= 0) return;
-  hipLaunchKernelGGL(k_db_encode, dim3((d.num_per + 1) / 2, d.njp, d.planes), dim3(256), 0, s, T, d);
+  const unsigned gx = d.only_item >= 0 ? 1u : (unsigned)((d.num_per + 1) / 2);
+  hipLaunchKernelGGL(k_db_encode, dim3(gx, d.njp, d.planes), dim3(256), 0, s, T, d);
 }
 
 __global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* in, int num_per) {

@@ -174,6 +174,10 @@ struct DbEncodeDesc {
   u32 pt_modulus;
   int planes, num_per, dim0, j0, nj, packed;
   int jp0, njp;           // local row pairs [jp0, jp0 + njp) to encode
+  // single-item update (lib/server/src/db/loading.rs:317-359 update_item_raw): only item `only_item`
+  // (global index) is re-encoded, its three quad neighbours keep their resident words; -1 = encode all
+  long only_item;
+  int only_q;             // quad column (ii / 2) of that item
 };
 void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s);
 

@@ -374,6 +374,12 @@ class Database:
         _chk(lib().sp_db_load_items(_vp(self.h), _p(b, u8p), C.c_size_t(b.size)))
         return self
 
+    def update_item(self, item_idx, data):
+        """upsert one item in place (lib/server update_item_raw, loading.rs:317-359)"""
+        b = np.frombuffer(bytes(data), dtype=np.uint8)
+        _chk(lib().sp_db_update_item(_vp(self.h), C.c_size_t(item_idx), _p(b, u8p), C.c_size_t(b.size)))
+        return self
+
     def fill_synthetic(self, seed):
         _chk(lib().sp_db_fill_synthetic(_vp(self.h), C.c_uint64(seed)))
         return self

@@ -332,6 +332,38 @@ def test_db_preprocessing_on_gpu(sp, oracle_mod, cfg, short):
     assert (db2.read_ref(3, 5, o.num_per - 1, 0, o.dim0 // 2) == exp[3, 5, o.num_per - 1, o.dim0 // 2:]).all()
 
 
+@pytest.mark.parametrize("cfg", [dict(FAST, db_item_size=256), dict(FAST, nu_1=2, nu_2=7, t_gsw=2, db_item_size=600)],
+                         ids=["narrow", "packed"])
+def test_db_update_item_sparse_bucket(sp, oracle_mod, cfg):
+    """an initially empty bucket (absent rows = zero polynomials, as lib/server's SparseDb)
+    upserted item by item equals the bulk-preprocessed database; overwriting an item changes only it."""
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    rng = np.random.default_rng(5)
+    isz = o.db_item_size
+    present = sorted(set(int(x) for x in rng.integers(0, o.num_items, 24)))
+    blob = np.zeros(o.num_items * isz, dtype=np.uint8)
+    db = sp.Database(p)
+    assert not db.read_ref(0, 0, 0, 0, o.dim0).any()
+    for i in present:
+        rec = rng.integers(0, 256, isz - (i % 3), dtype=np.uint8)   # short records are zero padded
+        blob[i * isz:i * isz + rec.size] = rec
+        db.update_item(i, rec.tobytes())
+    exp = o.load_db_from_bytes(blob.tobytes()).reshape(4, 2048, o.num_per, o.dim0)
+    for pl in range(4):
+        for z in (0, 9, 2047):
+            for ii in range(o.num_per):
+                assert (db.read_ref(pl, z, ii, 0, o.dim0) == exp[pl, z, ii]).all()
+    i = present[0]
+    blob[i * isz:(i + 1) * isz] = 7
+    db.update_item(i, bytes([7]) * isz)
+    exp = o.load_db_from_bytes(blob.tobytes()).reshape(4, 2048, o.num_per, o.dim0)
+    for ii in range(o.num_per):
+        assert (db.read_ref(2, 100, ii, 0, o.dim0) == exp[2, 100, ii]).all()
+    with pytest.raises(sp.SpiralError):
+        db.update_item(o.num_items, b"x")
+
+
 def test_db_preprocessing_then_query_decodes(sp, oracle_mod):
     cfg = dict(FAST, nu_1=6, nu_2=7, db_item_size=256)
     o = oracle_mod.Params(cfg)
