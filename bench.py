@@ -121,6 +121,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
@@ -145,7 +146,10 @@ def main():
     p = sp.Params(cfg)
     pp = sp.PublicParameters.deserialize(p, synthetic_wire_bytes(p.setup_bytes(), 1))
     queries = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
-    db = sp.Database(p, rank, world).fill_synthetic(0x123456789)  # util.rs:171-173 static seed
+    mode = os.environ.get("SPIRAL_MULTIGPU", "scatter") if world > 1 else "single"
+    if mode in ("scatter", "columns") and (1 << cfg["nu_2"]) < world:
+        mode = "reduce"
+    db = sp.Database(p, rank, world, by_columns=(mode == "columns")).fill_synthetic(0x123456789)  # util.rs:171-173 seed
     torch.cuda.synchronize()
 
     def barrier():
@@ -153,11 +157,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    distributed_fold = world > 1 and (1 << cfg["nu_2"]) >= world and os.environ.get("SPIRAL_MULTIGPU", "scatter") == "scatter"
+    distributed_fold = mode == "scatter"
 
     def step(i):
         run = sp.QueryRun(p, pp, queries[i % len(queries)])
-        if distributed_fold:
+        if mode == "columns":
+            # column shards: complete outputs per shard, no partial sums; only the folded cts are gathered
+            run.sweep(db)
+            run.fold_local(run.partial_ptr(), world)
+            run.sync()
+            gathered = gather_local(local_cts_tensor(run), rank, world, dst=0)
+            torch.cuda.synchronize()
+            out = run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
+        elif distributed_fold:
             # row-sharded sweep -> RCCL reduce-scatter over columns -> every rank folds its columns ->
             # gather of one ciphertext per plane per rank -> rank 0 folds the last log2(N) levels
             run.sweep_scatter(db, world)
@@ -224,7 +236,7 @@ def main():
             "config": {"workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
                                    "%s" % (args.config, json.dumps(cfg, sort_keys=True),
                                            p.db_words * 8 / 2**30,
-                                           "unsharded" if world == 1 else ("row-sharded dim0/%d per GPU + RCCL %s" % (world, "reduce-scatter, distributed fold, gather" if distributed_fold else "reduce to rank 0"))),
+                                           "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts, distributed fold, all-gather" % world, "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow",

@@ -70,6 +70,11 @@ int sp_params_ntt_table(const sp_params_t*, int crt, int which, uint64_t* out_n)
  * one deliberate API change: register once, query many times.
  * Row sharding (multi-GPU): shard `s` of `S` holds first-dimension rows j in [s*dim0/S, (s+1)*dim0/S). */
 sp_db_t* sp_db_create(const sp_params_t*, int shard, int num_shards);
+/* Column sharding (the zero-reduction alternative): shard s of S (a power of two) holds the
+ * output columns ii = s (mod S) of every row.  Each shard's sweep yields complete first-dimension outputs
+ * for its columns, so the flow is sp_query_sweep -> sp_query_fold_local(q, sp_query_partial_ptr(q), S) ->
+ * gather of the local results -> sp_query_finish_gathered; no partial sums cross GPUs. */
+sp_db_t* sp_db_create_columns(const sp_params_t*, int shard, int num_shards);
 void sp_db_free(sp_db_t*);
 /* Upload (a z-range of) one (instance,trial) plane given in the reference layout [z][ii][j] with
  * the FULL dim0 rows per (z,ii); the shard keeps only its rows.  `words` points at row z0.

@@ -167,28 +167,41 @@ int sp_params_ntt_table(const sp_params_t* h, int crt, int which, uint64_t* out_
 }
 
 // ---------------------------------------------------------------------------------------- DB
-sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) {
+static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, bool by_columns) {
   sp_db_t* out = nullptr;
   int rc = guarded([&] {
     need(h != nullptr, "params is null");
     const Params& p = h->p;
     need(num_shards >= 1 && shard >= 0 && shard < num_shards, "bad shard");
-    need(p.dim0() % (size_t)num_shards == 0, "dim0 not divisible by num_shards");
     auto d = std::make_unique<sp_db>();
     d->params = h;
     HIP_CHECK(hipGetDevice(&d->device));
-    d->shard = shard;
-    d->num_shards = num_shards;
-    d->nj = (int)(p.dim0() / num_shards);
-    d->j0 = shard * d->nj;
-    d->packed = db_can_pack((int)p.num_per(), d->nj) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
-    d->words.alloc((db_bytes((int)p.planes(), (int)p.num_per(), d->nj, d->packed) + 7) / 8);
+    if (by_columns) {
+      need((num_shards & (num_shards - 1)) == 0 && p.num_per() % (size_t)num_shards == 0 && (size_t)num_shards <= p.num_per(),
+           "column shards: num_shards must be a power of two dividing num_per");
+      d->col_g = shard;
+      d->col_G = num_shards;
+      d->np_local = (int)(p.num_per() / num_shards);
+      d->nj = (int)p.dim0();
+      d->j0 = 0;
+    } else {
+      need(p.dim0() % (size_t)num_shards == 0, "dim0 not divisible by num_shards");
+      d->shard = shard;
+      d->num_shards = num_shards;
+      d->nj = (int)(p.dim0() / num_shards);
+      d->j0 = shard * d->nj;
+      d->np_local = (int)p.num_per();
+    }
+    d->packed = db_can_pack(d->np_local, d->nj) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
+    d->words.alloc((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8);
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();
   });
   return rc == SP_OK ? out : nullptr;
 }
+sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, false); }
+sp_db_t* sp_db_create_columns(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, true); }
 void sp_db_free(sp_db_t* d) { delete d; }
 size_t sp_db_device_bytes(const sp_db_t* d) { return d ? d->words.bytes() : 0; }
 
@@ -206,8 +219,8 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     for (int z = 0; z < nz; z += zs) {
       const int cnt = std::min(zs, nz - z);
       HIP_CHECK(hipMemcpy(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8, hipMemcpyHostToDevice));
-      launch_db_relayout(d->words.p, plane, stage.p, z0 + z, cnt, (int)p.num_per(), (int)p.dim0(), d->j0, d->nj,
-                         d->packed, 0);
+      launch_db_relayout(d->words.p, plane, stage.p, z0 + z, cnt, d->np_local, (int)p.dim0(), d->j0, d->nj,
+                         d->packed, d->colmap(), 0);
       HIP_CHECK(hipDeviceSynchronize());
     }
   });
@@ -269,7 +282,8 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
       e.logp = (int)logp;
       e.pt_modulus = (u32)p.pt_modulus;
       e.planes = (int)p.planes();
-      e.num_per = (int)p.num_per();
+      e.num_per = d->np_local;
+      e.cm = d->colmap();
       e.dim0 = (int)p.dim0();
       e.j0 = d->j0;
       e.nj = d->nj;
@@ -293,6 +307,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     need(len <= p.db_item_size, "item longer than db_item_size");
     const size_t j = item_idx / p.num_per(), ii = item_idx % p.num_per();
     if ((int)j < d->j0 || (int)j >= d->j0 + d->nj) return;  // row lives on another shard
+    if ((int)(ii % (size_t)d->col_G) != d->col_g) return;   // column lives on another shard
     DeviceState& D = h->device_state();
     std::lock_guard<std::mutex> lk(d->mu);
     size_t logp = 0;
@@ -313,7 +328,8 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     e.logp = (int)logp;
     e.pt_modulus = (u32)p.pt_modulus;
     e.planes = (int)p.planes();
-    e.num_per = (int)p.num_per();
+    e.num_per = d->np_local;
+    e.cm = d->colmap();
     e.dim0 = (int)p.dim0();
     e.j0 = d->j0;
     e.nj = d->nj;
@@ -321,7 +337,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     e.jp0 = (int)(j - d->j0) / 2;
     e.njp = 1;
     e.only_item = (long)item_idx;
-    e.only_q = (int)(ii / 2);
+    e.only_q = (int)((ii / (size_t)d->col_G) / 2);
     launch_db_encode(D.T, e, 0);
     HIP_CHECK(hipDeviceSynchronize());
   });
@@ -332,7 +348,7 @@ int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
     need(d != nullptr, "null db");
     check_device(d->device);
     const Params& p = d->params->p;
-    launch_db_synth(d->words.p, seed, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), d->j0, d->nj, d->packed, 0);
+    launch_db_synth(d->words.p, seed, (int)p.planes(), d->np_local, (int)p.dim0(), d->j0, d->nj, d->packed, d->colmap(), 0);
     HIP_CHECK(hipDeviceSynchronize());
   });
 }
@@ -344,9 +360,10 @@ int sp_db_read_ref(const sp_db_t* d, int plane, int z, int ii, int j0, int count
     const Params& p = d->params->p;
     need(plane >= 0 && (size_t)plane < p.planes() && z >= 0 && z < N && ii >= 0 && (size_t)ii < p.num_per() && j0 >= 0 &&
              count >= 0 && j0 + count <= d->nj, "bad coordinates");
+    need(ii % d->col_G == d->col_g, "column is held by another shard");
     check_device(d->device);
     DevBuf<u64> tmp((size_t)std::max(count, 1));
-    launch_db_read(tmp.p, d->words.p, plane, z, ii, j0, count, (int)p.num_per(), d->nj, d->packed, 0);
+    launch_db_read(tmp.p, d->words.p, plane, z, ii / d->col_G, j0, count, d->np_local, d->nj, d->packed, 0);
     HIP_CHECK(hipMemcpy(out, tmp.p, (size_t)count * 8, hipMemcpyDeviceToHost));
   });
 }
@@ -478,6 +495,7 @@ int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
     const Params& p = q->params->p;
     need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
          "G must be a power of two <= num_per and equal to the db's num_shards");
+    need(db->col_G == 1, "sweep_scatter works on row shards");
     check_device(db->device);
     Workspace& W = *q->ws;
     W.out_G = G;
@@ -577,8 +595,8 @@ void sp_query_free(sp_query_t* q) { delete q; }
 
 int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
                      const sp_db_t* db, uint8_t* out, size_t out_cap, size_t* out_len) {
-  if (db && db->num_shards != 1) {
-    g_last_error = "sp_process_query needs an unsharded db; use sp_query_begin/sweep/finish for row shards";
+  if (db && (db->num_shards != 1 || db->col_G != 1)) {
+    g_last_error = "sp_process_query needs an unsharded db; use sp_query_begin/sweep/finish for shards";
     return SP_E_ARG;
   }
   sp_query_t* q = sp_query_begin(h, pp, query, query_len);
@@ -771,7 +789,7 @@ int sp_multiply_reg_by_database(const sp_params_t* h, const uint64_t* db, const 
     DevBuf<u32> d_res(4 * POLY_LEN * num_per);
     HIP_CHECK(hipMemcpyAsync(d_ref.p, db, words * 8, hipMemcpyHostToDevice, W->stream));
     const int packed = db_can_pack((int)num_per, (int)dim0) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
-    launch_db_relayout(d_dev.p, 0, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, packed, W->stream);
+    launch_db_relayout(d_dev.p, 0, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, packed, ColMap{}, W->stream);
     upload_raw(*W, v_firstdim, POLY_LEN * dim0 * 2, d_q);
     SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0, packed, 1};
     launch_sweep(W->D->T, d, W->stream);

@@ -915,17 +915,17 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
 
 // reference [z][ii][j] -> device [z][j - j0][ii] for nz rows starting at z0 (32x32 LDS tile transpose)
 __global__ __launch_bounds__(256) void k_db_relayout(u64* dst_plane, const u64* src, int z0, int num_per, int dim0,
-                                                     int j0, int nj) {
+                                                     int j0, int nj, ColMap cm) {
   __shared__ u64 tile[32][33];
   const int zl = blockIdx.z;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   const int jt = blockIdx.x * 32, it = blockIdx.y * 32;
-  const u64* s = src + (size_t)zl * num_per * dim0;
+  const u64* s = src + (size_t)zl * cm.np_global * dim0;
   u64* dpl = dst_plane + (size_t)(z0 + zl) * nj * num_per;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     int ii = it + ty + 8 * i, j = jt + tx;
-    if (ii < num_per && j < nj) tile[ty + 8 * i][tx] = s[(size_t)ii * dim0 + j0 + j];
+    if (ii < num_per && j < nj) tile[ty + 8 * i][tx] = s[(size_t)(cm.off + cm.stride * ii) * dim0 + j0 + j];
   }
   __syncthreads();
 #pragma unroll
@@ -936,7 +936,7 @@ __global__ __launch_bounds__(256) void k_db_relayout(u64* dst_plane, const u64* 
 }
 // reference layout -> PACKED: one thread per (z, jp, chunk, lane); gathers its 4 words (one-time cost)
 __global__ __launch_bounds__(256) void k_db_relayout_packed(u32* dst, int plane, const u64* src, int z0, int nz,
-                                                            int num_per, int dim0, int j0, int nj) {
+                                                            int num_per, int dim0, int j0, int nj, ColMap cm) {
   const int chunks = num_per >> 7, npairs = nj >> 1;
   const size_t total = (size_t)nz * npairs * chunks * 64;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
@@ -947,39 +947,41 @@ __global__ __launch_bounds__(256) void k_db_relayout_packed(u32* dst, int plane,
     const int jp = (int)(t % npairs);
     const int zl = (int)(t / npairs);
     const int ii = chunk * 128 + 2 * lane;
-    const u64* s = src + ((size_t)zl * num_per + ii) * dim0 + j0 + 2 * jp;
-    const u64 w00 = s[0], w10 = s[1], w01 = s[dim0], w11 = s[dim0 + 1];
+    const u64* s = src + ((size_t)zl * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + 2 * jp;
+    const size_t nx = (size_t)cm.stride * dim0;  // next local column
+    const u64 w00 = s[0], w10 = s[1], w01 = s[nx], w11 = s[nx + 1];
     u32* unit = dst + ((((size_t)plane * N + (z0 + zl)) * npairs + jp) * chunks + chunk) * 448;
     pack_unit_lane(unit, lane, w00, w01, w10, w11);
   }
 }
 void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
-                        int packed, hipStream_t s) {
+                        int packed, ColMap cm, hipStream_t s) {
+  if (cm.np_global == 0) cm.np_global = num_per;
   if (nz <= 0) return;
   if (packed) {
     hipLaunchKernelGGL(k_db_relayout_packed, dim3(4096), dim3(256), 0, s, reinterpret_cast<u32*>(dst), plane, src, z0,
-                       nz, num_per, dim0, j0, nj);
+                       nz, num_per, dim0, j0, nj, cm);
   } else {
     u64* dst_plane = dst + (size_t)plane * N * nj * num_per;
     hipLaunchKernelGGL(k_db_relayout, dim3((nj + 31) / 32, (num_per + 31) / 32, nz), dim3(256), 0, s, dst_plane, src,
-                       z0, num_per, dim0, j0, nj);
+                       z0, num_per, dim0, j0, nj, cm);
   }
 }
 
 __global__ __launch_bounds__(256) void k_db_synth(u64* dst, u64 seed, int num_per, int dim0, int j0, int nj,
-                                                  size_t total) {
+                                                  size_t total, ColMap cm) {
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
     // device index i = ((zp * nj) + jl) * num_per + ii
     size_t ii = i % num_per;
     size_t t = i / num_per;
     size_t jl = t % nj;
     size_t zp = t / nj;
-    size_t ref = (zp * num_per + ii) * dim0 + j0 + jl;
+    size_t ref = (zp * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + jl;
     dst[i] = synth_word(seed, ref);
   }
 }
 __global__ __launch_bounds__(256) void k_db_synth_packed(u32* dst, u64 seed, int num_per, int dim0, int j0, int nj,
-                                                         size_t total_lanes) {
+                                                         size_t total_lanes, ColMap cm) {
   const int chunks = num_per >> 7, npairs = nj >> 1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_lanes; i += (size_t)gridDim.x * 256) {
     const int lane = (int)(i & 63);
@@ -989,20 +991,22 @@ __global__ __launch_bounds__(256) void k_db_synth_packed(u32* dst, u64 seed, int
     const int jp = (int)(t2 % npairs);
     const size_t zp = t2 / npairs;
     const size_t ii = (size_t)chunk * 128 + 2 * lane;
-    const size_t r0 = (zp * num_per + ii) * dim0 + j0 + 2 * jp;  // (row 2jp, ii)
-    const size_t r1 = r0 + dim0;                                 // (row 2jp, ii+1)
+    const size_t r0 = (zp * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + 2 * jp;  // (row 2jp, ii)
+    const size_t r1 = r0 + (size_t)cm.stride * dim0;                                         // (row 2jp, ii+1)
     pack_unit_lane(dst + t * 448, lane, synth_word(seed, r0), synth_word(seed, r1), synth_word(seed, r0 + 1),
                    synth_word(seed, r1 + 1));
   }
 }
-void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, int packed, hipStream_t s) {
+void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, int packed, ColMap cm,
+                     hipStream_t s) {
+  if (cm.np_global == 0) cm.np_global = num_per;
   if (packed) {
     size_t lanes = (size_t)planes * N * (nj >> 1) * (num_per >> 7) * 64;
     hipLaunchKernelGGL(k_db_synth_packed, dim3(256 * 32), dim3(256), 0, s, reinterpret_cast<u32*>(dst), seed, num_per,
-                       dim0, j0, nj, lanes);
+                       dim0, j0, nj, lanes, cm);
   } else {
     size_t total = (size_t)planes * N * nj * num_per;
-    hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total);
+    hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total, cm);
   }
 }
 
@@ -1066,7 +1070,8 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
     const int a = ab >> 1, b = ab & 1;
     const int jl = 2 * jp + a, ii = 2 * qd + b;
     const bool valid = jl < d.nj && ii < d.num_per;
-    const size_t item = (size_t)(d.j0 + jl) * d.num_per + ii;  // i = j * num_per + ii (server.rs:332-333)
+    // i = j * num_per + ii (server.rs:332-333), ii = global column of local column `ii`
+    const size_t item = (size_t)(d.j0 + jl) * d.cm.np_global + d.cm.off + (size_t)d.cm.stride * ii;
     if (d.only_item >= 0 && (long)item != d.only_item) {
       // keep the neighbour's resident words
 #pragma unroll

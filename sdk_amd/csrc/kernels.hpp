@@ -146,6 +146,11 @@ struct SweepDesc {
   // [plane][r][crt][z][ii / out_G]; chunks are contiguous (chunk g goes to rank g)
   int out_G;
 };
+// Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
+// i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.
+struct ColMap {
+  int off = 0, stride = 1, np_global = 0;
+};
 inline bool db_can_pack(int num_per, int nj) { return num_per >= 128 && (nj % 2) == 0; }
 inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {
   return (size_t)planes * N * nj * num_per * (packed ? 7 : 8);
@@ -155,8 +160,9 @@ const char* sweep_kernel_name(int num_per);
 // reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order
 // words already on the device), dst plane base; keeps rows j0..j0+nj
 void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,
-                        int packed, hipStream_t s);
-void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, int packed, hipStream_t s);
+                        int packed, ColMap cm, hipStream_t s);
+void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int j0, int nj, int packed, ColMap cm,
+                     hipStream_t s);
 // read back words (plane, z, ii, j_local0 .. +count) of either device format into out[count] (device)
 void launch_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, int count, int num_per, int nj,
                     int packed, hipStream_t s);
@@ -177,7 +183,8 @@ struct DbEncodeDesc {
   // single-item update (lib/server/src/db/loading.rs:317-359 update_item_raw): only item `only_item`
   // (global index) is re-encoded, its three quad neighbours keep their resident words; -1 = encode all
   long only_item;
-  int only_q;             // quad column (ii / 2) of that item
+  int only_q;             // quad column (local ii / 2) of that item
+  ColMap cm;              // num_per above is the LOCAL column count
 };
 void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s);
 

@@ -510,7 +510,7 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
 void run_sweep(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
-  SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), (int)p.num_per(), (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
+  SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), db.np_local, (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
   launch_sweep(W.D->T, d, W.stream);
 }
 

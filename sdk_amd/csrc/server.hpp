@@ -136,6 +136,9 @@ struct sp_db {
   int shard = 0, num_shards = 1;
   int j0 = 0, nj = 0;
   int packed = 0;                     // 7-byte PACKED device format (kernels.hpp) vs 8-byte words
+  int col_g = 0, col_G = 1;           // column shard: holds columns ii = col_g (mod col_G)
+  int np_local = 0;                   // columns held = num_per / col_G
+  spiral::ColMap colmap() const { return spiral::ColMap{col_g, col_G, np_local * col_G}; }
   spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii] (or the PACKED unit stream)
   std::mutex mu;
 };

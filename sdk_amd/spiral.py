@@ -341,10 +341,12 @@ class Database:
 
     shard/num_shards row-shard the first dimension across GPUs (one Database per process/GPU)."""
 
-    def __init__(self, params, shard=0, num_shards=1):
+    def __init__(self, params, shard=0, num_shards=1, by_columns=False):
         self.params = params
-        self.shard, self.num_shards = shard, num_shards
-        self.h = lib().sp_db_create(_vp(params.h), C.c_int(shard), C.c_int(num_shards))
+        self.shard, self.num_shards, self.by_columns = shard, num_shards, by_columns
+        lib().sp_db_create_columns.restype = C.c_void_p
+        create = lib().sp_db_create_columns if by_columns else lib().sp_db_create
+        self.h = create(_vp(params.h), C.c_int(shard), C.c_int(num_shards))
         if not self.h:
             raise SpiralError(_err())
 
