@@ -119,6 +119,9 @@ def main():
     ap.add_argument("--config", default=os.environ.get("SPIRAL_BENCH_CONFIG", "c2"), choices=sorted(CONFIGS))
     ap.add_argument("--sweep-iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--batch", type=int, default=1,
+                    help="queries per step (N = 1 only); > 1 uses sp_process_query_batch: groups of <= 8 queries "
+                         "share one database pass (BASELINE configs[4]).  Default 1 = the single-query metric.")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
@@ -160,6 +163,9 @@ def main():
     distributed_fold = mode == "scatter"
 
     def step(i):
+        if args.batch > 1 and world == 1:
+            outs = sp.process_query_batch(p, pp, [queries[(i + k) % len(queries)] for k in range(args.batch)], db)
+            return outs[0], None
         run = sp.QueryRun(p, pp, queries[i % len(queries)])
         if mode == "columns":
             # column shards: complete outputs per shard, no partial sums; only the folded cts are gathered
@@ -222,7 +228,7 @@ def main():
         line = {
             "metric": "PIR queries/sec (single query, full answer path) on 2^%d items x %d B" %
                       (cfg["nu_1"] + cfg["nu_2"], cfg["db_item_size"]),
-            "value": args.steps / elapsed,
+            "value": args.steps * (args.batch if world == 1 else 1) / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -237,6 +243,7 @@ def main():
                                    "%s" % (args.config, json.dumps(cfg, sort_keys=True),
                                            p.db_words * 8 / 2**30,
                                            "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts, distributed fold, all-gather" % world, "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
+                       "queries_per_step": args.batch if world == 1 else 1,
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow",

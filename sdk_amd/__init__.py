@@ -30,6 +30,7 @@ from .spiral import (  # noqa: F401
     pack,
     params_from_json,
     process_query,
+    process_query_batch,
     regev_to_gsw,
     reorient_reg_ciphertexts,
     to_ntt,

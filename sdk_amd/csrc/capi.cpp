@@ -610,12 +610,70 @@ int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* que
 int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, const uint8_t* const* queries,
                            const size_t* query_lens, int batch, const sp_db_t* db, uint8_t* out, size_t out_stride,
                            size_t* out_len) {
-  if (!pps || !queries || !query_lens || batch < 0) {
+  if (!h || !pps || !queries || !query_lens || batch < 0 || !db || !out || !out_len) {
     g_last_error = "null argument";
     return SP_E_ARG;
   }
-  for (int i = 0; i < batch; i++) {
-    int rc = sp_process_query(h, pps[i], queries[i], query_lens[i], db, out + (size_t)i * out_stride, out_stride, out_len);
+  const Params& p = h->p;
+  const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !getenv("SPIRAL_NO_BATCH_SWEEP");
+  if (!batched) {  // 8-byte / narrow databases: one pass per query
+    for (int i = 0; i < batch; i++) {
+      int rc = sp_process_query(h, pps[i], queries[i], query_lens[i], db, out + (size_t)i * out_stride, out_stride, out_len);
+      if (rc != SP_OK) return rc;
+    }
+    return SP_OK;
+  }
+  if (out_stride < p.response_bytes()) {
+    g_last_error = "out_stride smaller than response_bytes";
+    return SP_E_ARG;
+  }
+  int group_max = SWEEP_BATCH_MAX;
+  if (const char* e = getenv("SPIRAL_BATCH_GROUP")) group_max = std::max(1, std::min(SWEEP_BATCH_MAX, atoi(e)));
+  for (int g0 = 0; g0 < batch; g0 += group_max) {
+    const int B = std::min(group_max, batch - g0);
+    std::vector<sp_query_t*> qs;
+    int rc = guarded([&] {
+      check_device(db->device);
+      // 1. expand every query of the group on its own stream
+      for (int i = 0; i < B; i++) {
+        sp_query_t* q = sp_query_begin(h, pps[g0 + i], queries[g0 + i], query_lens[g0 + i]);
+        if (!q) throw ArgError(g_last_error);
+        qs.push_back(q);
+        q->ws->ensure_sweep();
+      }
+      // 2. one database pass for the whole group, on the first query's stream
+      Workspace& W0 = *qs[0]->ws;
+      SweepBatchDesc d{};
+      d.db = db->words.p;
+      d.batch = B;
+      d.planes = (int)p.planes();
+      d.num_per = db->np_local;
+      d.dim0 = (int)p.dim0();
+      d.j0 = db->j0;
+      d.nj = db->nj;
+      for (int i = 0; i < B; i++) {
+        d.qv[i] = qs[i]->ws->qv.p;
+        d.out[i] = qs[i]->ws->sweep_out.p;
+        if (i > 0) HIP_CHECK(hipStreamWaitEvent(W0.stream, qs[i]->ws->ev[1], 0));
+      }
+      launch_sweep_batch(W0.D->T, d, W0.stream);
+      HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
+      // 3. fold / pack per query, concurrently on the queries' own streams
+      for (int i = 0; i < B; i++) {
+        Workspace& W = *qs[i]->ws;
+        if (i > 0) {
+          HIP_CHECK(hipStreamWaitEvent(W.stream, W0.ev[2], 0));
+          HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
+        }
+        run_finish(W, *qs[i]->pp, false);
+      }
+      for (int i = 0; i < B; i++) {
+        Workspace& W = *qs[i]->ws;
+        HIP_CHECK(hipStreamSynchronize(W.stream));
+        *out_len = encode_response(p, W.h_packed, out + (size_t)(g0 + i) * out_stride);
+      }
+    });
+    for (auto* q : qs) sp_query_free(q);
     if (rc != SP_OK) return rc;
   }
   return SP_OK;

@@ -801,6 +801,90 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
                    (u32)a03, (u32)a13);
 }
 
+// Multi-query PACKED sweep: B queries share one pass over the database (BASELINE configs[4]).  Per row
+// pair: one 28-byte load, B x 2 scalar query rows, 16 B multiply-accumulates.  HBM-bound up to B ~ 4,
+// integer-ALU-bound beyond.
+template <int B>
+__global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBatchDesc d) {
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  if (plane >= d.planes) return;
+  const int npairs = d.nj >> 1;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
+  const size_t ustride = (size_t)chunks * 448;
+  const size_t qoff = (size_t)z * d.dim0 + d.j0;
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  u64 acc[B][8];
+#pragma unroll
+  for (int b = 0; b < B; b++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[b][k] = 0;
+  for (int jb = 0; jb < npairs; jb += 128) {
+    const int je = min(jb + 128, npairs);
+    for (int jp = jb; jp < je; jp++) {
+      const u32* u = base + (size_t)jp * ustride;
+      const u32x4_t va = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
+      const u32x3_t vb = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+      const u32 d0 = va.x, d1 = va.y, d2 = va.z, d3 = va.w, d4 = vb.x, d5 = vb.y, d6 = vb.z;
+      const u32 f0 = d0 & M;
+      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+      const u32 f7 = d6 >> 4;
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv[b]) + qoff;
+        const uint4 qa = qrow[2 * jp];
+        const uint4 qb = qrow[2 * jp + 1];
+        acc[b][0] += (u64)qa.x * f0; acc[b][1] += (u64)qa.z * f0; acc[b][2] += (u64)qa.y * f1; acc[b][3] += (u64)qa.w * f1;
+        acc[b][4] += (u64)qa.x * f2; acc[b][5] += (u64)qa.z * f2; acc[b][6] += (u64)qa.y * f3; acc[b][7] += (u64)qa.w * f3;
+        acc[b][0] += (u64)qb.x * f4; acc[b][1] += (u64)qb.z * f4; acc[b][2] += (u64)qb.y * f5; acc[b][3] += (u64)qb.w * f5;
+        acc[b][4] += (u64)qb.x * f6; acc[b][5] += (u64)qb.z * f6; acc[b][6] += (u64)qb.y * f7; acc[b][7] += (u64)qb.w * f7;
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);
+      acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);
+      acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);
+      acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);
+    }
+  }
+  const size_t rc = (size_t)N * d.num_per;
+  const size_t zi = (size_t)plane * 4 * rc + (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    u32* o = d.out[b] + zi;
+    *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)acc[b][0], (u32)acc[b][4]);  // r=0, crt=0
+    *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)acc[b][2], (u32)acc[b][6]);  // r=0, crt=1
+    *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)acc[b][1], (u32)acc[b][5]);  // r=1, crt=0
+    *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)acc[b][3], (u32)acc[b][7]);  // r=1, crt=1
+  }
+}
+void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
+  const long units = (long)d.planes * N * (d.num_per >> 7);
+  const dim3 grid((unsigned)((units + 3) / 4));
+  switch (d.batch) {
+    case 1: hipLaunchKernelGGL(k_sweep_packed_batch<1>, grid, dim3(256), 0, s, T, d); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_batch<2>, grid, dim3(256), 0, s, T, d); break;
+    case 3: hipLaunchKernelGGL(k_sweep_packed_batch<3>, grid, dim3(256), 0, s, T, d); break;
+    case 4: hipLaunchKernelGGL(k_sweep_packed_batch<4>, grid, dim3(256), 0, s, T, d); break;
+    case 5: hipLaunchKernelGGL(k_sweep_packed_batch<5>, grid, dim3(256), 0, s, T, d); break;
+    case 6: hipLaunchKernelGGL(k_sweep_packed_batch<6>, grid, dim3(256), 0, s, T, d); break;
+    case 7: hipLaunchKernelGGL(k_sweep_packed_batch<7>, grid, dim3(256), 0, s, T, d); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_batch<8>, grid, dim3(256), 0, s, T, d); break;
+  }
+}
+
 // Packing helpers shared by the writers of the PACKED format.
 __device__ __forceinline__ void pack_unit_lane(u32* unit, int lane, u64 w00, u64 w01, u64 w10, u64 w11) {
   // w{row}{iiofs}: limbs f0..f7 = lo/hi of w00, w01, w10, w11

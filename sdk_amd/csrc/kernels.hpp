@@ -156,6 +156,17 @@ inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {
   return (size_t)planes * N * nj * num_per * (packed ? 7 : 8);
 }
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
+// B queries against ONE pass over the (PACKED) database: every database word is multiplied into B
+// accumulator sets.  B <= SWEEP_BATCH_MAX; qv[b] / out[b] as in SweepDesc.
+constexpr int SWEEP_BATCH_MAX = 8;
+struct SweepBatchDesc {
+  const u64* db;
+  const u64* qv[SWEEP_BATCH_MAX];
+  u32* out[SWEEP_BATCH_MAX];
+  int batch;
+  int planes, num_per, dim0, j0, nj;
+};
+void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);
 const char* sweep_kernel_name(int num_per);
 // reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order
 // words already on the device), dst plane base; keeps rows j0..j0+nj

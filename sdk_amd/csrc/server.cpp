@@ -271,7 +271,10 @@ void Workspace::ensure_expand() {
 
 size_t Workspace::plane_group() const {
   const Params& p = *P;
-  size_t per_plane = p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN * sizeof(u32);  // fold digits
+  const bool fused_ok = 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64 && fused_min_pairs < (1L << 40);
+  // raw ct staging (X, Y) per plane; plus the digit staging when the unfused path handles whole levels
+  size_t per_plane = p.num_per() * 2 * POLY_LEN * sizeof(u64) * 2;
+  if (!fused_ok) per_plane += p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN * sizeof(u32);
   size_t budget = (size_t)2 << 30;
   size_t pg = std::max<size_t>(1, budget / std::max<size_t>(per_plane, 1));
   return std::min(pg, p.planes());
@@ -287,8 +290,12 @@ void Workspace::ensure_finish() {
   const size_t pg = plane_group();
   foldX.ensure(pg * p.num_per() * 2 * POLY_LEN);
   foldY.ensure(std::max<size_t>(pg * p.num_per() / 2, 1) * 2 * POLY_LEN);
-  fold_dig.ensure(pg * p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN);
-  fold_ntt.ensure(std::max<size_t>(pg * p.num_per() / 2, 1) * 2 * 2 * POLY_LEN);
+  // the digit-NTT staging is only used by the unfused tree tail (levels with < fused_min_pairs units)
+  const bool fused_ok = 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64;
+  size_t dig_cts = pg * p.num_per();
+  if (fused_ok && fused_min_pairs < (1L << 40)) dig_cts = std::min<size_t>(dig_cts, std::max<size_t>(2 * (size_t)fused_min_pairs, 2 * pg));
+  fold_dig.ensure(dig_cts * 2 * p.t_gsw * 2 * POLY_LEN);
+  fold_ntt.ensure(std::max<size_t>(dig_cts / 2, 1) * 2 * 2 * POLY_LEN);
   final_cts.ensure(p.planes() * 2 * POLY_LEN);
   const size_t nb = p.planes();
   pack_dig.ensure(nb * p.t_conv * 2 * POLY_LEN);

@@ -508,6 +508,26 @@ def process_query(params, public_params, query, db):
     return out[:ln.value].tobytes()
 
 
+def process_query_batch(params, public_params_list, queries, db):
+    """B queries against one database pass per group of <= 8 (sp_process_query_batch; BASELINE configs[4]).
+    Equivalent to [process_query(params, pp_i, q_i, db) for i in ...] -- the reference's per-request loop
+    (lib/server/src/bin/server.rs:152-158)."""
+    B = len(queries)
+    if not isinstance(public_params_list, (list, tuple)):
+        public_params_list = [public_params_list] * B
+    qs = [(_q.data if isinstance(_q, Query) else bytes(_q)) for _q in queries]
+    bufs = [_bytes(q) for q in qs]
+    n = params.get("response_bytes")
+    out = np.zeros(B * n, dtype=np.uint8)
+    ln = C.c_size_t(0)
+    pp_arr = (C.c_void_p * B)(*[pp.h for pp in public_params_list])
+    q_arr = (u8p * B)(*[_p(b, u8p) for b in bufs])
+    l_arr = (C.c_size_t * B)(*[b.size for b in bufs])
+    _chk(lib().sp_process_query_batch(_vp(params.h), pp_arr, q_arr, l_arr, C.c_int(B), _vp(db.h), _p(out, u8p),
+                                      C.c_size_t(n), C.byref(ln)))
+    return [out[i * n:(i + 1) * n].tobytes() for i in range(B)]
+
+
 def expand_query(params, public_params, query):
     """server.rs:525-591 -> (v_reg_reoriented, v_folding)"""
     q = query.data if isinstance(query, Query) else bytes(query)

@@ -520,6 +520,25 @@ def test_column_sharded_single_gpu_emulation(sp, oracle_mod, cfg, G, loader):
     assert runs[0].finish_gathered(gathered.data_ptr(), G) == expect
 
 
+@pytest.mark.parametrize("cfg,B", [(dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 11), (FAST56, 3)], ids=["packed-11", "narrow-3"])
+def test_process_query_batch(sp, oracle_mod, cfg, B):
+    """BASELINE configs[4]: batched queries share database passes (groups of <= 8 on the PACKED layout; 11 = 8 + 3
+    exercises two group sizes); two different clients' keys in one batch.  Byte-identical per query."""
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cls = [oracle_mod.Client(o), oracle_mod.Client(o)]
+    pps = [cls[0].generate_keys(1), cls[1].generate_keys(2)]
+    gpps = [sp.PublicParameters.deserialize(p, x) for x in pps]
+    item, db = o.generate_random_db_and_get_item(3)
+    gdb = sp.Database(p).load(db)
+    idxs = [(37 * i + 5) % o.num_items for i in range(B)]
+    qs = [cls[i % 2].generate_query(idxs[i], 100 + i) for i in range(B)]
+    resp = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
+    for i in range(B):
+        assert resp[i] == o.process_query(pps[i % 2], qs[i], db), i
+    assert cls[1].decode_response(resp[1]) == o.item_to_vec(o.generate_random_db_and_get_item(idxs[1])[0])
+
+
 def test_bad_lengths_raise(sp, oracle_mod):
     o, cl, pp, q = _session(oracle_mod, FAST, 1, 7)
     p = sp.Params(FAST)
