@@ -993,9 +993,11 @@ int sp_fold_ciphertexts(const sp_params_t* h, uint64_t* cts, size_t num_per, con
       }
     HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
     const long saved = W->fused_min_pairs;
-    W->fused_min_pairs = 1L << 60;  // the stage export honours the caller's v_folding_neg: generic path
+    W->fused_min_pairs = 1L << 60;  // the stage export honours the caller's v_folding_neg: literal path
+    W->delta_tail = false;
     u64* res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
     W->fused_min_pairs = saved;
+    W->delta_tail = true;
     download_raw(*W, res, 2 * POLY_LEN, cts);
   });
 }

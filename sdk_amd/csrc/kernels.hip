@@ -182,6 +182,192 @@ __device__ __forceinline__ void ntt_inv_block(u32 (&v)[8], int tau, u32* ldsA, u
   }
 }
 
+// ---- M transforms at once per thread: the twiddles, Shoup quotients and LDS addresses are computed once
+// and applied to M independent coefficient vectors (same modulus); each barrier serves M transforms.
+// la / lb hold M consecutive LDS_WORDS-sized buffers.
+template <int S, bool DO_A, int M>
+__device__ __forceinline__ void fwd_pass_m(u32 (&v)[M][8], int b, const u32* __restrict__ fw,
+                                           const u32* __restrict__ fwp, u32 q, u32 q2) {
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) ct_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int i = N / (4 * S) + 2 * b + h;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      ct_bfly(v[m][4 * h + 0], v[m][4 * h + 2], w, wp, q, q2);
+      ct_bfly(v[m][4 * h + 1], v[m][4 * h + 3], w, wp, q, q2);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    int i = N / (2 * S) + 4 * b + h;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) ct_bfly(v[m][2 * h], v[m][2 * h + 1], w, wp, q, q2);
+  }
+}
+template <int S, bool DO_A, int M>
+__device__ __forceinline__ void inv_pass_m(u32 (&v)[M][8], int b, const u32* __restrict__ iw,
+                                           const u32* __restrict__ iwp, u32 q, u32 q2) {
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    int i = N / (2 * S) + 4 * b + h;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) gs_bfly(v[m][2 * h], v[m][2 * h + 1], w, wp, q, q2);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int i = N / (4 * S) + 2 * b + h;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      gs_bfly(v[m][4 * h + 0], v[m][4 * h + 2], w, wp, q, q2);
+      gs_bfly(v[m][4 * h + 1], v[m][4 * h + 3], w, wp, q, q2);
+    }
+  }
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) gs_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+  }
+}
+template <int M>
+__device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,
+                                                const u32* __restrict__ fw, const u32* __restrict__ fwp, u32 q, u32 q2) {
+  fwd_pass_m<256, true, M>(v, 0, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_A(tau + 256 * k);
+#pragma unroll
+    for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+    }
+    fwd_pass_m<32, true, M>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) lb[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = lb[m * LDS_WORDS + a];
+    }
+    fwd_pass_m<4, true, M>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_B(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_B(8 * tau + k);
+#pragma unroll
+    for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+  }
+  fwd_pass_m<1, false, M>(v, tau, fw, fwp, q, q2);
+#pragma unroll
+  for (int m = 0; m < M; m++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 x = v[m][k];
+      x -= (x >= q2 ? q2 : 0u);
+      x -= (x >= q ? q : 0u);
+      v[m][k] = x;
+    }
+}
+template <int M>
+__device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,
+                                                const u32* __restrict__ iw, const u32* __restrict__ iwp, u32 q, u32 q2) {
+  inv_pass_m<1, false, M>(v, tau, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_B(8 * tau + k);
+#pragma unroll
+    for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_B(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+    }
+    inv_pass_m<4, true, M>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) lb[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = lb[m * LDS_WORDS + a];
+    }
+    inv_pass_m<32, true, M>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_A(tau + 256 * k);
+#pragma unroll
+    for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+  }
+  inv_pass_m<256, true, M>(v, 0, iw, iwp, q, q2);
+#pragma unroll
+  for (int m = 0; m < M; m++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 x = v[m][k];
+      x -= (x >= q2 ? q2 : 0u);
+      x -= (x >= q ? q : 0u);
+      v[m][k] = x;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward NTT kernel: grid (n_out, 2 crt)
 // ------------------------------------------------------------------------------------------------
@@ -196,7 +382,8 @@ __global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
   const int rem = o - b * per_b;
   const int row = rem / d.cols, col = rem - row * d.cols;
   const int kdig = row / d.rdim, j = row - kdig * d.rdim;
-  const long sb = d.src_idx ? (long)d.src_idx[b] : (long)b;
+  long sb = d.src_idx ? (long)d.src_idx[b] : (long)b;
+  if (d.delta_off) sb = (long)(b / d.delta_inner) * d.delta_outer_stride + (b % d.delta_inner);
   const u64* src = d.src + (sb * d.src_batch_stride + (long)(d.src_row0 + j) * d.src_cols + col) * N;
   const ModConst m = T.c.mod[c];
   const int sh = kdig * d.bits;
@@ -207,7 +394,15 @@ __global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
   for (int k = 0; k < 8; k++) {
     u64 x = src[tau + 256 * k];
     u64 piece = (sh >= 64) ? 0ULL : ((x >> sh) & mask);  // gadget.rs:48-53
-    v[k] = (d.bits <= 28) ? (u32)piece : reduce64(piece, m);
+    u32 val = (d.bits <= 28) ? (u32)piece : reduce64(piece, m);
+    if (d.delta_off) {
+      u64 x2 = src[(size_t)d.delta_off * N + tau + 256 * k];
+      u64 piece2 = (sh >= 64) ? 0ULL : ((x2 >> sh) & mask);
+      u32 val2 = (d.bits <= 28) ? (u32)piece2 : reduce64(piece2, m);
+      u32 a = val >= m.q ? val - m.q : val, b2 = val2 >= m.q ? val2 - m.q : val2;  // digits may equal 2^28-1 > q
+      val = b2 >= a ? b2 - a : b2 + m.q - a;
+    }
+    v[k] = val;
   }
   const u32* fw = T.tw + (size_t)c * 4 * N;
   ntt_fwd_block(v, tau, ldsA, ldsB, fw, fw + N, m.q, m.two_q);
@@ -229,11 +424,22 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
   __shared__ u32 ldsA[LDS_WORDS];
   __shared__ u32 ldsB[LDS_WORDS];
   const int tau = threadIdx.x;
-  const int p = blockIdx.x;
+  int p = blockIdx.x;
   long base;
   long crt_stride = d.crt_stride, z_stride = d.z_stride;
   if (d.sweep_np > 0) {
     const long np = d.sweep_np;
+    // The 16 columns ii that share a 64-byte line of the [z][ii] source should be read through ONE XCD's
+    // L2 (blocks are dealt to XCDs round-robin): block b -> XCD b % 8 handles group (b/8/16)*8 + b%8.
+    if ((np % 16) == 0 && ((long)d.n_polys % 128) == 0) {
+      const int b = blockIdx.x;
+      const int xcd = b & 7, slot = b >> 3;
+      const int grp = (slot >> 4) * 8 + xcd, within = slot & 15;  // group = (plane, r, ii/16)
+      const int groups_per_plane = (int)(np / 16) * 2;
+      const int plane_g = grp / groups_per_plane, rem_g = grp % groups_per_plane;
+      const int r_g = rem_g / (int)(np / 16), iig = rem_g % (int)(np / 16);
+      p = (int)(((long)plane_g * np + iig * 16 + within) * 2 + r_g);
+    }
     const long ct = p >> 1, r = p & 1;
     const long plane = ct / np, ii = ct - plane * np;
     base = plane * 4 * N * np + r * 2 * N * np + ii;
@@ -279,6 +485,10 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
       unsigned zt = (unsigned)z * (unsigned)d.automorph_t;
       unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
       dst[rem] = (num & 1u) ? T.c.Q - val : val;
+    } else if (d.addend) {
+      const long ap = (long)(p / d.add_inner2) * d.add_outer_stride + (p % d.add_inner2);
+      u64 sres = val + d.addend[(size_t)ap * N + z];
+      dst[z] = sres >= T.c.Q ? sres - T.c.Q : sres;
     } else {
       dst[z] = val;
     }
@@ -287,6 +497,64 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
   if (d.n_polys <= 0) return;
   hipLaunchKernelGGL(k_ntt_inv, dim3(d.n_polys), dim3(256), 0, s, T, d);
+}
+
+// ------------------------------------------------------------------------------------------------
+// from_ntt of four adjacent sweep-output columns per workgroup.  grid (np/4 * 2 * planes)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst) {
+  __shared__ u32 lds0[4 * LDS_WORDS];
+  __shared__ u32 lds1[4 * LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int g = blockIdx.x;              // (plane, r, ii/4)
+  const int groups_per_plane = (np / 4) * 2;
+  const int plane = g / groups_per_plane, rem = g % groups_per_plane;
+  const int r = rem / (np / 4), ii0 = (rem % (np / 4)) * 4;
+  const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
+  u32 res0[4][8];
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* sp = src + base + (size_t)c * N * np;
+    u32 v[4][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      uint4 x = *reinterpret_cast<const uint4*>(sp + (size_t)(8 * tau + k) * np);
+      if (premod) {
+        x.x %= m.q; x.y %= m.q; x.z %= m.q; x.w %= m.q;
+      }
+      v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
+    }
+    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    if (c == 1) __syncthreads();
+    ntt_inv_block_m<4>(v, tau, lds0, lds1, iw, iw + N, m.q, m.two_q);
+    if (c == 0) {
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) res0[mm][k] = v[mm][k];
+    } else {
+      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+#pragma unroll
+      for (int mm = 0; mm < 4; mm++) {
+        u64* out = dst + (((size_t)plane * np + ii0 + mm) * 2 + r) * N;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          u32 x = res0[mm][k], y = v[mm][k];
+          u32 xm = x >= q1 ? x - q1 : x;
+          u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+          e = e >= q1 ? e - q1 : e;
+          out[tau + 256 * k] = (u64)x + (u64)q0 * (u64)e;
+        }
+      }
+    }
+  }
+}
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
+  if (n_planes <= 0) return;
+  hipLaunchKernelGGL(k_from_sweep4, dim3((unsigned)((np / 4) * 2 * n_planes)), dim3(256), 0, s, T, src, np, premod, dst);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -396,13 +664,114 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
     }
   }
 }
+// k_fold_fused with two digit transforms in flight per thread (shared twiddles / addresses / barriers).
+// Requires an even digit count t.
+__global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d) {
+  __shared__ u32 lds0[2 * LDS_WORDS];
+  __shared__ u32 lds1[2 * LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int two_t = 2 * d.t, four_t = 4 * d.t;
+  const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
+  const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
+  const u64 mask = (1ULL << d.bits) - 1ULL;
+  u32* la = lds0;
+  u32* lb = lds1;
+  u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* fw = T.tw + (size_t)c * 4 * N;
+    u64 acc0[8], acc1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      u64 x0[8], x1[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        x0[k] = ct0[(size_t)j * N + tau + 256 * k];
+        x1[k] = ct1[(size_t)j * N + tau + 256 * k];
+      }
+#pragma unroll 1
+      for (int kd = 0; kd < d.t; kd += 2) {
+        u32 v[2][8];
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+          const int sh = (kd + mm) * d.bits;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
+            const u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+            v[mm][k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
+          }
+        }
+        const u32* fwk = fw;
+        int tk = tau;
+        asm volatile("" : "+s"(fwk));
+        asm volatile("" : "+v"(tk));
+        ntt_fwd_block_m<2>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+        {
+          u32* tmp = la;
+          la = lb;
+          lb = tmp;
+        }
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+          const int kk = two_t + j + 2 * (kd + mm);
+          const uint4* a0 = reinterpret_cast<const uint4*>(d.mats + ((size_t)kk * 2 + c) * N + 8 * tk);
+          const uint4* a1 = reinterpret_cast<const uint4*>(d.mats + ((size_t)(four_t + kk) * 2 + c) * N + 8 * tk);
+          const uint4 p0 = a0[0], p1 = a0[1], r0 = a1[0], r1 = a1[1];
+          acc0[0] += (u64)p0.x * v[mm][0]; acc0[1] += (u64)p0.y * v[mm][1]; acc0[2] += (u64)p0.z * v[mm][2]; acc0[3] += (u64)p0.w * v[mm][3];
+          acc0[4] += (u64)p1.x * v[mm][4]; acc0[5] += (u64)p1.y * v[mm][5]; acc0[6] += (u64)p1.z * v[mm][6]; acc0[7] += (u64)p1.w * v[mm][7];
+          acc1[0] += (u64)r0.x * v[mm][0]; acc1[1] += (u64)r0.y * v[mm][1]; acc1[2] += (u64)r0.z * v[mm][2]; acc1[3] += (u64)r0.w * v[mm][3];
+          acc1[4] += (u64)r1.x * v[mm][4]; acc1[5] += (u64)r1.y * v[mm][5]; acc1[6] += (u64)r1.z * v[mm][6]; acc1[7] += (u64)r1.w * v[mm][7];
+        }
+      }
+    }
+    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    u32 vv[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      vv[0][k] = reduce64(acc0[k], m);
+      vv[1][k] = reduce64(acc1[k], m);
+    }
+    ntt_inv_block_m<2>(vv, tau, la, lb, iw, iw + N, m.q, m.two_q);
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        out[tau + 256 * k] = vv[0][k];
+        out[(size_t)N + tau + 256 * k] = vv[1][k];
+      }
+    } else {
+      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const size_t zi = (size_t)r * N + tau + 256 * k;
+          u32 x = (u32)out[zi], y = vv[r][k];
+          u32 xm = x >= q1 ? x - q1 : x;
+          u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+          e = e >= q1 ? e - q1 : e;
+          u64 val = (u64)x + (u64)q0 * (u64)e + ct0[zi];
+          out[zi] = val >= T.c.Q ? val - T.c.Q : val;
+        }
+      }
+    }
+  }
+}
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   static const int variant = [] {
     const char* e = getenv("SPIRAL_FOLD_VARIANT");
-    return e ? atoi(e) : 1;
+    return e ? atoi(e) : 2;
   }();
-  if (variant == 1)
+  if (variant == 2 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  else if (variant == 1)
     hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else
     hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
@@ -421,7 +790,7 @@ __global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
   const long ob = d.out_idx ? (long)d.out_idx[b] : (long)b * d.out_batch_stride;
   const size_t PW = 2 * N;
   for (int r = 0; r < d.R; r++) {
-    const u32* A = d.A + (size_t)r * d.K * PW + e;
+    const u32* A = d.A + (size_t)r * (d.A_row_stride ? d.A_row_stride : d.K) * PW + e;
     const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
     u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
     // two segments of B (k < split_k, k >= split_k), each walked 8 operands at a time with all 16

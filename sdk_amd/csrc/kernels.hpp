@@ -32,6 +32,11 @@ struct FwdDesc {
   int rdim, cols, t, bits;
   int src_batch_stride;  // in polys
   int src_row0, src_cols;
+  // delta mode (fold tree tail): output = NTT(digit_k(src2 poly) - digit_k(src poly) mod q); src2 poly =
+  // src poly + delta_off polys, where batch element b = (outer, inner) with inner < delta_inner reads
+  // src batch index outer * delta_outer_stride + inner
+  long delta_off;
+  int delta_inner, delta_outer_stride;
 };
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s);
 
@@ -53,8 +58,15 @@ struct InvDesc {
   int sweep_np;
   // optional fused automorphism (poly.rs:393-405) applied to the raw result: dst[(z*t) % N] = +-v
   int automorph_t;  // 0 = none
+  // optional: dst = (result + addend poly) mod Q, addend poly index = (p / add_inner2) * add_outer_stride + p % add_inner2
+  const u64* addend;
+  int add_inner2, add_outer_stride;
 };
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s);
+// from_ntt of the sweep-native buffer [plane][r][crt][z][ii] (num_per = np, np % 4 == 0), four adjacent
+// columns per workgroup (16-byte loads: a quarter of the cache-line traffic of the one-column form);
+// dst raw polys dense in the same order as InvDesc's sweep mode: poly (plane*np + ii)*2 + r.
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s);
 
 // ---- NTT-domain multiply-accumulate (poly.rs:437-481) --------------------------------------
 // out[b][r] = (addend ? addend[b][r] : 0) + sum_k A[r][k] * B[b][k]   (pointwise, per crt), r < R
@@ -70,6 +82,7 @@ struct MacDesc {
   const u32* addend;  // may alias out
   const int* out_idx;
   int R, K;
+  int A_row_stride;  // polys between consecutive rows of A; 0 = K (dense)
   int batch_inner, batch_outer;
   long B_inner_stride, B_outer_stride;  // in polys
   int split_k;

@@ -31,6 +31,7 @@ struct Workspace {
   u64* h_query = nullptr;
   u64* h_packed = nullptr;
   size_t h_packed_words = 0;
+  bool delta_tail = true;  // unfused fold levels use the delta form too (false: literal two-matrix form)
   int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
   long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused
 

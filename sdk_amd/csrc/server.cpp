@@ -552,6 +552,52 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
       cur = half;
       continue;
     }
+    if (W.delta_tail) {
+      // tree tail in the same delta form as k_fold_fused (half the digit transforms, C only), digit-parallel
+      FwdDesc f{};
+      f.src = X;
+      f.dst = W.fold_dig.p;
+      f.n_out = np * half * two_t;
+      f.rdim = 2;
+      f.cols = 1;
+      f.t = (int)p.t_gsw;
+      f.bits = (int)p.bits_per(p.t_gsw);
+      f.src_batch_stride = 2;
+      f.src_row0 = 0;
+      f.src_cols = 1;
+      f.delta_off = (long)half * 2;
+      f.delta_inner = half;
+      f.delta_outer_stride = cur;
+      launch_ntt_fwd(D.T, f, s);
+      MacDesc m{};
+      m.A = W.fold_mats.p + ((size_t)(top_idx - d) * 2 * 2 * two_t + two_t) * 2 * POLY_LEN;  // C block of row 0
+      m.A_row_stride = 2 * two_t;
+      m.B = W.fold_dig.p;
+      m.out = W.fold_ntt.p;
+      m.R = 2;
+      m.K = two_t;
+      m.batch_inner = np * half;
+      m.batch_outer = 1;
+      m.B_inner_stride = two_t;
+      m.split_k = two_t;
+      m.out_batch_stride = 2;
+      m.out_row_stride = 1;
+      launch_mac(D.T, m, s);
+      InvDesc inv{};
+      inv.src = W.fold_ntt.p;
+      inv.poly_stride = 2 * POLY_LEN;
+      inv.crt_stride = POLY_LEN;
+      inv.z_stride = 1;
+      inv.dst = Y;
+      inv.n_polys = np * half * 2;
+      inv.addend = X;
+      inv.add_inner2 = half * 2;
+      inv.add_outer_stride = cur * 2;
+      launch_ntt_inv(D.T, inv, s);
+      std::swap(X, Y);
+      cur = half;
+      continue;
+    }
     FwdDesc f{};
     f.src = X;
     f.dst = W.fold_dig.p;
@@ -712,13 +758,18 @@ void run_fold_all(Workspace& W, bool premod) {
   const size_t pg = W.plane_group();
   for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
     const int np = (int)std::min(pg, p.planes() - pg0);
-    InvDesc inv{};
-    inv.src = W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per();
-    inv.sweep_np = (int)p.num_per();
-    inv.dst = W.foldX.p;
-    inv.n_polys = np * (int)p.num_per() * 2;
-    inv.premod = premod ? 1 : 0;
-    launch_ntt_inv(D.T, inv, s);
+    if (p.num_per() % 4 == 0 && !getenv("SPIRAL_FROM_SWEEP1")) {
+      launch_from_sweep4(D.T, W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), np, premod ? 1 : 0,
+                         W.foldX.p, s);
+    } else {
+      InvDesc inv{};
+      inv.src = W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per();
+      inv.sweep_np = (int)p.num_per();
+      inv.dst = W.foldX.p;
+      inv.n_polys = np * (int)p.num_per() * 2;
+      inv.premod = premod ? 1 : 0;
+      launch_ntt_inv(D.T, inv, s);
+    }
     u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
     if (p.num_per() == 1) {
       HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
@@ -785,13 +836,17 @@ void run_fold_local(Workspace& W, const u32* reduced_chunk, int G) {
   const size_t pg = W.plane_group();
   for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
     const int np = (int)std::min(pg, p.planes() - pg0);
-    InvDesc inv{};
-    inv.src = reduced_chunk + pg0 * 4 * POLY_LEN * npl;
-    inv.sweep_np = npl;
-    inv.dst = W.foldX.p;
-    inv.n_polys = np * npl * 2;
-    inv.premod = 1;
-    launch_ntt_inv(D.T, inv, s);
+    if (npl % 4 == 0) {
+      launch_from_sweep4(D.T, reduced_chunk + pg0 * 4 * POLY_LEN * npl, npl, np, 1, W.foldX.p, s);
+    } else {
+      InvDesc inv{};
+      inv.src = reduced_chunk + pg0 * 4 * POLY_LEN * npl;
+      inv.sweep_np = npl;
+      inv.dst = W.foldX.p;
+      inv.n_polys = np * npl * 2;
+      inv.premod = 1;
+      launch_ntt_inv(D.T, inv, s);
+    }
     u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
     HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
   }
