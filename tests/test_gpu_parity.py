@@ -243,6 +243,53 @@ def test_process_query_next_rows(sp, oracle_mod, cfg, idx):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
+def test_process_query_lib_server_default_gadgets(sp, oracle_mod):
+    """The lib/server default parameter family (bin/server.rs:191-203; server.rs:1052-1066): odd gadget sizes
+    t = (7, 3, 5, 5) -> 9/19/12-bit digits, q2_bits 22, 4 instances x 32 KiB items; nu_1 shortened to 6."""
+    cfg = dict(SERVER_DEFAULT, nu_1=6)
+    idx = 1500
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 3)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    resp = sp.process_query(p, gpp, q, gdb)
+    assert len(resp) == 86016                      # SURVEY App. B
+    assert resp == o.process_query(pp, q, db)
+    assert cl.decode_response(resp) == o.item_to_vec(item)
+
+
+def test_concurrent_host_threads(sp, oracle_mod):
+    """Handles are immutable and shareable: 4 host threads issue queries against one registered database at
+    once (each call takes its own workspace + stream, SURVEY 8(b) threading row)."""
+    import threading
+    cfg = FAST56
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(4)
+    item, db = o.generate_random_db_and_get_item(9)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    qs = [cl.generate_query((17 * i) % o.num_items, 50 + i) for i in range(8)]
+    exp = [o.process_query(pp, q, db) for q in qs]
+    got = [None] * 8
+    errs = []
+
+    def work(t):
+        try:
+            for i in range(t, 8, 4):
+                for _ in range(3):
+                    got[i] = sp.process_query(p, gpp, qs[i], gdb)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(4)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    assert got == exp
+
+
 def test_process_query_c1(sp, oracle_mod):
     """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
     idx = 12345
