@@ -7,6 +7,7 @@
 // Residues leave every kernel canonical (< q), so all intermediates equal the scalar reference's.
 #include "kernels.hpp"
 
+#include <algorithm>
 #include <cstdlib>
 
 namespace spiral {
@@ -371,11 +372,8 @@ __device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la
 // ------------------------------------------------------------------------------------------------
 // forward NTT kernel: grid (n_out, 2 crt)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
-  __shared__ u32 ldsA[LDS_WORDS];
-  __shared__ u32 ldsB[LDS_WORDS];
+__device__ __forceinline__ void ntt_fwd_body(const DevTables& T, const FwdDesc& d, int o, int c, u32* ldsA, u32* ldsB) {
   const int tau = threadIdx.x;
-  const int o = blockIdx.x, c = blockIdx.y;
   const int rows = d.rdim * d.t;
   const int per_b = rows * d.cols;
   const int b = o / per_b;
@@ -410,9 +408,35 @@ __global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
   dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
   dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
 }
+__global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  ntt_fwd_body(T, d, blockIdx.x, blockIdx.y, ldsA, ldsB);
+}
+__global__ __launch_bounds__(256) void k_ntt_fwd3(DevTables T, FwdDesc d0, FwdDesc d1, FwdDesc d2) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  int o = blockIdx.x;
+  if (o < d0.n_out) {
+    ntt_fwd_body(T, d0, o, blockIdx.y, ldsA, ldsB);
+  } else if (o < d0.n_out + d1.n_out) {
+    ntt_fwd_body(T, d1, o - d0.n_out, blockIdx.y, ldsA, ldsB);
+  } else {
+    ntt_fwd_body(T, d2, o - d0.n_out - d1.n_out, blockIdx.y, ldsA, ldsB);
+  }
+}
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
   if (d.n_out <= 0) return;
   hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
+}
+void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, hipStream_t s) {
+  const int total = std::max(d0.n_out, 0) + std::max(d1.n_out, 0) + std::max(d2.n_out, 0);
+  if (total <= 0) return;
+  FwdDesc a = d0, b = d1, c = d2;
+  a.n_out = std::max(a.n_out, 0);
+  b.n_out = std::max(b.n_out, 0);
+  c.n_out = std::max(c.n_out, 0);
+  hipLaunchKernelGGL(k_ntt_fwd3, dim3(total, 2), dim3(256), 0, s, T, a, b, c);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -451,6 +475,29 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
   } else {
     base = (long)p * d.poly_stride;
   }
+  // fused scalar multiply of coefficient_expansion (contiguous sources only)
+  long scal_store = -1;
+  if (d.scal) {
+    if (p >= d.n_polys) {  // scalar-only entries: form and store, no transform
+      const int e = p - d.n_polys;
+      const int ct = d.scal_only_idx[e >> 1], r = e & 1;
+      const long sp = ((long)(ct - d.scal_thresh) * 2 + r) * 2 * N, dp = ((long)ct * 2 + r) * 2 * N;
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          const int z = 8 * tau + k;
+          d.scal_dst[dp + c * N + z] = reduce64((u64)d.src[sp + c * N + z] * (u64)d.scal[c * N + z], T.c.mod[c]);
+        }
+      return;
+    }
+    const int e = p / d.polys_per_idx, r = p - e * d.polys_per_idx;
+    const int ct = d.idx[e];
+    if (ct >= d.scal_thresh) {
+      scal_store = base;                                                // destination = this ct's own slot
+      base = (long)(ct - d.scal_thresh) * d.idx_stride + (long)r * d.poly_stride;  // source = v[ct - num_in]
+    }
+  }
   u32 res[2][8];
 #pragma unroll
   for (int c = 0; c < 2; c++) {
@@ -461,6 +508,10 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
     for (int k = 0; k < 8; k++) {
       u32 x = src[(long)(8 * tau + k) * z_stride];
       if (d.premod) x = x % m.q;
+      if (scal_store >= 0) {
+        x = reduce64((u64)x * (u64)d.scal[c * N + 8 * tau + k], m);
+        d.scal_dst[scal_store + (long)c * crt_stride + 8 * tau + k] = x;
+      }
       v[k] = x;
     }
     const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
@@ -495,8 +546,9 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
   }
 }
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
-  if (d.n_polys <= 0) return;
-  hipLaunchKernelGGL(k_ntt_inv, dim3(d.n_polys), dim3(256), 0, s, T, d);
+  const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);
+  if (blocks <= 0) return;
+  hipLaunchKernelGGL(k_ntt_inv, dim3(blocks), dim3(256), 0, s, T, d);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -780,10 +832,9 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // NTT-domain multiply-accumulate.  grid (2N/256, batch), one (crt, z) per thread.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
+__device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, int inner, int outer) {
   const int e = blockIdx.x * 256 + threadIdx.x;  // index into [crt][z]
   const int c = e >> POLY_LEN_LOG2;
-  const int inner = blockIdx.y, outer = blockIdx.z;
   const int b = outer * d.batch_inner + inner;
   const ModConst m = T.c.mod[c];
   const u32* B = d.B + ((size_t)outer * d.B_outer_stride + (size_t)inner * d.B_inner_stride) * 2 * N + e;
@@ -793,6 +844,7 @@ __global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
     const u32* A = d.A + (size_t)r * (d.A_row_stride ? d.A_row_stride : d.K) * PW + e;
     const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
     u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
+    if (d.extra && r == d.extra_row) acc += (u64)d.extra[(size_t)(d.extra_idx ? d.extra_idx[b] : b) * PW + e];
     // two segments of B (k < split_k, k >= split_k), each walked 8 operands at a time with all 16
     // loads issued before the multiplies: small batches are latency-bound, not bandwidth-bound.
     // products < 2^56: <= 64 terms between Barrett folds stay < 2^63.
@@ -821,9 +873,24 @@ __global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) {
     d.out[op] = (u32)acc;
   }
 }
+__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d1) {
+  const int y = blockIdx.y;
+  if (y < d0.batch_inner)
+    mac_body(T, d0, y, 0);
+  else
+    mac_body(T, d1, y - d0.batch_inner, 0);
+}
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
   if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
   hipLaunchKernelGGL(k_mac, dim3(2 * N / 256, d.batch_inner, d.batch_outer), dim3(256), 0, s, T, d);
+}
+void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipStream_t s) {
+  MacDesc a = d0, b = d1;
+  a.batch_inner = std::max(a.batch_inner, 0);
+  b.batch_inner = std::max(b.batch_inner, 0);
+  if (a.batch_inner + b.batch_inner <= 0) return;
+  hipLaunchKernelGGL(k_mac2, dim3(2 * N / 256, a.batch_inner + b.batch_inner, 1), dim3(256), 0, s, T, a, b);
 }
 
 __global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, const int* idx, const u32* src) {

@@ -39,6 +39,8 @@ struct FwdDesc {
   int delta_inner, delta_outer_stride;
 };
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s);
+// up to three descriptors in ONE launch (expansion rounds: left digits, right digits, row-1 NTT)
+void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, hipStream_t s);
 
 // ---- inverse NTT + CRT compose (poly.rs:646-663) -------------------------------------------
 // Source element (poly p, crt c, coefficient z) is read from
@@ -58,6 +60,14 @@ struct InvDesc {
   int sweep_np;
   // optional fused automorphism (poly.rs:393-405) applied to the raw result: dst[(z*t) % N] = +-v
   int automorph_t;  // 0 = none
+  // optional fused scalar multiply (coefficient_expansion, server.rs:105-110): ciphertexts idx[e] >= scal_thresh
+  // are first formed as scal * v[idx[e] - scal_thresh] (stored to scal_dst, the writable alias of src) and then
+  // inverse-transformed; n_scalar_only further ciphertexts (scal_only_idx) are only formed and stored.
+  const u32* scal;
+  u32* scal_dst;
+  int scal_thresh;
+  const int* scal_only_idx;
+  int n_scalar_only;
   // optional: dst = (result + addend poly) mod Q, addend poly index = (p / add_inner2) * add_outer_stride + p % add_inner2
   const u64* addend;
   int add_inner2, add_outer_stride;
@@ -88,8 +98,14 @@ struct MacDesc {
   int split_k;
   long split_off;  // in polys
   int out_batch_stride, out_row_stride;
+  // optional second addend for output row `extra_row`: NTT poly extra[extra_idx ? extra_idx[b] : b]
+  const u32* extra;
+  const int* extra_idx;
+  int extra_row;
 };
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s);
+// two descriptors in ONE launch (both must have batch_outer == 1)
+void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipStream_t s);
 
 // ---- fused fold step (server.rs:407-424) ----------------------------------------------------
 // One workgroup per (pair i, plane): out[plane][i] = from_ntt( [G-C | C] * NTT(G^-1([ct_i ; ct_{i+half}])) ),

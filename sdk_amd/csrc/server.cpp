@@ -107,12 +107,15 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
       RoundPlan rp;
       rp.num_in = 1 << r;
       rp.t_auto = (int)(POLY_LEN >> r) + 1;
-      std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout;
+      std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout, skip2;
       for (int half = 0; half < 2; half++)
         for (int i = 0; i < rp.num_in; i++) {  // both halves enumerate from 0 (server.rs:112-119)
           bool skip = (stop_round > 0 && r > stop_round && (i % 2) == 1) ||
                       (stop_round > 0 && r == stop_round && (i % 2) == 1 && (size_t)(i / 2) >= max_bits_right);
-          if (skip) continue;
+          if (skip) {
+            if (half == 1) skip2.push_back(rp.num_in + i);
+            continue;
+          }
           int ct = half * rp.num_in + i;
           int pos = (int)all_ct.size();
           all_ct.push_back(ct);
@@ -134,6 +137,8 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
       rp.left_out = put(lout);
       rp.right_pos = put(rpos);
       rp.right_out = put(rout);
+      rp.skip2 = put(skip2);
+      rp.n_skip2 = (int)skip2.size();
       D->max_all = std::max(D->max_all, (size_t)rp.n_all);
       D->max_left = std::max(D->max_left, (size_t)rp.n_left);
       D->max_right = std::max(D->max_right, (size_t)rp.n_right);
@@ -259,7 +264,7 @@ void Workspace::ensure_expand() {
   const size_t g = p.g();
   v.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);
   exp_raw.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
-  size_t dig = std::max(D->max_left * p.t_exp_left, D->max_right * p.t_exp_right);
+  size_t dig = D->max_left * p.t_exp_left + D->max_right * p.t_exp_right;  // both groups of a round coexist
   exp_dig.ensure(std::max<size_t>(dig, 1) * 2 * POLY_LEN);
   exp_ct1.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
   qv.ensure(POLY_LEN * p.dim0() * 2);
@@ -314,9 +319,8 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
   const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
   for (size_t r = 0; r < g_rounds; r++) {
     const RoundPlan& rp = D.rounds[r];
-    // v[num_in + i] = neg1[r] * v[i]   (server.rs:105-110)
-    launch_scalar_mul(D.T, W.v.p, (long)rp.num_in * 2, 0, D.neg1.p + r * 2 * POLY_LEN, rp.num_in * 2, s);
-    // ct = from_ntt(v_i); ct_auto = automorph(ct, t)   (server.rs:80-81)
+    // three launches per round:
+    // (1) v[num_in + i] = neg1[r] * v[i] (server.rs:105-110) fused into ct = from_ntt(v_i); ct_auto = automorph(ct, t)
     InvDesc inv{};
     inv.src = W.v.p;
     inv.idx = L + rp.all_ct;
@@ -328,16 +332,21 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
     inv.dst = W.exp_raw.p;
     inv.n_polys = rp.n_all * 2;
     inv.automorph_t = rp.t_auto;
+    inv.scal = D.neg1.p + r * 2 * POLY_LEN;
+    inv.scal_dst = W.v.p;
+    inv.scal_thresh = rp.num_in;
+    inv.scal_only_idx = L + rp.skip2;
+    inv.n_scalar_only = rp.n_skip2;
     launch_ntt_inv(D.T, inv, s);
-    // gadget_invert_rdim(ct_auto, rdim = 1) -> to_ntt_no_reduce -> W * ginv; v_i += ...  (server.rs:82-102)
+    // (2) gadget_invert_rdim(ct_auto, rdim = 1) -> to_ntt_no_reduce for both groups, and to_ntt(ct_auto row 1)
+    FwdDesc fd[3];
     for (int side = 0; side < 2; side++) {
       const int cnt = side == 0 ? rp.n_left : rp.n_right;
-      if (cnt == 0) continue;
       const int t = side == 0 ? tl : tr;
       FwdDesc f{};
       f.src = W.exp_raw.p;
       f.src_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
-      f.dst = W.exp_dig.p;
+      f.dst = W.exp_dig.p + (side == 0 ? 0 : (size_t)rp.n_left * tl * 2 * POLY_LEN);
       f.n_out = cnt * t;
       f.rdim = 1;
       f.cols = 1;
@@ -346,13 +355,34 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
       f.src_batch_stride = 2;
       f.src_row0 = 0;
       f.src_cols = 1;
-      launch_ntt_fwd(D.T, f, s);
+      fd[side] = f;
+    }
+    {
+      FwdDesc f1{};
+      f1.src = W.exp_raw.p;
+      f1.dst = W.exp_ct1.p;
+      f1.n_out = rp.n_all;
+      f1.rdim = 1;
+      f1.cols = 1;
+      f1.t = 1;
+      f1.bits = 64;
+      f1.src_batch_stride = 2;
+      f1.src_row0 = 1;
+      f1.src_cols = 1;
+      fd[2] = f1;
+    }
+    launch_ntt_fwd3(D.T, fd[0], fd[1], fd[2], s);
+    // (3) v_i += W * ginv + [0; to_ntt(ct_auto row 1)]   (server.rs:89-102)
+    MacDesc md[2];
+    for (int side = 0; side < 2; side++) {
+      const int cnt = side == 0 ? rp.n_left : rp.n_right;
+      const int t = side == 0 ? tl : tr;
       // nu_2 == 0: expand_query passes v_w_left for both sides (server.rs:573)
       const bool use_right = side == 1 && pp.has_right && p.db_dim_2 > 0;
       const size_t woff = use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl;
       MacDesc m{};
       m.A = pp.all.p + woff * 2 * POLY_LEN;
-      m.B = W.exp_dig.p;
+      m.B = fd[side].dst;
       m.out = W.v.p;
       m.addend = W.v.p;
       m.out_idx = L + (side == 0 ? rp.left_out : rp.right_out);
@@ -366,22 +396,12 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
       m.split_off = 0;
       m.out_batch_stride = 0;
       m.out_row_stride = 1;
-      launch_mac(D.T, m, s);
+      m.extra = W.exp_ct1.p;
+      m.extra_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
+      m.extra_row = 1;
+      md[side] = m;
     }
-    // + [0; to_ntt(ct_auto row 1)]   (server.rs:84-88, 95-98)
-    FwdDesc f1{};
-    f1.src = W.exp_raw.p;
-    f1.dst = W.exp_ct1.p;
-    f1.n_out = rp.n_all;
-    f1.rdim = 1;
-    f1.cols = 1;
-    f1.t = 1;
-    f1.bits = 64;
-    f1.src_batch_stride = 2;
-    f1.src_row0 = 1;
-    f1.src_cols = 1;
-    launch_ntt_fwd(D.T, f1, s);
-    launch_add_poly_into(D.T, W.v.p, L + rp.all_row1, W.exp_ct1.p, rp.n_all, s);
+    launch_mac2(D.T, md[0], md[1], s);
   }
 }
 

@@ -76,6 +76,8 @@ struct RoundPlan {
   size_t left_pos = 0;    // position within the active list of each left-group ct
   size_t left_out = 0;    // poly index (ct*2) of each left-group ct
   size_t right_pos = 0, right_out = 0;
+  size_t skip2 = 0;       // second-half cts that are pruned (only scalar-multiplied), server.rs:40-47
+  int n_skip2 = 0;
 };
 
 struct DeviceState {
