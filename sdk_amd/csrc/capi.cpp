@@ -42,6 +42,8 @@ struct sp_query {
   ~sp_query() {
     if (ws && params) {
       (void)hipStreamSynchronize(ws->stream);
+      (void)hipStreamSynchronize(ws->stream2);
+      ws->pipelined = false;
       params->release_ws(std::move(ws));
     }
   }
@@ -481,7 +483,14 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
     need(db->params == q->params, "db was created for different params");
     check_device(db->device);
     Workspace& W = *q->ws;
-    run_sweep(W, *db);
+    static const bool pipeline = [] {
+      const char* e = getenv("SPIRAL_PIPELINE");
+      return e ? atoi(e) != 0 : false;  // measured: no gain, the sweep's own v_mad_u64_u32 stream and the fold share the VALU
+    }();
+    if (pipeline && db->num_shards == 1 && db->col_G == 1 && q->params->p.planes() > 1)
+      run_sweep_pipelined(W, *db);
+    else
+      run_sweep(W, *db);
     HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
     q->state = 2;
   });
@@ -554,6 +563,7 @@ int sp_query_sync(sp_query_t* q) {
   return guarded([&] {
     need(q && q->ws, "null query");
     HIP_CHECK(hipStreamSynchronize(q->ws->stream));
+    HIP_CHECK(hipStreamSynchronize(q->ws->stream2));
   });
 }
 

@@ -1237,6 +1237,79 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
                    (u32)a03, (u32)a13);
 }
 
+// Persistent form of k_sweep_packed for the intra-query pipeline: a fixed grid of `wgs_per_cu` workgroups per
+// CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
+// LDS stay free for the fold kernels running concurrently on the second stream.
+template <int U>
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units) {
+  const int lane = threadIdx.x & 63;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int nwaves = gridDim.x * 4;
+  const int chunks = d.num_per >> 7;
+  const int npairs = d.nj >> 1;
+  const size_t ustride = (size_t)chunks * 448;
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  for (int unit = wave0; unit < units; unit += nwaves) {
+    const int chunk = unit % chunks;
+    const int zp = unit / chunks;
+    const int z = zp & (N - 1);
+    const int plane = zp >> POLY_LEN_LOG2;
+    const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
+    const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+    u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
+    for (int jb = 0; jb < npairs; jb += 128) {
+      const int je = min(jb + 128, npairs);
+      for (int jp0 = jb; jp0 < je; jp0 += U) {
+        u32x4_t va[U];
+        u32x3_t vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int jp = min(jp0 + u, je - 1);
+          const u32* uu = base + (size_t)jp * ustride;
+          va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(uu + lane * 4));
+          vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(uu + 256 + lane * 3));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int jp = jp0 + u;
+          if (jp < je) {
+            const u32 d0 = va[u].x, d1 = va[u].y, d2 = va[u].z, d3 = va[u].w, d4 = vb[u].x, d5 = vb[u].y, d6 = vb[u].z;
+            const uint4 qa = qrow[2 * jp];
+            const uint4 qb = qrow[2 * jp + 1];
+            const u32 f0 = d0 & M;
+            const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+            const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+            const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+            const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+            const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+            const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+            const u32 f7 = d6 >> 4;
+            a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
+            a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
+            a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
+            a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;
+          }
+        }
+      }
+      a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
+      a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
+    }
+    sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                     (u32)a03, (u32)a13);
+  }
+}
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s) {
+  const int units = d.planes * N * (d.num_per >> 7);
+  const dim3 grid((unsigned)std::min(256 * wgs_per_cu, (units + 3) / 4));
+  switch (unroll) {
+    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units); break;
+    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units); break;
+  }
+}
+
 // Multi-query PACKED sweep: B queries share one pass over the database (BASELINE configs[4]).  Per row
 // pair: one 28-byte load, B x 2 scalar query rows, 16 B multiply-accumulates.  HBM-bound up to B ~ 4,
 // integer-ALU-bound beyond.
@@ -1407,7 +1480,16 @@ __global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) 
 
 const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
 
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
+  // default: persistent grid of 4 workgroups per CU, 4 row pairs in flight per lane (profiles/r01_sweep_variants.md);
+  // SPIRAL_SWEEP_PERSIST_WGS=0 selects the one-wave-per-unit grid
+  static const int persist_wgs = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_WGS"); return e ? atoi(e) : 4; }();
+  static const int persist_unr = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_UNROLL"); return e ? atoi(e) : 4; }();
+  if (d.packed && persist_wgs > 0) {
+    launch_sweep_persist(T, d, persist_wgs, persist_unr, s);
+    return;
+  }
   if (d.packed) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
     hipLaunchKernelGGL(k_sweep_packed, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);

@@ -185,6 +185,8 @@ inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {
   return (size_t)planes * N * nj * num_per * (packed ? 7 : 8);
 }
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
+// persistent PACKED sweep with a capped footprint (wgs_per_cu workgroups per CU, `unroll` row pairs in flight)
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
 // B queries against ONE pass over the (PACKED) database: every database word is multiplied into B
 // accumulator sets.  B <= SWEEP_BATCH_MAX; qv[b] / out[b] as in SweepDesc.
 constexpr int SWEEP_BATCH_MAX = 8;

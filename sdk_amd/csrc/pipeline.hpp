@@ -1,5 +1,7 @@
 // Per-call device workspace + the stage functions of the answer path (server.cpp).
 #pragma once
+#include <vector>
+
 #include "server.hpp"
 
 namespace spiral {
@@ -9,6 +11,10 @@ struct Workspace {
   DeviceState* D;
   int device = -1;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
+  std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
+  hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
+  bool pipelined = false;                   // set by run_sweep_pipelined, consumed by run_finish
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
   // expansion
   DevBuf<u64> q_raw;      // query ct, raw 2x1
@@ -51,6 +57,7 @@ void run_folding_neg(Workspace& W);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
 void run_sweep(Workspace& W, const sp_db& db);
+void run_sweep_pipelined(Workspace& W, const sp_db& db);
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G);

@@ -243,6 +243,10 @@ namespace spiral {
 Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   device = D.device;
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming));
+  ev_plane.resize(P.planes());
+  for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
   h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
@@ -256,6 +260,10 @@ Workspace::~Workspace() {
   if (h_packed) (void)hipHostFree(h_packed);
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
+  for (auto& e : ev_plane)
+    if (e) (void)hipEventDestroy(e);
+  if (ev_fold) (void)hipEventDestroy(ev_fold);
+  if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
@@ -541,6 +549,59 @@ void run_sweep(Workspace& W, const sp_db& db) {
   launch_sweep(W.D->T, d, W.stream);
 }
 
+// from_ntt + fold of `np` planes starting at plane pg0 (sweep_out -> final_cts), on W.stream
+static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  hipStream_t s = W.stream;
+  if (p.num_per() % 4 == 0 && !getenv("SPIRAL_FROM_SWEEP1")) {
+    launch_from_sweep4(D.T, W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), np, premod ? 1 : 0,
+                       W.foldX.p, s);
+  } else {
+    InvDesc inv{};
+    inv.src = W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per();
+    inv.sweep_np = (int)p.num_per();
+    inv.dst = W.foldX.p;
+    inv.n_polys = np * (int)p.num_per() * 2;
+    inv.premod = premod ? 1 : 0;
+    launch_ntt_inv(D.T, inv, s);
+  }
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+}
+
+// Single-GPU query: the database is swept one (instance, trial) plane per launch, and the from_ntt + fold of
+// plane p (integer-ALU-bound) runs on a second stream while plane p+1 is being swept (HBM-bound).
+void run_sweep_pipelined(Workspace& W, const sp_db& db) {
+  const Params& p = *W.P;
+  W.ensure_sweep();
+  W.ensure_finish();
+  const size_t np_ = (size_t)db.np_local;
+  const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
+  for (size_t pl = 0; pl < p.planes(); pl++) {
+    SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
+                (int)p.dim0(), db.j0, db.nj, db.packed, 1};
+    static const int wgs = [] { const char* e = getenv("SPIRAL_PIPE_WGS"); return e ? atoi(e) : 4; }();
+    static const int unr = [] { const char* e = getenv("SPIRAL_PIPE_UNROLL"); return e ? atoi(e) : 4; }();
+    if (db.packed && wgs > 0)
+      launch_sweep_persist(W.D->T, d, wgs, unr, W.stream);
+    else
+      launch_sweep(W.D->T, d, W.stream);
+    HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
+    HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
+    std::swap(W.stream, W.stream2);
+    try {
+      fold_planes(W, pl, 1, false);
+    } catch (...) {
+      std::swap(W.stream, W.stream2);
+      throw;
+    }
+    std::swap(W.stream, W.stream2);
+  }
+  HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
+  W.pipelined = true;
+}
+
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
@@ -773,31 +834,8 @@ void run_pack(Workspace& W, const sp_pp& pp) {
 // from_ntt of the first-dimension outputs + fold, for every plane (server.rs:707-711, 731)
 void run_fold_all(Workspace& W, bool premod) {
   const Params& p = *W.P;
-  DeviceState& D = *W.D;
-  hipStream_t s = W.stream;
   const size_t pg = W.plane_group();
-  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
-    const int np = (int)std::min(pg, p.planes() - pg0);
-    if (p.num_per() % 4 == 0 && !getenv("SPIRAL_FROM_SWEEP1")) {
-      launch_from_sweep4(D.T, W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), np, premod ? 1 : 0,
-                         W.foldX.p, s);
-    } else {
-      InvDesc inv{};
-      inv.src = W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per();
-      inv.sweep_np = (int)p.num_per();
-      inv.dst = W.foldX.p;
-      inv.n_polys = np * (int)p.num_per() * 2;
-      inv.premod = premod ? 1 : 0;
-      launch_ntt_inv(D.T, inv, s);
-    }
-    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
-    if (p.num_per() == 1) {
-      HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    } else {
-      // after the last level the np results are dense: [np][1 ct]
-      HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
-    }
-  }
+  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) fold_planes(W, pg0, (int)std::min(pg, p.planes() - pg0), premod);
 }
 
 // ---- encode (server.rs:470-503) on the host: rescale (arith.rs:429-444) + LSB-first bit packing
@@ -899,7 +937,12 @@ void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int
 void run_finish(Workspace& W, const sp_pp& pp, bool premod) {
   const Params& p = *W.P;
   W.ensure_finish();
-  run_fold_all(W, premod);
+  if (W.pipelined) {  // folds were issued by run_sweep_pipelined on stream2
+    HIP_CHECK(hipStreamWaitEvent(W.stream, W.ev_fold, 0));
+    W.pipelined = false;
+  } else {
+    run_fold_all(W, premod);
+  }
   HIP_CHECK(hipEventRecord(W.ev[3], W.stream));
   run_pack(W, pp);
   HIP_CHECK(hipMemcpyAsync(W.h_packed, W.pack_raw.p, W.h_packed_words * sizeof(u64), hipMemcpyDeviceToHost, W.stream));
