@@ -537,7 +537,8 @@ int sp_query_finish_gathered(sp_query_t* q, const void* gathered, int G, uint8_t
     Workspace& W = *q->ws;
     run_finish_gathered(W, *q->pp, (const u64*)gathered, G);
     HIP_CHECK(hipStreamSynchronize(W.stream));
-    *out_len = encode_response(p, W.h_packed, out);
+    memcpy(out, W.h_response, p.response_bytes());
+  *out_len = p.response_bytes();
     float t = 0;
     HIP_CHECK(hipEventElapsedTime(&t, W.ev[0], W.ev[1]));
     q->ms[0] = t;
@@ -575,7 +576,8 @@ static void finish_impl(sp_query_t* q, bool premod, uint8_t* out, size_t out_cap
   Workspace& W = *q->ws;
   run_finish(W, *q->pp, premod);
   HIP_CHECK(hipStreamSynchronize(W.stream));
-  *out_len = encode_response(p, W.h_packed, out);
+  memcpy(out, W.h_response, p.response_bytes());
+  *out_len = p.response_bytes();
   float t = 0;
   HIP_CHECK(hipEventElapsedTime(&t, W.ev[0], W.ev[1]));
   q->ms[0] = t;
@@ -680,7 +682,8 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       for (int i = 0; i < B; i++) {
         Workspace& W = *qs[i]->ws;
         HIP_CHECK(hipStreamSynchronize(W.stream));
-        *out_len = encode_response(p, W.h_packed, out + (size_t)(g0 + i) * out_stride);
+        memcpy(out + (size_t)(g0 + i) * out_stride, W.h_response, p.response_bytes());
+        *out_len = p.response_bytes();
       }
     });
     for (auto* q : qs) sp_query_free(q);

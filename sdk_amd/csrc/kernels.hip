@@ -1041,6 +1041,71 @@ void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
   hipLaunchKernelGGL(k_u32_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
 }
 
+// rescale(a, Q, out_mod) of arith.rs:429-444 without 128-bit division: the truncated quotient
+// floor((|v| * out_mod + Q/2) / Q) is < 2^38, so a double estimate is within +-1 and is corrected exactly.
+__device__ __forceinline__ u64 rescale_dev(u64 a, u64 Q, u64 out_mod) {
+  u64 v = a % Q;
+  const bool neg = v >= Q / 2;  // inp_val -= inp_mod
+  const u64 mag = neg ? Q - v : v;
+  // num = mag * out_mod + Q/2  (up to ~2^93): 128-bit as (hi, lo)
+  u64 lo = mag * out_mod, hi = __umul64hi(mag, out_mod);
+  const u64 half = Q / 2;
+  lo += half;
+  hi += lo < half ? 1 : 0;
+  u64 qd = (u64)(((double)hi * 18446744073709551616.0 + (double)lo) / (double)Q);
+  // correct: want qd*Q <= num < (qd+1)*Q
+  for (int it = 0; it < 4; it++) {
+    const u64 plo = qd * Q, phi = __umul64hi(qd, Q);
+    const bool gt = phi > hi || (phi == hi && plo > lo);  // qd*Q > num
+    if (gt) {
+      qd--;
+      continue;
+    }
+    // rem = num - qd*Q  (fits 64 bits when qd is within 1 of the truth and Q < 2^57)
+    const u64 rlo = lo - plo, rhi = hi - phi - (lo < plo ? 1 : 0);
+    if (rhi != 0 || rlo >= Q) {
+      qd++;
+      continue;
+    }
+    break;
+  }
+  // result = (sign*qd + (Q/out)*out + 2*out) % out, then (+out) % out; all terms fit i64 magnitudes
+  const u64 base = (Q / out_mod) * out_mod + 2 * out_mod;
+  const u64 r = neg ? (base - qd) % out_mod : (base + qd) % out_mod;
+  return (r + out_mod) % out_mod;
+}
+__global__ __launch_bounds__(256) void k_encode(EncodeDesc d) {
+  const int per_inst_first = d.n * N, per_inst_rest = d.n * d.n * N;
+  const int per_inst = per_inst_first + per_inst_rest;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)d.instances * per_inst) return;
+  const int inst = (int)(i / per_inst), k = (int)(i % per_inst);
+  const u64* m = d.packed + (size_t)inst * (d.n + 1) * d.n * N;
+  const size_t inst_bits = (size_t)per_inst_first * d.q2_bits + (size_t)per_inst_rest * d.q1_bits;
+  u64 val;
+  size_t bit;
+  int nb;
+  if (k < per_inst_first) {
+    val = rescale_dev(m[k], d.Q, d.q2);
+    nb = d.q2_bits;
+    bit = (size_t)inst * inst_bits + (size_t)k * d.q2_bits;
+  } else {
+    const int kk = k - per_inst_first;
+    val = rescale_dev(m[per_inst_first + kk], d.Q, d.q1);
+    nb = d.q1_bits;
+    bit = (size_t)inst * inst_bits + (size_t)per_inst_first * d.q2_bits + (size_t)kk * d.q1_bits;
+  }
+  val &= nb >= 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
+  const size_t w = bit >> 6;
+  const int off = (int)(bit & 63);
+  atomicOr(d.out + w, (unsigned long long)(val << off));
+  if (off + nb > 64) atomicOr(d.out + w + 1, (unsigned long long)(val >> (64 - off)));
+}
+void launch_encode(const EncodeDesc& d, hipStream_t s) {
+  const long total = (long)d.instances * ((long)d.n * N + (long)d.n * d.n * N);
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+}
+
 // out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
 __global__ __launch_bounds__(256) void k_reorient(u64* out, const u32* v, int first, int step, int dim0) {
   __shared__ u64 tile[32][33];

@@ -150,6 +150,17 @@ void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows
 void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s);
 void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s);
 
+// ---- encode (server.rs:470-503) on the device: rescale (arith.rs:429-444) + LSB-first bit packing -------------
+// packed: [instances][(n+1) x n raw polys]; out: zeroed buffer of response_bytes/8 u64 words (atomicOr packing)
+struct EncodeDesc {
+  const u64* packed;
+  unsigned long long* out;
+  int instances, n;
+  u64 Q, q1, q2;
+  int q1_bits, q2_bits;
+};
+void launch_encode(const EncodeDesc& d, hipStream_t s);
+
 // ---- query reorientation (util.rs:323-355) --------------------------------------------------
 // v (NTT cts, 2 polys each) at ct indices first + step*j, j < dim0  ->  out[z][j][r] = lo | hi << 32
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s);

@@ -37,6 +37,8 @@ struct Workspace {
   u64* h_query = nullptr;
   u64* h_packed = nullptr;
   size_t h_packed_words = 0;
+  DevBuf<u64> enc_out;       // response bits built on the device
+  uint8_t* h_response = nullptr;
   bool delta_tail = true;  // unfused fold levels use the delta form too (false: literal two-matrix form)
   int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
   long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused
@@ -65,5 +67,6 @@ void run_fold_all(Workspace& W, bool premod);
 void run_pack(Workspace& W, const sp_pp& pp);
 void run_finish(Workspace& W, const sp_pp& pp, bool premod);
 size_t encode_response(const Params& p, const u64* packed, uint8_t* out);
+void run_encode_device(Workspace& W);  // pack_raw -> enc_out -> h_response (async on W.stream)
 
 }  // namespace spiral

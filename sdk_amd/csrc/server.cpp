@@ -251,6 +251,8 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
   h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
   HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
+  HIP_CHECK(hipHostMalloc((void**)&h_response, P.response_bytes() + 16, hipHostMallocDefault));
+  enc_out.alloc(P.response_bytes() / 8 + 2);
   q_raw.alloc(2 * POLY_LEN);
   if (const char* e = getenv("SPIRAL_FUSED_MIN_PAIRS")) fused_min_pairs = atol(e);
 }
@@ -258,6 +260,7 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
 Workspace::~Workspace() {
   if (h_query) (void)hipHostFree(h_query);
   if (h_packed) (void)hipHostFree(h_packed);
+  if (h_response) (void)hipHostFree(h_response);
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_plane)
@@ -930,8 +933,28 @@ void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, (size_t)planes * ctw * sizeof(u64), hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipEventRecord(W.ev[3], s));
   run_pack(W, pp);
-  HIP_CHECK(hipMemcpyAsync(W.h_packed, W.pack_raw.p, W.h_packed_words * sizeof(u64), hipMemcpyDeviceToHost, s));
+  run_encode_device(W);
   HIP_CHECK(hipEventRecord(W.ev[4], s));
+}
+
+void run_encode_device(Workspace& W) {
+  const Params& p = *W.P;
+  hipStream_t s = W.stream;
+  HIP_CHECK(hipMemsetAsync(W.enc_out.p, 0, W.enc_out.bytes(), s));
+  EncodeDesc e{};
+  e.packed = W.pack_raw.p;
+  e.out = reinterpret_cast<unsigned long long*>(W.enc_out.p);
+  e.instances = (int)p.instances;
+  e.n = (int)p.n;
+  e.Q = p.modulus;
+  e.q1 = 4 * p.pt_modulus;
+  e.q2 = p.q2();
+  int q1_bits = 0;
+  while (((u64)1 << q1_bits) < e.q1) q1_bits++;
+  e.q1_bits = q1_bits;
+  e.q2_bits = (int)p.q2_bits;
+  launch_encode(e, s);
+  HIP_CHECK(hipMemcpyAsync(W.h_response, W.enc_out.p, p.response_bytes(), hipMemcpyDeviceToHost, s));
 }
 
 void run_finish(Workspace& W, const sp_pp& pp, bool premod) {
@@ -945,7 +968,7 @@ void run_finish(Workspace& W, const sp_pp& pp, bool premod) {
   }
   HIP_CHECK(hipEventRecord(W.ev[3], W.stream));
   run_pack(W, pp);
-  HIP_CHECK(hipMemcpyAsync(W.h_packed, W.pack_raw.p, W.h_packed_words * sizeof(u64), hipMemcpyDeviceToHost, W.stream));
+  run_encode_device(W);
   HIP_CHECK(hipEventRecord(W.ev[4], W.stream));
   (void)p;
 }
