@@ -237,9 +237,11 @@ def main():
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
-            "dtype": "u64 accumulate of u32xu32 products mod 28-bit primes (u32 NTT butterflies)",
+            "dtype": "u64",
             "data": "synthetic",
-            "config": {"workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
+            "config": {"arithmetic": "exact integers: u32 x u32 -> u64 multiply-accumulate mod two 28-bit primes, u32 NTT "
+                                     "butterflies (Shoup), no floating point",
+                       "workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
                                    "%s" % (args.config, json.dumps(cfg, sort_keys=True),
                                            p.db_words * 8 / 2**30,
                                            "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts, distributed fold, all-gather" % world, "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
