@@ -1543,6 +1543,53 @@ __global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) 
   }
 }
 
+// NARROW with 16-byte non-temporal loads (2 <= num_per <= 64): thread tau reads words 2 tau, 2 tau + 1 (+512 s):
+// the same row j, columns ii0 = (2 tau) % num_per and ii0 + 1.
+__global__ __launch_bounds__(256) void k_sweep_narrow2(DevTables T, SweepDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* qs = reinterpret_cast<uint4*>(smem);                              // [nj]
+  u32* red = reinterpret_cast<u32*>(smem + (size_t)d.nj * sizeof(uint4));  // [256][8]
+  const int tau = threadIdx.x;
+  const int zp = blockIdx.x;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  for (int j = tau; j < d.nj; j += 256) qs[j] = qrow[j];
+  __syncthreads();
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u64* p = d.db + (size_t)zp * d.nj * d.num_per;
+  const int L = d.nj * d.num_per;
+  const int np_log = __ffs(d.num_per) - 1;
+  u64 a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt = 0;
+  for (int f = 2 * tau; f < L; f += 512) {
+    ulonglong2 w;
+    w.x = __builtin_nontemporal_load(p + f);
+    w.y = __builtin_nontemporal_load(p + f + 1);
+    const uint4 qa = qs[f >> np_log];
+    const u32 b0l = (u32)w.x, b0h = (u32)(w.x >> 32), b1l = (u32)w.y, b1h = (u32)(w.y >> 32);
+    a[0] += (u64)qa.x * b0l; a[1] += (u64)qa.z * b0l; a[2] += (u64)qa.y * b0h; a[3] += (u64)qa.w * b0h;
+    a[4] += (u64)qa.x * b1l; a[5] += (u64)qa.z * b1l; a[6] += (u64)qa.y * b1h; a[7] += (u64)qa.w * b1h;
+    if (++cnt == 255) {
+      cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = reduce64(a[i], (i & 2) ? m1 : m0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[tau * 8 + i] = reduce64(a[i], (i & 2) ? m1 : m0);
+  __syncthreads();
+  if (tau < 4 * d.num_per) {
+    const int which = tau >> np_log, ii = tau & (d.num_per - 1);
+    const int slot = (ii & 1) * 4 + which, first = ii >> 1, step = d.num_per >> 1;
+    u64 sacc = 0;
+    for (int t2 = first; t2 < 256; t2 += step) sacc += red[t2 * 8 + slot];
+    const u32 r = reduce64(sacc, which < 2 ? m0 : m1);
+    const int rr = which & 1, cc = which >> 1;
+    d.out[sweep_out_index(d, plane, rr * 2 + cc, z, ii)] = r;
+  }
+}
+
 const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
 
 void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
@@ -1575,8 +1622,13 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
       default: hipLaunchKernelGGL((k_sweep_wide<1, true>), grid, dim3(256), 0, s, T, d); break;
     }
   } else {
-    size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
-    hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+    if (d.num_per >= 2 && !getenv("SPIRAL_NARROW1")) {
+      size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 8 * sizeof(u32);
+      hipLaunchKernelGGL(k_sweep_narrow2, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+    } else {
+      size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
+      hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+    }
   }
 }
 
