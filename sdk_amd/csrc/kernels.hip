@@ -852,6 +852,21 @@ __device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, i
       const int k_lo = seg == 0 ? 0 : d.split_k, k_hi = seg == 0 ? min(d.split_k, d.K) : d.K;
       const u32* Bs = seg == 0 ? B : B + (size_t)(d.split_off - d.split_k) * PW;
       int k = k_lo, since = 0;
+      for (; k + 28 <= k_hi; k += 28) {  // 56 loads in flight: the small expansion rounds are pure latency
+        u32 a[28], bb[28];
+#pragma unroll
+        for (int u = 0; u < 28; u++) {
+          a[u] = A[(size_t)(k + u) * PW];
+          bb[u] = Bs[(size_t)(k + u) * PW];
+        }
+#pragma unroll
+        for (int u = 0; u < 28; u++) acc += (u64)a[u] * (u64)bb[u];
+        since += 28;
+        if (since >= 56) {
+          acc = reduce64(acc, m);
+          since = 0;
+        }
+      }
       for (; k + 8 <= k_hi; k += 8) {
         u32 a[8], bb[8];
 #pragma unroll
