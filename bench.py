@@ -248,7 +248,7 @@ def main():
                        "queries_per_step": args.batch if world == 1 else 1,
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow",
+            "roofline": {"bound": "hbm", "kernel": "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, world),
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": sweep_ms,
