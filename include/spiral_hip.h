@@ -165,6 +165,10 @@ int sp_query_timings(const sp_query_t*, float* ms4);
  * average milliseconds per launch in *ms_per_launch. */
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch);
 
+/* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient
+ * vectors per thread, `blocks` workgroups each chaining `reps` transforms, no memory traffic but twiddles). */
+int sp_bench_ntt(const sp_params_t*, int M, int blocks, int reps, float* ns_per_ntt);
+
 /* ------------------------------------------------------------ stage level
  * 1:1 with the reference's pub functions, operating on caller-owned host arrays in ref layout.
  * These exist for parity tests and for callers (lib/server) that drive stages themselves. */

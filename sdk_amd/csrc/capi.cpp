@@ -714,6 +714,17 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
   });
 }
 
+// transform-core micro-benchmark (profiling aid): ns per 2048-point forward NTT with M vectors per thread
+int sp_bench_ntt(const sp_params_t* h, int M, int blocks, int reps, float* ns_per_ntt) {
+  return guarded([&] {
+    need(h && ns_per_ntt && blocks > 0 && reps > 0, "bad argument");
+    Scoped W(h);
+    DevBuf<u32> scratch((size_t)blocks * 256);
+    const float ms = bench_ntt_core(W->D->T, M, blocks, reps, scratch.p, W->stream);
+    *ns_per_ntt = ms * 1e6f / ((float)blocks * reps * (M == 1 || M == 2 ? M : 4));
+  });
+}
+
 // ------------------------------------------------------------------------------- stage level
 int sp_to_ntt(const sp_params_t* h, const uint64_t* raw, uint64_t* out, size_t count) {
   return guarded([&] {

@@ -369,6 +369,62 @@ __device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la
     }
 }
 
+// ---- micro-benchmark of the transform core (no memory traffic besides twiddles): `reps` chained transforms of M
+// coefficient vectors per workgroup; used by sp_bench_ntt to separate the NTT core cost from the fused kernels'.
+template <int M>
+__global__ __launch_bounds__(256) void k_ntt_core_bench(DevTables T, u32* out, int reps) {
+  __shared__ u32 lds0[M * LDS_WORDS];
+  __shared__ u32 lds1[M * LDS_WORDS];
+  const int tau = threadIdx.x;
+  const ModConst m = T.c.mod[blockIdx.x & 1];
+  const u32* fw = T.tw + (size_t)(blockIdx.x & 1) * 4 * N;
+  u32 v[M][8];
+#pragma unroll
+  for (int mm = 0; mm < M; mm++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[mm][k] = (tau * 2654435761u + k * 40503u + mm + blockIdx.x) % m.q;
+  u32* la = lds0;
+  u32* lb = lds1;
+  for (int r = 0; r < reps; r++) {
+    const u32* fwk = fw;
+    int tk = tau;
+    asm volatile("" : "+s"(fwk));
+    asm volatile("" : "+v"(tk));
+    ntt_fwd_block_m<M>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+    u32* t = la;
+    la = lb;
+    lb = t;
+  }
+  u32 acc = 0;
+#pragma unroll
+  for (int mm = 0; mm < M; mm++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc ^= v[mm][k];
+  out[blockIdx.x * 256 + tau] = acc;
+}
+float bench_ntt_core(const DevTables& T, int M, int blocks, int reps, u32* scratch, hipStream_t s) {
+  hipEvent_t a, b;
+  (void)hipEventCreate(&a);
+  (void)hipEventCreate(&b);
+  auto go = [&] {
+    switch (M) {
+      case 1: hipLaunchKernelGGL(k_ntt_core_bench<1>, dim3(blocks), dim3(256), 0, s, T, scratch, reps); break;
+      case 2: hipLaunchKernelGGL(k_ntt_core_bench<2>, dim3(blocks), dim3(256), 0, s, T, scratch, reps); break;
+      default: hipLaunchKernelGGL(k_ntt_core_bench<4>, dim3(blocks), dim3(256), 0, s, T, scratch, reps); break;
+    }
+  };
+  go();
+  (void)hipEventRecord(a, s);
+  go();
+  (void)hipEventRecord(b, s);
+  (void)hipEventSynchronize(b);
+  float ms = 0;
+  (void)hipEventElapsedTime(&ms, a, b);
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  return ms;
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward NTT kernel: grid (n_out, 2 crt)
 // ------------------------------------------------------------------------------------------------

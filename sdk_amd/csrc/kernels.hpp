@@ -42,6 +42,9 @@ void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s);
 // up to three descriptors in ONE launch (expansion rounds: left digits, right digits, row-1 NTT)
 void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, hipStream_t s);
 
+// micro-benchmark of the transform core: returns milliseconds for blocks*reps*M transforms
+float bench_ntt_core(const DevTables& T, int M, int blocks, int reps, u32* scratch, hipStream_t s);
+
 // ---- inverse NTT + CRT compose (poly.rs:646-663) -------------------------------------------
 // Source element (poly p, crt c, coefficient z) is read from
 //   src[(idx ? idx[p / polys_per_idx] * idx_stride + (p % polys_per_idx) * poly_stride : p * poly_stride)
