@@ -33,6 +33,12 @@ CONFIGS = {
     # the reference's own packed preset CFG_20_256 (2^20 x 256 B packed into 2^15 x 8 KiB)
     "p2": {"n": 2, "nu_1": 9, "nu_2": 6, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
            "t_exp_right": 56, "instances": 1, "db_item_size": 8192},
+    # configs[3]: 2^20 items x 32 KiB (SpiralWiki-style payload): 16 planes, 256 GiB encoded (224 GiB packed)
+    "c4": {"n": 2, "nu_1": 9, "nu_2": 11, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 4, "db_item_size": 32768},
+    # configs[2] per-GPU view: 2^22 items x 256 B (nu = (9,13)); run with --gpus 8 (32 GiB of rows per GPU)
+    "c3": {"n": 2, "nu_1": 9, "nu_2": 13, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
     "fast": {"n": 2, "nu_1": 6, "nu_2": 2, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
              "t_exp_right": 8, "instances": 1, "db_item_size": 8192},
 }
