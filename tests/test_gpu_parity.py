@@ -1,6 +1,8 @@
 """GPU parity: every stage of the HIP answer path, called through the C ABI, against the CPU oracle on
 identical seeded inputs -- bit-exact (integer arithmetic).  Mirrors the reference's test ladder
 (SURVEY.md App. F): L0 kernels, stage functions, end-to-end response bytes, then decrypt."""
+import os
+
 import numpy as np
 import pytest
 
@@ -620,3 +622,13 @@ def test_row_sharded_partials_sum_to_full(sp, oracle_mod):
         torch.cuda.synchronize()
         assert runs[0].finish() == expect
         assert cl.decode_response(expect) == o.item_to_vec(item)
+
+
+def test_rccl_world1_paths():
+    """The N > 1 bench paths through a real nccl (RCCL) process group (world size 1; a 1-GPU box cannot host
+    two ranks): collectives on the library's own device buffers, byte-identical responses."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "_rccl_world1.py")], capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
