@@ -63,14 +63,15 @@ def sweep_algorithmic_bytes(cfg, shards):
     return T * N * num_per * (dim0 // shards) * 8 + T * N * (dim0 // shards) * 2 * 8 + T * num_per * 4 * N * 8
 
 
-def pmc_traffic(cfg_name, world):
+def pmc_traffic(cfg_name, world, launches):
     """HBM bytes per sweep launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE); bench.py cannot collect counters itself.  None when no matching record."""
     if cfg_name != "c2" or world != 1:
         return None
     path = os.path.join(ROOT, "profiles", "r01_pmc_sweep_c2_packed.json")
     try:
-        return json.load(open(path))["hbm_bytes_per_launch"]
+        rec = json.load(open(path))
+        return rec["hbm_bytes_per_launch"] * rec.get("launches_per_query", 1) / launches
     except Exception:
         return None
 
@@ -225,9 +226,10 @@ def main():
 
     # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
     run = sp.QueryRun(p, pp, queries[0])
-    sweep_ms = run.bench_sweep(db, args.sweep_iters)
+    sweep_ms = run.bench_sweep(db, args.sweep_iters)          # per kernel launch
+    launches = run.sweep_launches(db)                         # 1, or one per plane when the fold is overlapped
     run.free()
-    alg_bytes = sweep_algorithmic_bytes(cfg, world)
+    alg_bytes = sweep_algorithmic_bytes(cfg, world) / launches
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
 
     if rank == 0:
@@ -256,8 +258,9 @@ def main():
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
             "roofline": {"bound": "hbm", "kernel": "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, world),
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, world, launches),
                          "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": sweep_ms,
+                         "launches_per_query": launches,
                          "note": "achieved = algorithmic bytes (reference 8-byte words) / HIP-event time of the sweep "
                                  "launch; the resident database is bit-packed to 7 bytes per word, so HBM traffic "
                                  "(PMC, profiles/r01_pmc_sweep_c2_packed.json) is below the algorithmic bytes"},

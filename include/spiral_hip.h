@@ -160,9 +160,12 @@ void* sp_query_stream(sp_query_t*);
  * [0] expand+conversion+folding_neg, [1] db sweep, [2] from_ntt+fold, [3] pack+encode(+D2H). */
 int sp_query_timings(const sp_query_t*, float* ms4);
 
-/* Stand-alone timed sweep for the roofline measurement: runs the db-sweep kernel `iters` times over
- * `db` with the query slice of `q`, HIP events on the launch stream around the whole batch; returns
- * average milliseconds per launch in *ms_per_launch. */
+/* Stand-alone timed sweep for the roofline measurement: issues the db-sweep launches of one query over `db`
+ * (the same kernel and launch shapes sp_process_query uses) `iters` times with the query slice of `q`, HIP events
+ * on the launch stream around the whole batch; returns average milliseconds per kernel launch in *ms_per_launch.
+ * sp_sweep_launches() = kernel launches per query sweep (the planes of a wide single-GPU database are swept one
+ * launch each so that the fold of plane p overlaps the sweep of plane p+1; 1 otherwise). */
+int sp_sweep_launches(const sp_params_t*, const sp_db_t*);
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch);
 
 /* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient

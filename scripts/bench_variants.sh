@@ -3,7 +3,7 @@
 cd "$(dirname "$0")/.."
 for v in "$@"; do
   echo "== $v"
-  env $v timeout 200 python bench.py --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
+  env $v timeout 200 python bench.py --config ${CONFIG:-c2} --steps ${STEPS:-5} --warmup 1 --no-cpu-baseline 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     try: d = json.loads(l)

@@ -483,11 +483,7 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
     need(db->params == q->params, "db was created for different params");
     check_device(db->device);
     Workspace& W = *q->ws;
-    static const bool pipeline = [] {
-      const char* e = getenv("SPIRAL_PIPELINE");
-      return e ? atoi(e) != 0 : false;  // measured: no gain, the sweep's own v_mad_u64_u32 stream and the fold share the VALU
-    }();
-    if (pipeline && db->num_shards == 1 && db->col_G == 1 && q->params->p.planes() > 1)
+    if (sweep_is_pipelined(q->params->p, *db))
       run_sweep_pipelined(W, *db);
     else
       run_sweep(W, *db);
@@ -701,17 +697,30 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
     hipEvent_t a, b;
     HIP_CHECK(hipEventCreate(&a));
     HIP_CHECK(hipEventCreate(&b));
-    run_sweep(W, *db);  // warm
+    // the same launches process_query issues for this database (one per plane when the sweep is pipelined)
+    const Params& p = q->params->p;
+    const bool per_plane = sweep_is_pipelined(p, *db);
+    auto sweep_once = [&] {
+      if (!per_plane) return run_sweep(W, *db);
+      W.ensure_sweep();
+      for (size_t pl = 0; pl < p.planes(); pl++) launch_plane_sweep(W, *db, pl);
+    };
+    sweep_once();  // warm
     HIP_CHECK(hipEventRecord(a, W.stream));
-    for (int i = 0; i < iters; i++) run_sweep(W, *db);
+    for (int i = 0; i < iters; i++) sweep_once();
     HIP_CHECK(hipEventRecord(b, W.stream));
     HIP_CHECK(hipStreamSynchronize(W.stream));
     float t = 0;
     HIP_CHECK(hipEventElapsedTime(&t, a, b));
-    *ms_per_launch = t / iters;
+    *ms_per_launch = t / ((float)iters * (per_plane ? (float)p.planes() : 1.0f));
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   });
+}
+
+int sp_sweep_launches(const sp_params_t* h, const sp_db_t* db) {
+  if (!h || !db) return 0;
+  return sweep_is_pipelined(h->p, *db) ? (int)h->p.planes() : 1;
 }
 
 // transform-core micro-benchmark (profiling aid): ns per 2048-point forward NTT with M vectors per thread

@@ -774,9 +774,14 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
 }
 // k_fold_fused with two digit transforms in flight per thread (shared twiddles / addresses / barriers).
 // Requires an even digit count t.
+// TW_LDS: the forward twiddles + Shoup quotients of the current modulus (16 KiB) are staged in LDS once per
+// modulus, so the 4 x 14 twiddle reads of every digit transform are ds_reads (no vector-memory latency, and no
+// queueing behind a concurrent sweep's load stream when the fold runs on the second stream).
+template <bool TW_LDS>
 __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d) {
   __shared__ u32 lds0[2 * LDS_WORDS];
   __shared__ u32 lds1[2 * LDS_WORDS];
+  __shared__ u32 ltw[TW_LDS ? 2 * N : 4];
   const int tau = threadIdx.x;
   const int i = blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
@@ -790,6 +795,13 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
     const u32* fw = T.tw + (size_t)c * 4 * N;
+    if (TW_LDS) {
+      if (c == 1) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; k++)  // [fw | fwp] = 2N words
+        reinterpret_cast<uint4*>(ltw)[tau + 256 * k] = reinterpret_cast<const uint4*>(fw)[tau + 256 * k];
+      __syncthreads();
+    }
     u64 acc0[8], acc1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
@@ -818,7 +830,10 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
         int tk = tau;
         asm volatile("" : "+s"(fwk));
         asm volatile("" : "+v"(tk));
-        ntt_fwd_block_m<2>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+        if (TW_LDS)
+          ntt_fwd_block_m<2>(v, tk, la, lb, ltw, ltw + N, m.q, m.two_q);
+        else
+          ntt_fwd_block_m<2>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
         {
           u32* tmp = la;
           la = lb;
@@ -875,10 +890,12 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   static const int variant = [] {
     const char* e = getenv("SPIRAL_FOLD_VARIANT");
-    return e ? atoi(e) : 2;
+    return e ? atoi(e) : 3;
   }();
-  if (variant == 2 && (d.t % 2) == 0)
-    hipLaunchKernelGGL(k_fold_fused2, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  if (variant == 3 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  else if (variant == 2 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 1)
     hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else
@@ -1377,7 +1394,10 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
 // CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
 // LDS stay free for the fold kernels running concurrently on the second stream.
 template <int U>
-__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units) {
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio) {
+  // the sweep is a latency-bound load stream using ~20 % of the VALU slots: when fold kernels share the CU its
+  // waves must win instruction arbitration or the loads in flight (and the HBM rate) drop
+  if (hi_prio) __builtin_amdgcn_s_setprio(3);
   const int lane = threadIdx.x & 63;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int nwaves = gridDim.x * 4;
@@ -1438,11 +1458,12 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
 void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s) {
   const int units = d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)std::min(256 * wgs_per_cu, (units + 3) / 4));
+  static const int prio = [] { const char* e = getenv("SPIRAL_SWEEP_PRIO"); return e ? atoi(e) : 1; }();
   switch (unroll) {
-    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units); break;
-    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units); break;
-    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units); break;
-    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units); break;
+    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio); break;
   }
 }
 

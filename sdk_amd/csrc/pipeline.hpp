@@ -60,6 +60,8 @@ void run_begin_direct(Workspace& W, const uint8_t* query);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
 void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
+bool sweep_is_pipelined(const Params& p, const sp_db& db);
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G);

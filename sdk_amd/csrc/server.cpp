@@ -573,23 +573,39 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 
-// Single-GPU query: the database is swept one (instance, trial) plane per launch, and the from_ntt + fold of
-// plane p (integer-ALU-bound) runs on a second stream while plane p+1 is being swept (HBM-bound).
+// Single-GPU query on a wide PACKED database: the database is swept one (instance, trial) plane per launch, and
+// the from_ntt + fold of plane p (integer-ALU-bound, ~20 % of the sweep's duration) runs on the second stream while
+// plane p+1 is being swept (HBM-bound, ~20 % VALU use, 40 VGPRs per wave: the fold's workgroups fit beside it).
+// Only the last plane's fold is exposed.  Worth it when one plane's sweep outlasts one plane's fold, i.e. for
+// num_per >= 1024; narrow databases keep the single launch + all-planes fold (their fold is latency-bound).
+bool sweep_is_pipelined(const Params& p, const sp_db& db) {
+  static const bool enabled = [] {
+    const char* e = getenv("SPIRAL_PIPELINE");
+    return e ? atoi(e) != 0 : true;
+  }();
+  return enabled && db.packed && db.num_shards == 1 && db.col_G == 1 && p.planes() > 1 && p.num_per() >= 1024;
+}
+
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
+  const Params& p = *W.P;
+  const size_t np_ = (size_t)db.np_local;
+  const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
+  SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
+              (int)p.dim0(), db.j0, db.nj, db.packed, 1};
+  static const int wgs = [] { const char* e = getenv("SPIRAL_PIPE_WGS"); return e ? atoi(e) : 4; }();
+  static const int unr = [] { const char* e = getenv("SPIRAL_PIPE_UNROLL"); return e ? atoi(e) : 4; }();
+  if (db.packed && wgs > 0)
+    launch_sweep_persist(W.D->T, d, wgs, unr, W.stream);
+  else
+    launch_sweep(W.D->T, d, W.stream);
+}
+
 void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
   W.ensure_finish();
-  const size_t np_ = (size_t)db.np_local;
-  const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   for (size_t pl = 0; pl < p.planes(); pl++) {
-    SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
-                (int)p.dim0(), db.j0, db.nj, db.packed, 1};
-    static const int wgs = [] { const char* e = getenv("SPIRAL_PIPE_WGS"); return e ? atoi(e) : 4; }();
-    static const int unr = [] { const char* e = getenv("SPIRAL_PIPE_UNROLL"); return e ? atoi(e) : 4; }();
-    if (db.packed && wgs > 0)
-      launch_sweep_persist(W.D->T, d, wgs, unr, W.stream);
-    else
-      launch_sweep(W.D->T, d, W.stream);
+    launch_plane_sweep(W, db, pl);
     HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
     HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
     std::swap(W.stream, W.stream2);

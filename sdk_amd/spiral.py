@@ -491,9 +491,13 @@ class QueryRun:
         return list(t)
 
     def bench_sweep(self, db, iters):
+        """average milliseconds per db-sweep kernel launch (sweep_launches(db) launches per query)"""
         ms = C.c_float(0)
         _chk(lib().sp_bench_sweep(_vp(self.h), _vp(db.h), C.c_int(iters), C.byref(ms)))
         return ms.value
+
+    def sweep_launches(self, db):
+        return int(lib().sp_sweep_launches(_vp(self.params.h), _vp(db.h)))
 
 
 def process_query(params, public_params, query, db):
