@@ -135,8 +135,7 @@ def main():
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
-    from sdk_amd.sharding import (gather_local, local_cts_tensor, partial_tensor, reduce_partials,
-                                  reduce_scatter_partials)
+    from sdk_amd.sharding import gather_local, local_cts_tensor, partial_tensor, reduce_partials, scatter_fold_query
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -147,27 +146,33 @@ def main():
     torch.cuda.set_device(local_rank)
     if sp.lib().sp_set_device(local_rank) != 0:
         raise SystemExit("sp_set_device failed")
-    if world > 1:
+    # SPIRAL_FORCE_DIST=1: run the N > 1 code path (process group, collectives) at world size 1 (1-GPU boxes)
+    use_dist = world > 1 or os.environ.get("SPIRAL_FORCE_DIST") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     p = sp.Params(cfg)
     pp = sp.PublicParameters.deserialize(p, synthetic_wire_bytes(p.setup_bytes(), 1))
     queries = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
-    mode = os.environ.get("SPIRAL_MULTIGPU", "scatter") if world > 1 else "single"
+    mode = os.environ.get("SPIRAL_MULTIGPU", "scatter") if use_dist else "single"
     if mode in ("scatter", "columns") and (1 << cfg["nu_2"]) < world:
         mode = "reduce"
     db = sp.Database(p, rank, world, by_columns=(mode == "columns")).fill_synthetic(0x123456789)  # util.rs:171-173 seed
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     distributed_fold = mode == "scatter"
+    # stream-ordered flow with the reduce-scatter of plane p overlapping the sweep of plane p+1; verified below
+    # against the host-synchronised flow of the same data path before it is timed
+    overlap = os.environ.get("SPIRAL_OVERLAP", "1") != "0"
 
     def step(i):
         if args.batch > 1 and world == 1:
@@ -185,16 +190,8 @@ def main():
         elif distributed_fold:
             # row-sharded sweep -> RCCL reduce-scatter over columns -> every rank folds its columns ->
             # gather of one ciphertext per plane per rank -> rank 0 folds the last log2(N) levels
-            run.sweep_scatter(db, world)
-            run.sync()
-            mine = reduce_scatter_partials(partial_tensor(run), rank, world)  # 8 * (q-1) < 2^31
-            torch.cuda.synchronize()
-            run.fold_local(mine.data_ptr(), world)
-            run.sync()
-            gathered = gather_local(local_cts_tensor(run), rank, world, dst=0)
-            torch.cuda.synchronize()
-            out = run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
-        elif world > 1:
+            out = scatter_fold_query(run, db, rank, world, overlap=overlap)
+        elif use_dist:
             run.sweep(db)
             run.sync()
             reduce_partials(partial_tensor(run), dst=0)  # RCCL ncclSum over xGMI onto rank 0
@@ -207,6 +204,19 @@ def main():
         run.free()
         return out, t
 
+    if distributed_fold and overlap:
+        # self-check: the overlapped flow must reproduce the synchronised flow's response byte for byte
+        overlap = False
+        ref, _ = step(0)
+        overlap = True
+        got, _ = step(0)
+        ok = torch.tensor([1 if (rank != 0 or got == ref) else 0], device="cuda")
+        dist.broadcast(ok, src=0)
+        if int(ok.item()) != 1:
+            overlap = False
+            if rank == 0:
+                print("bench: overlapped multi-GPU flow disagreed with the synchronised flow; timing the latter",
+                      file=sys.stderr, flush=True)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -218,7 +228,7 @@ def main():
             stage += np.array(t)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -226,8 +236,10 @@ def main():
 
     # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
     run = sp.QueryRun(p, pp, queries[0])
-    sweep_ms = run.bench_sweep(db, args.sweep_iters)          # per kernel launch
-    launches = run.sweep_launches(db)                         # 1, or one per plane when the fold is overlapped
+    if distributed_fold and overlap:                          # one launch per plane, exchange overlapped
+        sweep_ms, launches = run.bench_sweep(db, args.sweep_iters, per_plane=1), cfg["instances"] * cfg["n"] ** 2
+    else:                                                     # 1, or one per plane when the fold is overlapped
+        sweep_ms, launches = run.bench_sweep(db, args.sweep_iters), run.sweep_launches(db)
     run.free()
     alg_bytes = sweep_algorithmic_bytes(cfg, world) / launches
     achieved = alg_bytes / (sweep_ms * 1e-3) / 1e9
@@ -252,7 +264,7 @@ def main():
                        "workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
                                    "%s" % (args.config, json.dumps(cfg, sort_keys=True),
                                            p.db_words * 8 / 2**30,
-                                           "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts, distributed fold, all-gather" % world, "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
+                                           "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts%s, distributed fold, all-gather" % (world, " (per plane, overlapping the next plane's sweep)" if overlap else ""), "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
                        "queries_per_step": args.batch if world == 1 else 1,
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
                                     "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
@@ -270,7 +282,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

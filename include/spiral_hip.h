@@ -143,6 +143,11 @@ int sp_process_query_batch(const sp_params_t*, const sp_pp_t* const* pps, const 
  *   ...           : caller gathers the G local results on the finishing rank: [g][plane][2][N]
  *   finish_gathered: the last log2(G) fold levels (leaf g = rank g), pack, encode. */
 int sp_query_sweep_scatter(sp_query_t*, const sp_db_t*, int G);
+/* The same sweep one (instance, trial) plane per launch, planes in order 0 .. planes-1.  Plane p's region of the
+ * partial buffer ([p * partial_words/planes, (p+1) * partial_words/planes)) is laid out [g][r][crt][z][ii / G], so
+ * each plane can be reduce-scattered on its own, overlapping the exchange of plane p with the sweep of plane p+1;
+ * the concatenation of the received chunks is the [plane][r][crt][z][ii / G] buffer sp_query_fold_local takes. */
+int sp_query_sweep_scatter_plane(sp_query_t*, const sp_db_t*, int G, int plane);
 int sp_query_fold_local(sp_query_t*, const void* reduced_chunk_dev, int G);
 void* sp_query_local_cts_ptr(sp_query_t*);
 size_t sp_query_local_cts_words(const sp_query_t*);
@@ -167,6 +172,9 @@ int sp_query_timings(const sp_query_t*, float* ms4);
  * launch each so that the fold of plane p overlaps the sweep of plane p+1; 1 otherwise). */
 int sp_sweep_launches(const sp_params_t*, const sp_db_t*);
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch);
+/* per_plane_launches: 1 = one launch per plane (what sp_query_sweep_scatter_plane issues), 0 = one launch,
+ * -1 = what sp_query_sweep would do for this db (sp_bench_sweep). */
+int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane_launches, float* ms_per_launch);
 
 /* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient
  * vectors per thread, `blocks` workgroups each chaining `reps` transforms, no memory traffic but twiddles). */

@@ -38,6 +38,7 @@ struct sp_query {
   const sp_pp* pp = nullptr;
   std::unique_ptr<Workspace> ws;
   int state = 0;  // 1 begun, 2 swept, 3 finished
+  int next_plane = 0;  // sp_query_sweep_scatter_plane progress
   float ms[4] = {0, 0, 0, 0};
   ~sp_query() {
     if (ws && params) {
@@ -511,6 +512,35 @@ int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
   });
 }
 
+int sp_query_sweep_scatter_plane(sp_query_t* q, const sp_db_t* db, int G, int plane) {
+  return guarded([&] {
+    need(q && db, "null argument");
+    need(db->params == q->params, "db was created for different params");
+    const Params& p = q->params->p;
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
+         "G must be a power of two <= num_per and equal to the db's num_shards");
+    need(db->col_G == 1, "sweep_scatter works on row shards");
+    need(plane >= 0 && (size_t)plane < p.planes(), "plane out of range");
+    need(q->state == 1 && q->next_plane == plane, "sp_query_sweep_scatter_plane: planes must be swept in order after begin");
+    check_device(db->device);
+    Workspace& W = *q->ws;
+    W.ensure_sweep();
+    W.out_G = G;
+    try {
+      launch_plane_sweep(W, *db, (size_t)plane);
+    } catch (...) {
+      W.out_G = 1;
+      throw;
+    }
+    W.out_G = 1;
+    q->next_plane = plane + 1;
+    if ((size_t)q->next_plane == p.planes()) {
+      HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
+      q->state = 2;
+    }
+  });
+}
+
 int sp_query_fold_local(sp_query_t* q, const void* reduced_chunk, int G) {
   return guarded([&] {
     need(q && reduced_chunk, "null argument");
@@ -689,6 +719,10 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
 }
 
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch) {
+  return sp_bench_sweep_ex(q, db, iters, -1, ms_per_launch);
+}
+
+int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane_launches, float* ms_per_launch) {
   return guarded([&] {
     need(q && db && ms_per_launch && iters > 0, "bad argument");
     need(q->state >= 1, "query not begun");
@@ -699,7 +733,8 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
     HIP_CHECK(hipEventCreate(&b));
     // the same launches process_query issues for this database (one per plane when the sweep is pipelined)
     const Params& p = q->params->p;
-    const bool per_plane = sweep_is_pipelined(p, *db);
+    const bool per_plane = per_plane_launches < 0 ? sweep_is_pipelined(p, *db) : per_plane_launches != 0;
+    need(!per_plane || db->col_G == 1, "per-plane launches need a row-sharded or unsharded db");
     auto sweep_once = [&] {
       if (!per_plane) return run_sweep(W, *db);
       W.ensure_sweep();

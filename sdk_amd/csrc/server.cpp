@@ -591,7 +591,7 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
   const size_t np_ = (size_t)db.np_local;
   const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
-              (int)p.dim0(), db.j0, db.nj, db.packed, 1};
+              (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
   static const int wgs = [] { const char* e = getenv("SPIRAL_PIPE_WGS"); return e ? atoi(e) : 4; }();
   static const int unr = [] { const char* e = getenv("SPIRAL_PIPE_UNROLL"); return e ? atoi(e) : 4; }();
   if (db.packed && wgs > 0)

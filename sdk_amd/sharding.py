@@ -71,12 +71,72 @@ def gather_local(local, rank, world, dst=0):
     return out if rank == dst else None
 
 
+def scatter_fold_query(run, db, rank, world, overlap=True):
+    """The N > 1 answer path after sp_query_begin, rank-local view (north star): row-sharded
+    sweep -> RCCL reduce-scatter of the partial Regev ciphertexts over the column axis -> every rank folds its
+    columns with the top nu_2 - log2(world) selector bits -> all-gather of one ciphertext per plane per rank ->
+    rank 0 folds the last log2(world) levels, packs and encodes.  Returns the response bytes on rank 0, None
+    elsewhere.
+
+    overlap=True: everything is ordered on the query's HIP stream (no host synchronisation until the response
+    is copied out); the database is swept one plane per launch and the reduce-scatter of plane p (RCCL's own
+    stream) runs while plane p+1 is swept.  overlap=False: one sweep launch, one reduce-scatter, host
+    synchronisation between the steps (the reference implementation of the same data flow)."""
+    import torch
+    import torch.distributed as dist
+    planes = run.params.get("instances") * run.params.get("n") ** 2
+    if not overlap:
+        run.sweep_scatter(db, world)
+        run.sync()
+        mine = reduce_scatter_partials(partial_tensor(run), rank, world)
+        torch.cuda.synchronize()
+        run.fold_local(mine.data_ptr(), world)
+        run.sync()
+        gathered = gather_local(local_cts_tensor(run), rank, world, dst=0)
+        torch.cuda.synchronize()
+        return run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
+    part = partial_tensor(run)
+    pw = part.numel() // planes
+    chunk = pw // world
+    nccl = dist.get_backend() == "nccl"
+    with torch.cuda.stream(torch.cuda.ExternalStream(run.stream())):
+        mine = torch.empty(planes * chunk, dtype=part.dtype, device=part.device)
+        works = []
+        for pl in range(planes):
+            run.sweep_scatter_plane(db, world, pl)
+            src, dst = part[pl * pw:(pl + 1) * pw], mine[pl * chunk:(pl + 1) * chunk]
+            if nccl:
+                works.append(dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                dist.all_reduce(src, op=dist.ReduceOp.SUM)
+                dst.copy_(src[rank * chunk:(rank + 1) * chunk])
+        for w in works:
+            w.wait()  # stream-level: the query stream waits for the collective, the host does not
+        run.fold_local(mine.data_ptr(), world)
+        local = local_cts_tensor(run)
+        gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
+        if nccl:
+            dist.all_gather_into_tensor(gathered, local)
+        else:
+            dist.all_gather(list(gathered.view(world, -1).unbind(0)), local.contiguous())
+        out = run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
+    run.sync()  # mine / gathered are released by the caller's scope: nothing may still be reading them
+    return out
+
+
 def scatter_layout_index(num_per, planes, G, plane, r, crt, z, ii, N=2048):
     """flat index of output (plane, r, crt, z, ii) in the column-interleaved partial buffer
     (kernels.hip sweep_out_index): chunk ii % G, then [plane][r][crt][z][ii // G]"""
     npl = num_per // G
     chunk_words = planes * 4 * N * npl
     return (ii % G) * chunk_words + (((plane * 2 + r) * 2 + crt) * N + z) * npl + ii // G
+
+
+def scatter_plane_layout_index(num_per, G, plane, r, crt, z, ii, N=2048):
+    """flat index of output (plane, r, crt, z, ii) when the sweep runs one plane per launch
+    (sp_query_sweep_scatter_plane): [plane][chunk ii % G][r][crt][z][ii // G]"""
+    npl = num_per // G
+    return plane * 4 * N * num_per + (ii % G) * 4 * N * npl + ((r * 2 + crt) * N + z) * npl + ii // G
 
 
 def fold_schedule(nu_2, G):

@@ -446,6 +446,11 @@ class QueryRun:
         _chk(lib().sp_query_sweep_scatter(_vp(self.h), _vp(db.h), C.c_int(G)))
         return self
 
+    def sweep_scatter_plane(self, db, G, plane):
+        """one plane of sweep_scatter; plane region of the partial buffer = [g][r][crt][z][ii / G]"""
+        _chk(lib().sp_query_sweep_scatter_plane(_vp(self.h), _vp(db.h), C.c_int(G), C.c_int(plane)))
+        return self
+
     def fold_local(self, reduced_chunk_ptr, G):
         _chk(lib().sp_query_fold_local(_vp(self.h), C.c_void_p(reduced_chunk_ptr), C.c_int(G)))
         return self
@@ -490,10 +495,11 @@ class QueryRun:
         _chk(lib().sp_query_timings(_vp(self.h), t))
         return list(t)
 
-    def bench_sweep(self, db, iters):
-        """average milliseconds per db-sweep kernel launch (sweep_launches(db) launches per query)"""
+    def bench_sweep(self, db, iters, per_plane=-1):
+        """average milliseconds per db-sweep kernel launch (sweep_launches(db) launches per query by default;
+        per_plane = 1 / 0 forces one launch per plane / one launch)"""
         ms = C.c_float(0)
-        _chk(lib().sp_bench_sweep(_vp(self.h), _vp(db.h), C.c_int(iters), C.byref(ms)))
+        _chk(lib().sp_bench_sweep_ex(_vp(self.h), _vp(db.h), C.c_int(iters), C.c_int(per_plane), C.byref(ms)))
         return ms.value
 
     def sweep_launches(self, db):

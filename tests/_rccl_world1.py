@@ -49,6 +49,13 @@ def main():
     assert run.finish_gathered(gathered.data_ptr(), world) == expect, "scatter path"
     run.free()
 
+    # the same path as bench.py drives it: stream-ordered with per-plane async reduce-scatter, and host-synchronised
+    from sdk_amd.sharding import scatter_fold_query
+    for overlap in (True, False, True):
+        run = sp.QueryRun(p, gpp, q)
+        assert scatter_fold_query(run, gdb, rank, world, overlap=overlap) == expect, "scatter_fold_query overlap=%s" % overlap
+        run.free()
+
     # reduce: sweep -> dist.reduce -> finish
     run = sp.QueryRun(p, gpp, q).sweep(gdb)
     run.sync()

@@ -499,13 +499,15 @@ def test_c2_full_size_sampled_parity(sp, oracle_mod):
     assert len(run.finish()) == p.get("response_bytes")
 
 
+@pytest.mark.parametrize("per_plane", [False, True], ids=["one-launch", "per-plane"])
 @pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4)],
                          ids=["narrow-G2", "narrow-G8", "packed-G4"])
-def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G):
+def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G, per_plane):
     """The N > 1 bench path (sweep_scatter -> reduce-scatter -> fold_local -> gather -> finish_gathered) with
-    the G ranks played one after another on one GPU; the collective is replaced by a torch sum/slice."""
+    the G ranks played one after another on one GPU; the collective is replaced by a torch sum/slice.
+    per-plane: the sweep one plane per launch (sp_query_sweep_scatter_plane), reduce-scattered plane by plane."""
     import torch
-    from sdk_amd.sharding import local_cts_tensor, partial_tensor
+    from sdk_amd.sharding import local_cts_tensor, partial_tensor, scatter_layout_index, scatter_plane_layout_index
     idx = 77
     o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
     p = sp.Params(cfg)
@@ -513,16 +515,43 @@ def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G):
     gpp = sp.PublicParameters.deserialize(p, pp)
     expect = o.process_query(pp, q, db)
     shards = [sp.Database(p, s, G).load(db) for s in range(G)]
-    runs = [sp.QueryRun(p, gpp, q).sweep_scatter(shards[s], G) for s in range(G)]
+    planes = 4
+    if per_plane:
+        runs = [sp.QueryRun(p, gpp, q) for s in range(G)]
+        with pytest.raises(sp.SpiralError):
+            runs[0].sweep_scatter_plane(shards[0], G, 1)       # planes go in order
+        for s in range(G):
+            for pl in range(planes):
+                runs[s].sweep_scatter_plane(shards[s], G, pl)
+    else:
+        runs = [sp.QueryRun(p, gpp, q).sweep_scatter(shards[s], G) for s in range(G)]
     total = None
     for r in runs:
         r.sync()
         t = partial_tensor(r)
         total = t.clone() if total is None else total + t
     chunk = total.numel() // G
+    if per_plane:
+        # the two layouts hold the same values: [plane][g][...] vs [g][plane][...]
+        ref_runs = [sp.QueryRun(p, gpp, q).sweep_scatter(shards[s], G) for s in range(G)]
+        ref_total = None
+        for r in ref_runs:
+            r.sync()
+            t = partial_tensor(r)
+            ref_total = t.clone() if ref_total is None else ref_total + t
+        rng = np.random.default_rng(3)
+        for _ in range(200):
+            pl, rr, c, z, ii = (int(rng.integers(planes)), int(rng.integers(2)), int(rng.integers(2)),
+                                int(rng.integers(2048)), int(rng.integers(o.num_per)))
+            assert int(total[scatter_plane_layout_index(o.num_per, G, pl, rr, c, z, ii)]) == \
+                int(ref_total[scatter_layout_index(o.num_per, planes, G, pl, rr, c, z, ii)])
+        pw, pc = total.numel() // planes, total.numel() // planes // G
     locals_ = []
     for g, r in enumerate(runs):
-        mine = total[g * chunk:(g + 1) * chunk].contiguous()
+        if per_plane:
+            mine = torch.cat([total[pl * pw + g * pc:pl * pw + (g + 1) * pc] for pl in range(planes)]).contiguous()
+        else:
+            mine = total[g * chunk:(g + 1) * chunk].contiguous()
         torch.cuda.synchronize()
         r.fold_local(mine.data_ptr(), G)
         r.sync()
