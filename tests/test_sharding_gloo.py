@@ -150,3 +150,29 @@ def test_shard_rows_contract():
         shard_rows(512, 0, 16)      # int32 partial sums are only overflow-free for <= 8 shards
     with pytest.raises(ValueError):
         shard_rows(6, 0, 4)
+
+
+@pytest.mark.parametrize("num_per,G", [(16, 2), (32, 8), (8, 4)])
+def test_scatter_layouts_are_permutations(num_per, G):
+    """Both column-interleaved partial layouts ([g][plane].. of sweep_scatter and [plane][g].. of
+    sweep_scatter_plane) enumerate the buffer exactly once, and rank g's chunk of every plane holds the columns
+    ii = g (mod G) in [r][crt][z][ii // G] order — what sp_query_fold_local consumes."""
+    from sdk_amd.sharding import scatter_layout_index, scatter_plane_layout_index
+    N, planes = 8, 4   # the index functions are linear in N: a small N keeps the enumeration cheap
+    total = planes * 4 * N * num_per
+    a = np.zeros(total, dtype=np.int64)
+    b = np.zeros(total, dtype=np.int64)
+    npl = num_per // G
+    for pl in range(planes):
+        for r in range(2):
+            for c in range(2):
+                for z in range(N):
+                    for ii in range(num_per):
+                        a[scatter_layout_index(num_per, planes, G, pl, r, c, z, ii, N=N)] += 1
+                        i2 = scatter_plane_layout_index(num_per, G, pl, r, c, z, ii, N=N)
+                        b[i2] += 1
+                        # inside plane pl, chunk g starts at g * (plane words / G)
+                        g, off = ii % G, i2 - pl * 4 * N * num_per
+                        assert off // (4 * N * npl) == g
+                        assert off % (4 * N * npl) == ((r * 2 + c) * N + z) * npl + ii // G
+    assert (a == 1).all() and (b == 1).all()
