@@ -710,8 +710,12 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
         u32 v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
-          const u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
-          const u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+          u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
+          u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+          if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
+            d0 = d0 >= m.q ? d0 - m.q : d0;
+            d1 = d1 >= m.q ? d1 - m.q : d1;
+          }
           v[k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
         }
         const u32* fwk = fw;
@@ -821,8 +825,12 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
           const int sh = (kd + mm) * d.bits;
 #pragma unroll
           for (int k = 0; k < 8; k++) {
-            const u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
-            const u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+            u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
+            u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+            if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
+              d0 = d0 >= m.q ? d0 - m.q : d0;
+              d1 = d1 >= m.q ? d1 - m.q : d1;
+            }
             v[mm][k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
           }
         }
@@ -1470,8 +1478,16 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
 // Multi-query PACKED sweep: B queries share one pass over the database (BASELINE configs[4]).  Per row
 // pair: one 28-byte load, B x 2 scalar query rows, 16 B multiply-accumulates.  HBM-bound up to B ~ 4,
 // integer-ALU-bound beyond.
-template <int B>
+// U row pairs (28 B per lane each) are in flight per wave (U = 4 needs npairs % 4 == 0: no ragged tail, straight-line
+// code): with B queries' accumulators the kernel runs at 2-5 waves per SIMD, and one load per wave leaves the HBM
+// pipe mostly empty (B = 8: 21 ms per pass instead of ~10).
+// QLDS: the B queries' rows for this workgroup's z (B * nj * 16 B, 64 KiB at B = 8) are staged in LDS once and
+// read back as broadcast ds_reads.  The scalar-load form keeps them in the 16 KiB scalar cache, which B > 4
+// overflows: every query word then costs an L2 round trip and the pass takes 25 ms instead of ~10 at B = 8.
+// Needs all four waves of the workgroup on the same z (chunks % 4 == 0).
+template <int B, int U, bool QLDS>
 __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBatchDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
   const int lane = threadIdx.x & 63;
   const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int chunks = d.num_per >> 7;
@@ -1479,6 +1495,18 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
   const int zp = unit / chunks;
   const int z = zp & (N - 1);
   const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qs = reinterpret_cast<const uint4*>(smem_q);  // [B][nj]
+  if (QLDS) {
+    const int zp0 = (blockIdx.x * 4) / chunks;  // the whole workgroup shares one (plane, z)
+    const int z0 = zp0 & (N - 1);
+    uint4* qw = reinterpret_cast<uint4*>(smem_q);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint4* src = reinterpret_cast<const uint4*>(d.qv[b]) + ((size_t)z0 * d.dim0 + d.j0);
+      for (int j = threadIdx.x; j < d.nj; j += 256) qw[b * d.nj + j] = src[j];
+    }
+    __syncthreads();
+  }
   if (plane >= d.planes) return;
   const int npairs = d.nj >> 1;
   const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
@@ -1491,13 +1519,30 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
   for (int b = 0; b < B; b++)
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[b][k] = 0;
-  for (int jb = 0; jb < npairs; jb += 128) {
-    const int je = min(jb + 128, npairs);
-    for (int jp = jb; jp < je; jp++) {
-      const u32* u = base + (size_t)jp * ustride;
-      const u32x4_t va = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
-      const u32x3_t vb = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
-      const u32 d0 = va.x, d1 = va.y, d2 = va.z, d3 = va.w, d4 = vb.x, d5 = vb.y, d6 = vb.z;
+  // software pipeline: the loads of the next U row pairs are issued before the current U are consumed
+  u32x4_t va[U], na[U];
+  u32x3_t vb[U], nb[U];
+#pragma unroll
+  for (int uu = 0; uu < U; uu++) {
+    const u32* u = base + (size_t)uu * ustride;
+    va[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
+    vb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+  }
+  for (int jp0 = 0; jp0 < npairs; jp0 += U) {
+    const bool more = jp0 + U < npairs;
+    if (more) {
+#pragma unroll
+      for (int uu = 0; uu < U; uu++) {
+        const u32* u = base + (size_t)(jp0 + U + uu) * ustride;
+        na[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
+        nb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the multiply-accumulates
+#pragma unroll
+    for (int uu = 0; uu < U; uu++) {
+      const int jp = jp0 + uu;
+      const u32 d0 = va[uu].x, d1 = va[uu].y, d2 = va[uu].z, d3 = va[uu].w, d4 = vb[uu].x, d5 = vb[uu].y, d6 = vb[uu].z;
       const u32 f0 = d0 & M;
       const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
       const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
@@ -1508,7 +1553,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
       const u32 f7 = d6 >> 4;
 #pragma unroll
       for (int b = 0; b < B; b++) {
-        const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv[b]) + qoff;
+        const uint4* __restrict__ qrow = QLDS ? qs + b * d.nj : reinterpret_cast<const uint4*>(d.qv[b]) + qoff;
         const uint4 qa = qrow[2 * jp];
         const uint4 qb = qrow[2 * jp + 1];
         acc[b][0] += (u64)qa.x * f0; acc[b][1] += (u64)qa.z * f0; acc[b][2] += (u64)qa.y * f1; acc[b][3] += (u64)qa.w * f1;
@@ -1517,12 +1562,19 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
         acc[b][4] += (u64)qb.x * f6; acc[b][5] += (u64)qb.z * f6; acc[b][6] += (u64)qb.y * f7; acc[b][7] += (u64)qb.w * f7;
       }
     }
+    if (!more || ((jp0 + U) & 127) == 0) {  // at most 256 rows of < 2^56 products between Barrett folds
 #pragma unroll
-    for (int b = 0; b < B; b++) {
-      acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);
-      acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);
-      acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);
-      acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);
+      for (int b = 0; b < B; b++) {
+        acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);
+        acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);
+        acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);
+        acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);
+      }
+    }
+#pragma unroll
+    for (int uu = 0; uu < U; uu++) {
+      va[uu] = na[uu];
+      vb[uu] = nb[uu];
     }
   }
   const size_t rc = (size_t)N * d.num_per;
@@ -1539,16 +1591,25 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
   const long units = (long)d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)((units + 3) / 4));
+  const bool unroll = ((d.nj >> 1) % 4) == 0;
+  static const int lds_min_b = [] { const char* e = getenv("SPIRAL_BATCH_QLDS_MIN"); return e ? atoi(e) : 5; }();
+  const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && (size_t)d.batch * d.nj * 16 <= 65536;
+  const size_t lds = qlds ? (size_t)d.batch * d.nj * 16 : 0;
+#define SP_BATCH_CASE(B)                                                                              \
+  case B:                                                                                             \
+    if (qlds)                                                                                         \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, (B >= 7 ? 2 : 4), true>), grid, dim3(256), lds, s, T, d); \
+    else if (unroll)                                                                                  \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, false>), grid, dim3(256), 0, s, T, d);           \
+    else                                                                                              \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 1, false>), grid, dim3(256), 0, s, T, d);           \
+    break;
   switch (d.batch) {
-    case 1: hipLaunchKernelGGL(k_sweep_packed_batch<1>, grid, dim3(256), 0, s, T, d); break;
-    case 2: hipLaunchKernelGGL(k_sweep_packed_batch<2>, grid, dim3(256), 0, s, T, d); break;
-    case 3: hipLaunchKernelGGL(k_sweep_packed_batch<3>, grid, dim3(256), 0, s, T, d); break;
-    case 4: hipLaunchKernelGGL(k_sweep_packed_batch<4>, grid, dim3(256), 0, s, T, d); break;
-    case 5: hipLaunchKernelGGL(k_sweep_packed_batch<5>, grid, dim3(256), 0, s, T, d); break;
-    case 6: hipLaunchKernelGGL(k_sweep_packed_batch<6>, grid, dim3(256), 0, s, T, d); break;
-    case 7: hipLaunchKernelGGL(k_sweep_packed_batch<7>, grid, dim3(256), 0, s, T, d); break;
-    default: hipLaunchKernelGGL(k_sweep_packed_batch<8>, grid, dim3(256), 0, s, T, d); break;
+    SP_BATCH_CASE(1) SP_BATCH_CASE(2) SP_BATCH_CASE(3) SP_BATCH_CASE(4)
+    SP_BATCH_CASE(5) SP_BATCH_CASE(6) SP_BATCH_CASE(7) SP_BATCH_CASE(8)
+    default: break;
   }
+#undef SP_BATCH_CASE
 }
 
 // Packing helpers shared by the writers of the PACKED format.

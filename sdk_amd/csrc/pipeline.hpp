@@ -62,6 +62,7 @@ void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);
 void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
+bool fused_fold_supported(const Params& p);
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G);

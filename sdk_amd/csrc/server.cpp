@@ -287,7 +287,7 @@ void Workspace::ensure_expand() {
 
 size_t Workspace::plane_group() const {
   const Params& p = *P;
-  const bool fused_ok = 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64 && fused_min_pairs < (1L << 40);
+  const bool fused_ok = fused_fold_supported(p) && fused_min_pairs < (1L << 40);
   // raw ct staging (X, Y) per plane; plus the digit staging when the unfused path handles whole levels
   size_t per_plane = p.num_per() * 2 * POLY_LEN * sizeof(u64) * 2;
   if (!fused_ok) per_plane += p.num_per() * 2 * p.t_gsw * 2 * POLY_LEN * sizeof(u32);
@@ -307,7 +307,7 @@ void Workspace::ensure_finish() {
   foldX.ensure(pg * p.num_per() * 2 * POLY_LEN);
   foldY.ensure(std::max<size_t>(pg * p.num_per() / 2, 1) * 2 * POLY_LEN);
   // the digit-NTT staging is only used by the unfused tree tail (levels with < fused_min_pairs units)
-  const bool fused_ok = 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64;
+  const bool fused_ok = fused_fold_supported(p);
   size_t dig_cts = pg * p.num_per();
   if (fused_ok && fused_min_pairs < (1L << 40)) dig_cts = std::min<size_t>(dig_cts, std::max<size_t>(2 * (size_t)fused_min_pairs, 2 * pg));
   fold_dig.ensure(dig_cts * 2 * p.t_gsw * 2 * POLY_LEN);
@@ -621,6 +621,9 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   W.pipelined = true;
 }
 
+// k_fold_fused* keep gadget digits in u32 and need digit < 2q, i.e. at most 28 bits per digit (t_gsw >= 2)
+bool fused_fold_supported(const Params& p) { return 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) <= 28; }
+
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
@@ -637,7 +640,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
     const int half = cur / 2;
     // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
     // the three-kernel form, which parallelises over digits
-    if ((long)np * half >= W.fused_min_pairs && 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) < 64) {
+    if ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p)) {
       FoldDesc fd{};
       fd.X = X;
       fd.Y = Y;

@@ -661,3 +661,46 @@ def test_rccl_world1_paths():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "_rccl_world1.py")], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+def test_overlapped_fold_many_planes_parity(sp, oracle_mod):
+    """The default path of wide packed databases (one sweep launch per plane, from_ntt + fold of plane p on the
+    second stream under the sweep of plane p+1) with 8 planes (instances = 2), byte-identical to the oracle.
+    t_gsw = 2 keeps the oracle fast (the response is not decodable at this noise level and need not be) and makes
+    the gadget digits 28 bits wide, i.e. possibly >= q: the fused fold has to canonicalise them."""
+    cfg = {"n": 2, "nu_1": 4, "nu_2": 10, "p": 256, "q2_bits": 20, "t_gsw": 2, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 2, "db_item_size": 16384}
+    o, cl, pp, q = _session(oracle_mod, cfg, 1234, 6)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(1234)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    run = sp.QueryRun(p, gpp, q)
+    assert run.sweep_launches(gdb) == (1 if os.environ.get("SPIRAL_PIPELINE") == "0" else 8)
+    resp = run.sweep(gdb).finish()
+    run.free()
+    assert resp == o.process_query(pp, q, db)
+    assert sp.process_query(p, gpp, q, gdb) == resp
+
+
+def test_process_query_batch_lds_staged(sp, oracle_mod):
+    """Batched sweep with the queries' rows staged in LDS (groups of >= 5 queries on databases with >= 512 columns):
+    14 queries = one group of 8 (two row pairs in flight) + one of 6 (four in flight); byte-identical per query."""
+    cfg = {"n": 2, "nu_1": 4, "nu_2": 9, "p": 256, "q2_bits": 20, "t_gsw": 2, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 8192}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(21)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    item, db = o.generate_random_db_and_get_item(9)
+    gdb = sp.Database(p).load(db)
+    B = 14
+    qs = [cl.generate_query((523 * i + 9) % o.num_items, 300 + i) for i in range(B)]
+    resp = sp.process_query_batch(p, [gpp] * B, qs, gdb)
+    for i in (0, 3, 7, 8, 13):   # both groups, first and last slot of each
+        assert resp[i] == o.process_query(pp, qs[i], db), i
+    single = sp.process_query(p, gpp, qs[5], gdb)
+    assert resp[5] == single
+    for i in range(B):
+        assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
