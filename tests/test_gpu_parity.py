@@ -704,3 +704,45 @@ def test_process_query_batch_lds_staged(sp, oracle_mod):
     assert resp[5] == single
     for i in range(B):
         assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
+
+
+def _valid_cfg(c):
+    dim0, right = 1 << c["nu_1"], c["t_gsw"] * c["nu_2"]
+    g = max(1, int(np.ceil(np.log2(right + dim0))))
+    return 2 * max(dim0, right) <= (1 << g) and (c.get("version", 0) == 0 or c["n"] == 2)
+
+
+_FUZZ = [
+    # odd digit counts (one-transform fused kernel), 28-bit digits, 19-bit digits, small plaintext moduli,
+    # several instances, packing version 1, ragged item sizes, nu_2 from 1 to 7
+    dict(n=2, nu_1=6, nu_2=4, p=256, q2_bits=20, t_gsw=3, t_conv=4, t_exp_left=8, t_exp_right=56, instances=1, db_item_size=8192),
+    dict(n=2, nu_1=6, nu_2=5, p=256, q2_bits=22, t_gsw=5, t_conv=3, t_exp_left=5, t_exp_right=28, instances=1, db_item_size=5000),
+    dict(n=2, nu_1=5, nu_2=3, p=16, q2_bits=18, t_gsw=7, t_conv=2, t_exp_left=4, t_exp_right=14, instances=2, db_item_size=4096),
+    dict(n=2, nu_1=5, nu_2=6, p=256, q2_bits=20, t_gsw=2, t_conv=4, t_exp_left=8, t_exp_right=56, instances=1, db_item_size=3000),
+    dict(n=2, nu_1=6, nu_2=7, p=4, q2_bits=14, t_gsw=4, t_conv=7, t_exp_left=16, t_exp_right=8, instances=1, db_item_size=1024),
+    dict(n=2, nu_1=7, nu_2=2, p=256, q2_bits=27, t_gsw=10, t_conv=4, t_exp_left=8, t_exp_right=56, instances=3, db_item_size=20000),
+    dict(n=2, nu_1=6, nu_2=1, p=64, q2_bits=21, t_gsw=6, t_conv=5, t_exp_left=7, t_exp_right=9, instances=1, db_item_size=6000),
+    dict(n=2, nu_1=6, nu_2=4, p=256, q2_bits=20, t_gsw=8, t_conv=4, t_exp_left=8, t_exp_right=56, instances=2, db_item_size=16384, version=1),
+    dict(n=2, nu_1=5, nu_2=5, p=256, q2_bits=20, t_gsw=9, t_conv=4, t_exp_left=6, t_exp_right=19, instances=1, db_item_size=8192),
+    dict(n=2, nu_1=6, nu_2=3, p=256, q2_bits=20, t_gsw=14, t_conv=14, t_exp_left=14, t_exp_right=14, instances=1, db_item_size=8192),
+]
+
+
+@pytest.mark.parametrize("fused_min", ["1", "256"], ids=["fused-all-levels", "default-threshold"])
+@pytest.mark.parametrize("ci", range(len(_FUZZ)))
+def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min):
+    """End-to-end response bytes over a spread of gadget widths / moduli / shapes, with the fused fold kernels forced
+    onto every tree level and with the default level threshold."""
+    cfg = _FUZZ[ci]
+    assert _valid_cfg(cfg), cfg
+    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", fused_min)
+    o = oracle_mod.Params(cfg)
+    idx = (977 * (ci + 1)) % o.num_items
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(60 + ci)
+    q = cl.generate_query(idx, 160 + ci)
+    p = sp.Params(cfg)          # workspaces of this handle read the env at creation
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
