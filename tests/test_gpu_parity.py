@@ -499,15 +499,17 @@ def test_c2_full_size_sampled_parity(sp, oracle_mod):
     assert len(run.finish()) == p.get("response_bytes")
 
 
+@pytest.mark.parametrize("fused_min", ["256", "1"], ids=["default-threshold", "fused-all-levels"])
 @pytest.mark.parametrize("per_plane", [False, True], ids=["one-launch", "per-plane"])
 @pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4)],
                          ids=["narrow-G2", "narrow-G8", "packed-G4"])
-def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G, per_plane):
+def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg, G, per_plane, fused_min):
     """The N > 1 bench path (sweep_scatter -> reduce-scatter -> fold_local -> gather -> finish_gathered) with
     the G ranks played one after another on one GPU; the collective is replaced by a torch sum/slice.
     per-plane: the sweep one plane per launch (sp_query_sweep_scatter_plane), reduce-scattered plane by plane."""
     import torch
     from sdk_amd.sharding import local_cts_tensor, partial_tensor, scatter_layout_index, scatter_plane_layout_index
+    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", fused_min)   # the fused fold kernels in fold_local / finish_gathered too
     idx = 77
     o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
     p = sp.Params(cfg)
@@ -566,10 +568,12 @@ def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, cfg, G, per_plane
 @pytest.mark.parametrize("cfg,G,loader", [(dict(FAST56, nu_2=4), 4, "load"), (dict(FAST, nu_1=6, nu_2=8, db_item_size=256), 2, "items"),
                                           (dict(FAST, nu_1=6, nu_2=8, db_item_size=256), 8, "load")],
                          ids=["narrow-G4", "packed-G2-items", "narrow-from-packed-G8"])
-def test_column_sharded_single_gpu_emulation(sp, oracle_mod, cfg, G, loader):
+def test_column_sharded_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg, G, loader):
     """column shards (ii = g mod G), complete per-shard outputs, local fold, gather, final levels."""
     import torch
     from sdk_amd.sharding import local_cts_tensor
+    if loader == "items":
+        monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", "1")
     idx = 1234 % (1 << (cfg["nu_1"] + cfg["nu_2"]))
     o, cl, pp, q = _session(oracle_mod, cfg, idx, 55)
     p = sp.Params(cfg)
