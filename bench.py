@@ -178,7 +178,7 @@ def main():
         if args.batch > 1 and world == 1:
             outs = sp.process_query_batch(p, pp, [queries[(i + k) % len(queries)] for k in range(args.batch)], db)
             return outs[0], None
-        run = sp.QueryRun(p, pp, queries[i % len(queries)])
+        run = sp.QueryRun(p, pp, queries[i % len(queries)], db=db)  # row shards: expansion pruned to the shard's rows
         if mode == "columns":
             # column shards: complete outputs per shard, no partial sums; only the folded cts are gathered
             run.sweep(db)
@@ -235,7 +235,7 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
 
     # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
-    run = sp.QueryRun(p, pp, queries[0])
+    run = sp.QueryRun(p, pp, queries[0], db=db)
     if distributed_fold and overlap:                          # one launch per plane, exchange overlapped
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters, per_plane=1), cfg["instances"] * cfg["n"] ** 2
     else:                                                     # 1, or one per plane when the fold is overlapped

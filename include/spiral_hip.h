@@ -153,6 +153,12 @@ void* sp_query_local_cts_ptr(sp_query_t*);
 size_t sp_query_local_cts_words(const sp_query_t*);
 int sp_query_finish_gathered(sp_query_t*, const void* gathered_dev, int G, uint8_t* out, size_t out_cap, size_t* out_len);
 sp_query_t* sp_query_begin(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len);
+/* The same for a query that will sweep `db`: on a row shard only the first-dimension ciphertexts of the shard's
+ * rows are expanded (the even subtree of coefficient_expansion is pruned to their ancestors; server.rs:58-111 is
+ * otherwise unchanged, the GSW side is complete).  The sweep calls then insist on a database with those rows.
+ * db == NULL, unsharded or column-sharded: identical to sp_query_begin. */
+sp_query_t* sp_query_begin_for_db(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
+                                  const sp_db_t* db);
 int sp_query_sweep(sp_query_t*, const sp_db_t*);
 void* sp_query_partial_ptr(sp_query_t*);
 size_t sp_query_partial_words(const sp_query_t*);

@@ -39,6 +39,7 @@ struct sp_query {
   std::unique_ptr<Workspace> ws;
   int state = 0;  // 1 begun, 2 swept, 3 finished
   int next_plane = 0;  // sp_query_sweep_scatter_plane progress
+  int rows_j0 = 0, rows_nj = 0;  // sp_query_begin_for_db on a row shard: only these first-dimension rows were expanded
   float ms[4] = {0, 0, 0, 0};
   ~sp_query() {
     if (ws && params) {
@@ -458,20 +459,29 @@ int sp_pp_export(const sp_pp_t* pp, uint64_t* out, size_t cap_words, size_t* n_w
 
 // ------------------------------------------------------------------------------ process_query
 sp_query_t* sp_query_begin(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len) {
+  return sp_query_begin_for_db(h, pp, query, query_len, nullptr);
+}
+
+sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
+                                  const sp_db_t* db) {
   sp_query_t* out = nullptr;
   int rc = guarded([&] {
     need(h && pp && query, "null argument");
     need(pp->params == h, "public parameters were created for different params");
+    need(!db || db->params == h, "db was created for different params");
     check_device(pp->device);
+    const bool rows = db && db->num_shards > 1 && db->col_G == 1;
     auto q = std::make_unique<sp_query>();
     q->params = const_cast<sp_params*>(h);
     q->pp = pp;
     q->ws = q->params->acquire_ws();
     Workspace& W = *q->ws;
     HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
-    run_begin(W, *pp, query, query_len);
+    run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0);
     HIP_CHECK(hipEventRecord(W.ev[1], W.stream));
     q->state = 1;
+    q->rows_j0 = rows ? db->j0 : 0;
+    q->rows_nj = rows ? db->nj : 0;
     out = q.release();
   });
   return rc == SP_OK ? out : nullptr;
@@ -482,6 +492,8 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
     need(q && db, "null argument");
     need(q->state == 1, "sp_query_sweep: query not in 'begun' state");
     need(db->params == q->params, "db was created for different params");
+    need(q->rows_nj == 0 || (db->col_G == 1 && db->j0 == q->rows_j0 && db->nj == q->rows_nj),
+         "the query was expanded for another row shard (sp_query_begin_for_db)");
     check_device(db->device);
     Workspace& W = *q->ws;
     if (sweep_is_pipelined(q->params->p, *db))
@@ -498,6 +510,8 @@ int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
     need(q && db, "null argument");
     need(q->state == 1, "sp_query_sweep_scatter: query not in 'begun' state");
     need(db->params == q->params, "db was created for different params");
+    need(q->rows_nj == 0 || (db->col_G == 1 && db->j0 == q->rows_j0 && db->nj == q->rows_nj),
+         "the query was expanded for another row shard (sp_query_begin_for_db)");
     const Params& p = q->params->p;
     need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
          "G must be a power of two <= num_per and equal to the db's num_shards");
@@ -516,6 +530,8 @@ int sp_query_sweep_scatter_plane(sp_query_t* q, const sp_db_t* db, int G, int pl
   return guarded([&] {
     need(q && db, "null argument");
     need(db->params == q->params, "db was created for different params");
+    need(q->rows_nj == 0 || (db->col_G == 1 && db->j0 == q->rows_j0 && db->nj == q->rows_nj),
+         "the query was expanded for another row shard (sp_query_begin_for_db)");
     const Params& p = q->params->p;
     need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
          "G must be a power of two <= num_per and equal to the db's num_shards");

@@ -53,11 +53,12 @@ struct Workspace {
   size_t plane_group() const;
 };
 
-void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds);
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan = nullptr);
 void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
 void run_folding_neg(Workspace& W);
 void run_begin_direct(Workspace& W, const uint8_t* query);
-void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len);
+// j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0);
 void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);

@@ -54,6 +54,89 @@ void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
 }
 
 // ---------------------------------------------------------------------------------- device state
+// Expansion schedule (server.rs:19-121) restricted to the first-dimension rows [j0, j0 + nj): output ct c of round
+// r (index < 2^(r+1)) is an ancestor of leaf L iff L = c (mod 2^(r+1)); leaf 2j is row j (server.rs:566-568), the odd
+// leaves are the GSW selector bits and are always kept.  j0 = 0, nj = dim0 gives the reference's own schedule.
+static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj, std::vector<int>& L) {
+  auto put = [&](const std::vector<int>& v) {
+    size_t off = L.size();
+    L.insert(L.end(), v.begin(), v.end());
+    return off;
+  };
+  std::vector<RoundPlan> rounds;
+  const size_t g = P.g();
+  const size_t nu2 = P.db_dim_2;
+  const size_t stop_round = nu2 > 0 ? P.stop_round() : 0;
+  const size_t max_bits_right = nu2 > 0 ? P.t_gsw * nu2 : 0;
+  const bool prune = nu2 > 0 && (j0 != 0 || nj != (int)P.dim0());
+  for (size_t r = 0; r < g; r++) {
+    RoundPlan rp;
+    rp.num_in = 1 << r;
+    rp.t_auto = (int)(POLY_LEN >> r) + 1;
+    // even cts needed by the row range: c = 2j (mod 2^(r+1)) for some j in [j0, j0 + nj)
+    std::vector<char> need_even((size_t)2 << r, 1);
+    if (prune) {
+      std::fill(need_even.begin(), need_even.end(), 0);
+      const size_t mod = (size_t)2 << r;
+      if ((size_t)nj * 2 >= mod) {
+        std::fill(need_even.begin(), need_even.end(), 1);
+      } else {
+        for (int j = j0; j < j0 + nj; j++) need_even[((size_t)2 * j) % mod] = 1;
+      }
+    }
+    std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout, skip2;
+    for (int half = 0; half < 2; half++)
+      for (int i = 0; i < rp.num_in; i++) {  // both halves enumerate from 0 (server.rs:112-119)
+        bool skip = (stop_round > 0 && r > stop_round && (i % 2) == 1) ||
+                    (stop_round > 0 && r == stop_round && (i % 2) == 1 && (size_t)(i / 2) >= max_bits_right);
+        const int ct = half * rp.num_in + i;
+        if (skip) {
+          if (half == 1 && !prune) skip2.push_back(rp.num_in + i);
+          continue;
+        }
+        if (r != 0 && (i % 2) == 0 && !need_even[ct]) continue;
+        int pos = (int)all_ct.size();
+        all_ct.push_back(ct);
+        all_row1.push_back(ct * 2 + 1);
+        if (r != 0 && (i % 2) == 0) {
+          lpos.push_back(pos);
+          lout.push_back(ct * 2);
+        } else {
+          rpos.push_back(pos);
+          rout.push_back(ct * 2);
+        }
+      }
+    rp.n_all = (int)all_ct.size();
+    rp.n_left = (int)lpos.size();
+    rp.n_right = (int)rpos.size();
+    rp.all_ct = put(all_ct);
+    rp.all_row1 = put(all_row1);
+    rp.left_pos = put(lpos);
+    rp.left_out = put(lout);
+    rp.right_pos = put(rpos);
+    rp.right_out = put(rout);
+    rp.skip2 = put(skip2);
+    rp.n_skip2 = (int)skip2.size();
+    rounds.push_back(rp);
+  }
+  return rounds;
+}
+
+const DeviceState::PrunedPlan& DeviceState::pruned_plan(const Params& P, int j0, int nj) {
+  std::lock_guard<std::mutex> lk(pruned_mu);
+  for (auto& pp : pruned)
+    if (pp->j0 == j0 && pp->nj == nj) return *pp;
+  auto pl = std::make_unique<PrunedPlan>();
+  pl->j0 = j0;
+  pl->nj = nj;
+  std::vector<int> L;
+  pl->rounds = build_round_plans(P, j0, nj, L);
+  pl->lists.alloc(std::max<size_t>(L.size(), 1));
+  if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  pruned.push_back(std::move(pl));
+  return *pruned.back();
+}
+
 static std::unique_ptr<DeviceState> build_device_state(const Params& P, int device) {
   auto D = std::make_unique<DeviceState>();
   D->device = device;
@@ -101,48 +184,11 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
     return off;
   };
   if (P.expand_queries) {
-    const size_t stop_round = nu2 > 0 ? P.stop_round() : 0;
-    const size_t max_bits_right = nu2 > 0 ? P.t_gsw * nu2 : 0;
-    for (size_t r = 0; r < g; r++) {
-      RoundPlan rp;
-      rp.num_in = 1 << r;
-      rp.t_auto = (int)(POLY_LEN >> r) + 1;
-      std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout, skip2;
-      for (int half = 0; half < 2; half++)
-        for (int i = 0; i < rp.num_in; i++) {  // both halves enumerate from 0 (server.rs:112-119)
-          bool skip = (stop_round > 0 && r > stop_round && (i % 2) == 1) ||
-                      (stop_round > 0 && r == stop_round && (i % 2) == 1 && (size_t)(i / 2) >= max_bits_right);
-          if (skip) {
-            if (half == 1) skip2.push_back(rp.num_in + i);
-            continue;
-          }
-          int ct = half * rp.num_in + i;
-          int pos = (int)all_ct.size();
-          all_ct.push_back(ct);
-          all_row1.push_back(ct * 2 + 1);
-          if (r != 0 && (i % 2) == 0) {
-            lpos.push_back(pos);
-            lout.push_back(ct * 2);
-          } else {
-            rpos.push_back(pos);
-            rout.push_back(ct * 2);
-          }
-        }
-      rp.n_all = (int)all_ct.size();
-      rp.n_left = (int)lpos.size();
-      rp.n_right = (int)rpos.size();
-      rp.all_ct = put(all_ct);
-      rp.all_row1 = put(all_row1);
-      rp.left_pos = put(lpos);
-      rp.left_out = put(lout);
-      rp.right_pos = put(rpos);
-      rp.right_out = put(rout);
-      rp.skip2 = put(skip2);
-      rp.n_skip2 = (int)skip2.size();
+    D->rounds = build_round_plans(P, 0, (int)P.dim0(), L);
+    for (const RoundPlan& rp : D->rounds) {
       D->max_all = std::max(D->max_all, (size_t)rp.n_all);
       D->max_left = std::max(D->max_left, (size_t)rp.n_left);
       D->max_right = std::max(D->max_right, (size_t)rp.n_right);
-      D->rounds.push_back(rp);
     }
   }
   {
@@ -322,14 +368,15 @@ void Workspace::ensure_finish() {
 
 // ---------------------------------------------------------------------------------- pipeline stages
 // server.rs:19-121; v[0] holds the NTT'd query ct.
-void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds) {
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
-  const int* L = D.lists.p;
+  const int* L = plan ? plan->lists.p : D.lists.p;
+  const std::vector<RoundPlan>& rounds = plan ? plan->rounds : D.rounds;
   const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
   for (size_t r = 0; r < g_rounds; r++) {
-    const RoundPlan& rp = D.rounds[r];
+    const RoundPlan& rp = rounds[r];
     // three launches per round:
     // (1) v[num_in + i] = neg1[r] * v[i] (server.rs:105-110) fused into ct = from_ntt(v_i); ct_auto = automorph(ct, t)
     InvDesc inv{};
@@ -515,7 +562,7 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
 }
 
 // Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
-void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len) {
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0, int nj) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
@@ -534,7 +581,9 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};  // v[0] = query.ct.ntt()  (server.rs:545)
   launch_ntt_fwd(D.T, f, s);
   const size_t g = p.g();
-  run_coefficient_expansion(W, pp, g);
+  // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
+  const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
+  run_coefficient_expansion(W, pp, g, prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
   if (p.db_dim_2 > 0) {
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)

@@ -89,6 +89,16 @@ struct DeviceState {
   DevBuf<int> lists;
   std::vector<RoundPlan> rounds;
   size_t max_all = 0, max_left = 0, max_right = 0;
+  // Expansion schedules pruned to the first-dimension rows [j0, j0 + nj) a row shard needs (the even "left" subtree
+  // only computes the ancestors of those leaves; the GSW side is always complete).  Built on first use.
+  struct PrunedPlan {
+    int j0 = 0, nj = 0;
+    std::vector<RoundPlan> rounds;  // offsets into `lists` below
+    DevBuf<int> lists;
+  };
+  std::vector<std::unique_ptr<PrunedPlan>> pruned;
+  std::mutex pruned_mu;
+  const PrunedPlan& pruned_plan(const Params& P, int j0, int nj);
   // regev_to_gsw lists (batch b = d*t_gsw + j)
   size_t gsw_src_ct = 0;     // ct index 2b+1 (or b when nu_2 == 0: unused)
   size_t gsw_src_poly = 0;   // poly index (2b+1)*2

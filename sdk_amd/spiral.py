@@ -418,11 +418,15 @@ def synth_words(seed, ref_indices):
 class QueryRun:
     """One in-flight query split around the exchange step (see include/spiral_hip.h)."""
 
-    def __init__(self, params, pp, query):
+    def __init__(self, params, pp, query, db=None):
+        """db: the database this query will sweep; on a row shard the expansion is pruned to the shard's rows"""
         q = query.data if isinstance(query, Query) else bytes(query)
         d = _bytes(q)
         self.params, self.pp = params, pp
-        self.h = lib().sp_query_begin(_vp(params.h), _vp(pp.h), _p(d, u8p), C.c_size_t(d.size))
+        L = lib()
+        L.sp_query_begin_for_db.restype = C.c_void_p
+        self.h = L.sp_query_begin_for_db(_vp(params.h), _vp(pp.h), _p(d, u8p), C.c_size_t(d.size),
+                                         _vp(db.h) if db is not None else None)
         if not self.h:
             raise SpiralError(_err())
 

@@ -519,9 +519,12 @@ def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg,
     shards = [sp.Database(p, s, G).load(db) for s in range(G)]
     planes = 4
     if per_plane:
-        runs = [sp.QueryRun(p, gpp, q) for s in range(G)]
+        # begun for their shard: only the shard's first-dimension rows of the query are expanded
+        runs = [sp.QueryRun(p, gpp, q, db=shards[s]) for s in range(G)]
         with pytest.raises(sp.SpiralError):
             runs[0].sweep_scatter_plane(shards[0], G, 1)       # planes go in order
+        with pytest.raises(sp.SpiralError):
+            runs[0].sweep_scatter_plane(shards[1], G, 0)       # expanded for shard 0's rows only
         for s in range(G):
             for pl in range(planes):
                 runs[s].sweep_scatter_plane(shards[s], G, pl)
@@ -644,7 +647,7 @@ def test_row_sharded_partials_sum_to_full(sp, oracle_mod):
     expect = o.process_query(pp, q, db)
     for G in (2, 4, 8):
         shards = [sp.Database(p, s, G).load(db) for s in range(G)]
-        runs = [sp.QueryRun(p, gpp, q).sweep(shards[s]) for s in range(G)]
+        runs = [sp.QueryRun(p, gpp, q, db=shards[s] if G != 4 else None).sweep(shards[s]) for s in range(G)]
         total = None
         for r in runs:
             r.sync()
