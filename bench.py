@@ -148,7 +148,12 @@ def main():
         raise SystemExit("sp_set_device failed")
     # SPIRAL_FORCE_DIST=1: run the N > 1 code path (process group, collectives) at world size 1 (1-GPU boxes)
     use_dist = world > 1 or os.environ.get("SPIRAL_FORCE_DIST") == "1"
+    real_stdout = None
     if use_dist:
+        # RCCL prints a version banner through C stdio on stdout; keep stdout for the one JSON line
+        sys.stdout.flush()
+        real_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -281,7 +286,13 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         else:
             line["cpu_baseline"] = None
+        if real_stdout is not None:
+            C.CDLL(None).fflush(None)
+            sys.stdout.flush()
+            os.dup2(real_stdout, 1)
         print(json.dumps(line), flush=True)
+        if real_stdout is not None:
+            os.dup2(2, 1)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

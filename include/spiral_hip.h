@@ -149,6 +149,13 @@ int sp_query_sweep_scatter(sp_query_t*, const sp_db_t*, int G);
  * the concatenation of the received chunks is the [plane][r][crt][z][ii / G] buffer sp_query_fold_local takes. */
 int sp_query_sweep_scatter_plane(sp_query_t*, const sp_db_t*, int G, int plane);
 int sp_query_fold_local(sp_query_t*, const void* reduced_chunk_dev, int G);
+/* The local fold one plane at a time on the query's SECOND stream (sp_query_stream2), planes in order: plane p may
+ * be folded as soon as it has been swept and its reduced chunk ([r][crt][z][ii / G]) is complete — the caller orders
+ * stream2 after that exchange — so the fold of plane p runs beside the sweep / exchange of the later planes.
+ * sp_query_fold_local_join() orders the main stream after all of them (replaces sp_query_fold_local). */
+int sp_query_fold_local_plane(sp_query_t*, const void* reduced_plane_chunk_dev, int G, int plane);
+int sp_query_fold_local_join(sp_query_t*);
+void* sp_query_stream2(sp_query_t*);
 void* sp_query_local_cts_ptr(sp_query_t*);
 size_t sp_query_local_cts_words(const sp_query_t*);
 int sp_query_finish_gathered(sp_query_t*, const void* gathered_dev, int G, uint8_t* out, size_t out_cap, size_t* out_len);

@@ -39,6 +39,7 @@ struct sp_query {
   std::unique_ptr<Workspace> ws;
   int state = 0;  // 1 begun, 2 swept, 3 finished
   int next_plane = 0;  // sp_query_sweep_scatter_plane progress
+  int next_fold_plane = 0;  // sp_query_fold_local_plane progress
   int rows_j0 = 0, rows_nj = 0;  // sp_query_begin_for_db on a row shard: only these first-dimension rows were expanded
   float ms[4] = {0, 0, 0, 0};
   ~sp_query() {
@@ -567,6 +568,32 @@ int sp_query_fold_local(sp_query_t* q, const void* reduced_chunk, int G) {
     q->state = 4;
   });
 }
+int sp_query_fold_local_plane(sp_query_t* q, const void* reduced_plane_chunk, int G, int plane) {
+  return guarded([&] {
+    need(q && reduced_plane_chunk, "null argument");
+    const Params& p = q->params->p;
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per(), "bad G");
+    need(plane >= 0 && (size_t)plane < p.planes(), "plane out of range");
+    // plane `plane` must have been swept (its exchange is the caller's to order on sp_query_stream2)
+    need((q->state == 1 && plane < q->next_plane) || q->state == 2, "sp_query_fold_local_plane: plane has not been swept");
+    need(plane == q->next_fold_plane, "sp_query_fold_local_plane: planes must be folded in order");
+    run_fold_local_plane(*q->ws, (const u32*)reduced_plane_chunk, G, plane);
+    q->next_fold_plane = plane + 1;
+  });
+}
+
+int sp_query_fold_local_join(sp_query_t* q) {
+  return guarded([&] {
+    need(q, "null argument");
+    need(q->state == 2 && (size_t)q->next_fold_plane == q->params->p.planes(),
+         "sp_query_fold_local_join: every plane must have been swept and folded");
+    run_fold_local_join(*q->ws);
+    q->state = 4;
+  });
+}
+
+void* sp_query_stream2(sp_query_t* q) { return q && q->ws ? (void*)q->ws->stream2 : nullptr; }
+
 void* sp_query_local_cts_ptr(sp_query_t* q) { return q && q->ws ? (void*)q->ws->final_cts.p : nullptr; }
 size_t sp_query_local_cts_words(const sp_query_t* q) { return q ? q->params->p.planes() * 2 * POLY_LEN : 0; }
 

@@ -66,6 +66,8 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
 bool fused_fold_supported(const Params& p);
 u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
+void run_fold_local_plane(Workspace& W, const u32* reduced_plane_chunk, int G, int plane);
+void run_fold_local_join(Workspace& W);
 void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int G);
 void run_fold_all(Workspace& W, bool premod);
 void run_pack(Workspace& W, const sp_pp& pp);

@@ -956,29 +956,54 @@ size_t encode_response(const Params& p, const u64* packed, uint8_t* out) {
 // ---- distributed fold (multi-GPU reduce-scatter path) ------------------------------------------------
 // This rank's reduced chunk holds columns ii = g + G*i (i < num_per/G) of every plane:
 // [plane][r][crt][z][i].  Folding them uses the top nu_2 - log2(G) selector bits.
-void run_fold_local(Workspace& W, const u32* reduced_chunk, int G) {
+// % q, from_ntt and the local fold levels of planes [pg0, pg0 + np) of a reduced chunk ([plane][r][crt][z][npl],
+// `chunk` points at plane pg0) on W.stream
+static void fold_local_planes(Workspace& W, const u32* chunk, int G, size_t pg0, int np) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
+  const int npl = (int)p.num_per() / G;
+  if (npl % 4 == 0) {
+    launch_from_sweep4(D.T, chunk, npl, np, 1, W.foldX.p, s);
+  } else {
+    InvDesc inv{};
+    inv.src = chunk;
+    inv.sweep_np = npl;
+    inv.dst = W.foldX.p;
+    inv.n_polys = np * npl * 2;
+    inv.premod = 1;
+    launch_ntt_inv(D.T, inv, s);
+  }
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+}
+
+void run_fold_local(Workspace& W, const u32* reduced_chunk, int G) {
+  const Params& p = *W.P;
   W.ensure_finish();
   const int npl = (int)p.num_per() / G;
   const size_t pg = W.plane_group();
-  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) {
-    const int np = (int)std::min(pg, p.planes() - pg0);
-    if (npl % 4 == 0) {
-      launch_from_sweep4(D.T, reduced_chunk + pg0 * 4 * POLY_LEN * npl, npl, np, 1, W.foldX.p, s);
-    } else {
-      InvDesc inv{};
-      inv.src = reduced_chunk + pg0 * 4 * POLY_LEN * npl;
-      inv.sweep_np = npl;
-      inv.dst = W.foldX.p;
-      inv.n_polys = np * npl * 2;
-      inv.premod = 1;
-      launch_ntt_inv(D.T, inv, s);
-    }
-    u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
-    HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
+  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg)
+    fold_local_planes(W, reduced_chunk + pg0 * 4 * POLY_LEN * npl, G, pg0, (int)std::min(pg, p.planes() - pg0));
+}
+
+// One plane of the local fold on the SECOND stream (the caller has ordered stream2 after the plane's exchange):
+// runs beside the sweeps / exchanges of the later planes.  run_fold_local_join orders the main stream after them.
+void run_fold_local_plane(Workspace& W, const u32* reduced_plane_chunk, int G, int plane) {
+  W.ensure_finish();
+  std::swap(W.stream, W.stream2);
+  try {
+    fold_local_planes(W, reduced_plane_chunk, G, (size_t)plane, 1);
+  } catch (...) {
+    std::swap(W.stream, W.stream2);
+    throw;
   }
+  std::swap(W.stream, W.stream2);
+}
+
+void run_fold_local_join(Workspace& W) {
+  HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
+  HIP_CHECK(hipStreamWaitEvent(W.stream, W.ev_fold, 0));
 }
 
 // gathered: [G][planes][2][N] raw cts (rank g's local results).  Leaf g of the remaining tree is rank g.

@@ -78,9 +78,9 @@ def scatter_fold_query(run, db, rank, world, overlap=True):
     rank 0 folds the last log2(world) levels, packs and encodes.  Returns the response bytes on rank 0, None
     elsewhere.
 
-    overlap=True: everything is ordered on the query's HIP stream (no host synchronisation until the response
-    is copied out); the database is swept one plane per launch and the reduce-scatter of plane p (RCCL's own
-    stream) runs while plane p+1 is swept.  overlap=False: one sweep launch, one reduce-scatter, host
+    overlap=True: everything is ordered on the query's two HIP streams (no host synchronisation until the
+    response is copied out); the database is swept one plane per launch, the reduce-scatter of plane p (RCCL's own
+    stream) and then its local fold (second stream) run while the later planes are swept.  overlap=False: one sweep launch, one reduce-scatter, host
     synchronisation between the steps (the reference implementation of the same data flow)."""
     import torch
     import torch.distributed as dist
@@ -99,20 +99,27 @@ def scatter_fold_query(run, db, rank, world, overlap=True):
     pw = part.numel() // planes
     chunk = pw // world
     nccl = dist.get_backend() == "nccl"
-    with torch.cuda.stream(torch.cuda.ExternalStream(run.stream())):
+    main, second = torch.cuda.ExternalStream(run.stream()), torch.cuda.ExternalStream(run.stream2())
+    with torch.cuda.stream(main):
         mine = torch.empty(planes * chunk, dtype=part.dtype, device=part.device)
-        works = []
-        for pl in range(planes):
+    for pl in range(planes):
+        src, dst = part[pl * pw:(pl + 1) * pw], mine[pl * chunk:(pl + 1) * chunk]
+        with torch.cuda.stream(main):
             run.sweep_scatter_plane(db, world, pl)
-            src, dst = part[pl * pw:(pl + 1) * pw], mine[pl * chunk:(pl + 1) * chunk]
-            if nccl:
-                works.append(dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, async_op=True))
+            if nccl:   # RCCL's stream waits for the sweep of this plane, not for the later ones
+                work = dist.reduce_scatter_tensor(dst, src, op=dist.ReduceOp.SUM, async_op=True)
             else:
                 dist.all_reduce(src, op=dist.ReduceOp.SUM)
                 dst.copy_(src[rank * chunk:(rank + 1) * chunk])
-        for w in works:
-            w.wait()  # stream-level: the query stream waits for the collective, the host does not
-        run.fold_local(mine.data_ptr(), world)
+                work = None
+        with torch.cuda.stream(second):
+            if work is not None:
+                work.wait()            # stream-level: the second stream waits for this plane's exchange
+            else:
+                second.wait_stream(main)
+        run.fold_local_plane(dst.data_ptr(), world, pl)   # second stream, beside the later planes' sweeps
+    run.fold_local_join()
+    with torch.cuda.stream(main):
         local = local_cts_tensor(run)
         gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)
         if nccl:

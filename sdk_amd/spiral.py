@@ -459,6 +459,18 @@ class QueryRun:
         _chk(lib().sp_query_fold_local(_vp(self.h), C.c_void_p(reduced_chunk_ptr), C.c_int(G)))
         return self
 
+    def fold_local_plane(self, reduced_plane_chunk_ptr, G, plane):
+        _chk(lib().sp_query_fold_local_plane(_vp(self.h), C.c_void_p(reduced_plane_chunk_ptr), C.c_int(G), C.c_int(plane)))
+        return self
+
+    def fold_local_join(self):
+        _chk(lib().sp_query_fold_local_join(_vp(self.h)))
+        return self
+
+    def stream2(self):
+        lib().sp_query_stream2.restype = C.c_void_p
+        return int(lib().sp_query_stream2(_vp(self.h)) or 0)
+
     def local_cts_ptr(self):
         lib().sp_query_local_cts_ptr.restype = C.c_void_p
         return int(lib().sp_query_local_cts_ptr(_vp(self.h)))

@@ -558,7 +558,14 @@ def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg,
         else:
             mine = total[g * chunk:(g + 1) * chunk].contiguous()
         torch.cuda.synchronize()
-        r.fold_local(mine.data_ptr(), G)
+        if per_plane:   # one plane at a time on the second stream, then the join (what the overlapped flow issues)
+            with pytest.raises(sp.SpiralError):
+                r.fold_local_plane(mine.data_ptr(), G, 1)    # planes go in order
+            for pl in range(planes):
+                r.fold_local_plane(mine[pl * pc:].data_ptr(), G, pl)
+            r.fold_local_join()
+        else:
+            r.fold_local(mine.data_ptr(), G)
         r.sync()
         locals_.append(local_cts_tensor(r).clone())
     gathered = torch.cat(locals_).contiguous()
