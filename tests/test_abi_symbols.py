@@ -67,3 +67,23 @@ def test_compute_fails_loudly_without_gpu():
         sp.to_ntt(p, np.zeros(2048, dtype=np.uint64))
     with pytest.raises(sp.SpiralError):
         sp.Database(p)
+
+
+def test_params_validation_rejects_what_the_reference_cannot_run():
+    """Params are validated on the host: a configuration the reference would index out of bounds with
+    (coefficient_expansion writes 2*max(dim0, t_gsw*nu_2) ciphertexts into a 2^g vector, server.rs:525-591),
+    unknown packing versions and version 1 with n != 2 (lib/server pack.rs:46-99) are errors, not crashes."""
+    import sdk_amd as sp
+    from conftest import FAST
+    ok = dict(FAST)
+    sp.Params(ok)
+    for bad in (dict(FAST, nu_1=3, nu_2=7, t_gsw=8),      # 2*56 > 2^g = 64
+                dict(FAST, version=2),
+                dict(FAST, version=1, n=3),
+                dict(FAST, nu_1=0, nu_2=0, t_gsw=8)):
+        try:
+            sp.Params(bad)
+        except sp.SpiralError:
+            continue
+        # nu_1 = 0 is legal if the reference accepts it; only the first three must raise
+        assert bad.get("nu_1") == 0, bad
