@@ -610,11 +610,18 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // from_ntt of four adjacent sweep-output columns per workgroup.  grid (np/4 * 2 * planes)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst) {
+__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map) {
   __shared__ u32 lds0[4 * LDS_WORDS];
   __shared__ u32 lds1[4 * LDS_WORDS];
   const int tau = threadIdx.x;
-  const int g = blockIdx.x;              // (plane, r, ii/4)
+  int g = blockIdx.x;                    // (plane, r, ii/4)
+  // The 8 column groups that share one 128-byte line of the [z][ii] source should go through ONE XCD's L2, back
+  // to back (workgroups are dealt to the 8 XCDs round-robin): block b -> XCD b % 8 handles line (b/64)*8 + b%8,
+  // group (b/8) % 8 of that line.  Otherwise every line is fetched from HBM by up to 8 L2s.
+  if (xcd_map) {
+    const int xcd = g & 7, t = g >> 3;
+    g = ((t >> 3) * 8 + xcd) * 8 + (t & 7);
+  }
   const int groups_per_plane = (np / 4) * 2;
   const int plane = g / groups_per_plane, rem = g % groups_per_plane;
   const int r = rem / (np / 4), ii0 = (rem % (np / 4)) * 4;
@@ -662,7 +669,10 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
 }
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
-  hipLaunchKernelGGL(k_from_sweep4, dim3((unsigned)((np / 4) * 2 * n_planes)), dim3(256), 0, s, T, src, np, premod, dst);
+  const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
+  static const int want = [] { const char* e = getenv("SPIRAL_FROM_SWEEP_XCD"); return e ? atoi(e) : 1; }();
+  const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
+  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
 }
 
 // ------------------------------------------------------------------------------------------------
