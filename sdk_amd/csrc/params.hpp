@@ -3,6 +3,9 @@
 // derived sizes -- but carries the tables in the form the HIP kernels consume (u32 twiddles,
 // Shoup quotients, Barrett/Garner constants).
 #pragma once
+// The wire formats are the reference's to_ne_bytes / from_ne_bytes images (client.rs:58,77,292; util.rs:294-319;
+// server.rs:369), i.e. little-endian on the x86-64 hosts both run on.
+static_assert(__BYTE_ORDER__ == __ORDER_LITTLE_ENDIAN__, "spiral_hip assumes a little-endian host");
 #include <cstddef>
 #include <cstdint>
 #include <string>
