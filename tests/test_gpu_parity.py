@@ -739,6 +739,12 @@ _FUZZ = [
     dict(n=2, nu_1=6, nu_2=4, p=256, q2_bits=20, t_gsw=8, t_conv=4, t_exp_left=8, t_exp_right=56, instances=2, db_item_size=16384, version=1),
     dict(n=2, nu_1=5, nu_2=5, p=256, q2_bits=20, t_gsw=9, t_conv=4, t_exp_left=6, t_exp_right=19, instances=1, db_item_size=8192),
     dict(n=2, nu_1=6, nu_2=3, p=256, q2_bits=20, t_gsw=14, t_conv=14, t_exp_left=14, t_exp_right=14, instances=1, db_item_size=8192),
+    # extreme gadgets: one 57-bit digit (no fused fold), 28-bit digits everywhere (digits can exceed q), t_conv = 1,
+    # 2-bit digits (t = 28)
+    dict(n=2, nu_1=5, nu_2=3, p=256, q2_bits=20, t_gsw=1, t_conv=4, t_exp_left=8, t_exp_right=56, instances=1, db_item_size=8192),
+    dict(n=2, nu_1=5, nu_2=4, p=256, q2_bits=20, t_gsw=4, t_conv=2, t_exp_left=2, t_exp_right=2, instances=1, db_item_size=8192),
+    dict(n=2, nu_1=4, nu_2=5, p=256, q2_bits=20, t_gsw=2, t_conv=1, t_exp_left=3, t_exp_right=4, instances=1, db_item_size=2048),
+    dict(n=2, nu_1=6, nu_2=4, p=256, q2_bits=20, t_gsw=28, t_conv=28, t_exp_left=28, t_exp_right=56, instances=1, db_item_size=8192),
 ]
 
 
