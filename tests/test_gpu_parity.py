@@ -501,8 +501,9 @@ def test_c2_full_size_sampled_parity(sp, oracle_mod):
 
 @pytest.mark.parametrize("fused_min", ["256", "1"], ids=["default-threshold", "fused-all-levels"])
 @pytest.mark.parametrize("per_plane", [False, True], ids=["one-launch", "per-plane"])
-@pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4)],
-                         ids=["narrow-G2", "narrow-G8", "packed-G4"])
+@pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4),
+                                   (dict(FAST56, nu_2=5, t_gsw=3, t_conv=3, t_exp_left=5), 4)],
+                         ids=["narrow-G2", "narrow-G8", "packed-G4", "odd-gadgets-G4"])
 def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg, G, per_plane, fused_min):
     """The N > 1 bench path (sweep_scatter -> reduce-scatter -> fold_local -> gather -> finish_gathered) with
     the G ranks played one after another on one GPU; the collective is replaced by a torch sum/slice.
@@ -572,7 +573,8 @@ def test_distributed_fold_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg,
     torch.cuda.synchronize()
     resp = runs[0].finish_gathered(gathered.data_ptr(), G)
     assert resp == expect
-    assert cl.decode_response(resp) == o.item_to_vec(item)
+    if cfg["t_gsw"] >= 8:   # the narrow test gadgets are too noisy to decode; byte parity is the claim there
+        assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
 @pytest.mark.parametrize("cfg,G,loader", [(dict(FAST56, nu_2=4), 4, "load"), (dict(FAST, nu_1=6, nu_2=8, db_item_size=256), 2, "items"),
