@@ -679,6 +679,19 @@ def test_rccl_world1_paths():
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+def test_overlapped_fold_direct_upload_parity(sp, oracle_mod):
+    """Non-expanded ('direct_upload') query on a wide packed database: the overlapped per-plane path with the
+    fold matrices coming straight from the wire (server.rs:666-679) instead of regev_to_gsw."""
+    cfg = {"n": 2, "nu_1": 4, "nu_2": 10, "p": 256, "q2_bits": 20, "t_gsw": 2, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 8192, "direct_upload": 1}
+    o, cl, pp, q = _session(oracle_mod, cfg, 1234, 6)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(1234)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
+
+
 def test_overlapped_fold_many_planes_parity(sp, oracle_mod):
     """The default path of wide packed databases (one sweep launch per plane, from_ntt + fold of plane p on the
     second stream under the sweep of plane p+1) with 8 planes (instances = 2), byte-identical to the oracle.
