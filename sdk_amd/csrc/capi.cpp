@@ -621,7 +621,12 @@ int sp_query_finish_gathered(sp_query_t* q, const void* gathered, int G, uint8_t
   });
 }
 
-void* sp_query_partial_ptr(sp_query_t* q) { return q && q->ws ? (void*)q->ws->sweep_out.p : nullptr; }
+void* sp_query_partial_ptr(sp_query_t* q) {
+  if (!q || !q->ws) return nullptr;
+  // valid before the first sweep too (callers set up their exchange buffers up front)
+  if (guarded([&] { q->ws->ensure_sweep(); }) != SP_OK) return nullptr;
+  return (void*)q->ws->sweep_out.p;
+}
 size_t sp_query_partial_words(const sp_query_t* q) {
   if (!q) return 0;
   const Params& p = q->params->p;

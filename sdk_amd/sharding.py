@@ -71,16 +71,20 @@ def gather_local(local, rank, world, dst=0):
     return out if rank == dst else None
 
 
-def scatter_fold_query(run, db, rank, world, overlap=True):
+def scatter_fold_query(run, db, rank, world, overlap=True, fold_per_plane=False):
     """The N > 1 answer path after sp_query_begin, rank-local view (north star): row-sharded
     sweep -> RCCL reduce-scatter of the partial Regev ciphertexts over the column axis -> every rank folds its
     columns with the top nu_2 - log2(world) selector bits -> all-gather of one ciphertext per plane per rank ->
     rank 0 folds the last log2(world) levels, packs and encodes.  Returns the response bytes on rank 0, None
     elsewhere.
 
-    overlap=True: everything is ordered on the query's two HIP streams (no host synchronisation until the
-    response is copied out); the database is swept one plane per launch, the reduce-scatter of plane p (RCCL's own
-    stream) and then its local fold (second stream) run while the later planes are swept.  overlap=False: one sweep launch, one reduce-scatter, host
+    overlap=True: everything is ordered on the query's HIP streams (no host synchronisation until the response
+    is copied out); the database is swept one plane per launch and the reduce-scatter of plane p (RCCL's own
+    stream) runs while the later planes are swept; then one local fold over all planes.
+    fold_per_plane=True additionally folds plane p on the second stream as soon as its exchange is done.  Measured
+    with the exchange replaced by a local copy (scripts/rank_emulation.py flow, C2): the per-plane fold chains are
+    latency-bound and serialise, 3.22 vs 2.64 ms per query at 8 shards, 4.51 vs 4.11 at 4, 7.08 vs 6.97 at 2 —
+    hence off by default.  overlap=False: one sweep launch, one reduce-scatter, host
     synchronisation between the steps (the reference implementation of the same data flow)."""
     import torch
     import torch.distributed as dist
@@ -102,6 +106,7 @@ def scatter_fold_query(run, db, rank, world, overlap=True):
     main, second = torch.cuda.ExternalStream(run.stream()), torch.cuda.ExternalStream(run.stream2())
     with torch.cuda.stream(main):
         mine = torch.empty(planes * chunk, dtype=part.dtype, device=part.device)
+    works = []
     for pl in range(planes):
         src, dst = part[pl * pw:(pl + 1) * pw], mine[pl * chunk:(pl + 1) * chunk]
         with torch.cuda.stream(main):
@@ -112,13 +117,22 @@ def scatter_fold_query(run, db, rank, world, overlap=True):
                 dist.all_reduce(src, op=dist.ReduceOp.SUM)
                 dst.copy_(src[rank * chunk:(rank + 1) * chunk])
                 work = None
-        with torch.cuda.stream(second):
-            if work is not None:
-                work.wait()            # stream-level: the second stream waits for this plane's exchange
-            else:
-                second.wait_stream(main)
-        run.fold_local_plane(dst.data_ptr(), world, pl)   # second stream, beside the later planes' sweeps
-    run.fold_local_join()
+        if fold_per_plane:
+            with torch.cuda.stream(second):
+                if work is not None:
+                    work.wait()        # stream-level: the second stream waits for this plane's exchange
+                else:
+                    second.wait_stream(main)
+            run.fold_local_plane(dst.data_ptr(), world, pl)   # second stream, beside the later planes' sweeps
+        elif work is not None:
+            works.append(work)
+    if fold_per_plane:
+        run.fold_local_join()
+    else:
+        with torch.cuda.stream(main):
+            for w in works:
+                w.wait()               # stream-level: the query stream waits for the exchanges, the host does not
+        run.fold_local(mine.data_ptr(), world)
     with torch.cuda.stream(main):
         local = local_cts_tensor(run)
         gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=local.device)

@@ -491,7 +491,10 @@ class QueryRun:
         _chk(lib().sp_query_sync(_vp(self.h)))
 
     def partial_ptr(self):
-        return int(lib().sp_query_partial_ptr(_vp(self.h)))
+        ptr = lib().sp_query_partial_ptr(_vp(self.h))
+        if not ptr:
+            raise SpiralError(_err() or "no partial buffer")
+        return int(ptr)
 
     def partial_words(self):
         return int(lib().sp_query_partial_words(_vp(self.h)))

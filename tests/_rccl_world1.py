@@ -51,9 +51,10 @@ def main():
 
     # the same path as bench.py drives it: stream-ordered with per-plane async reduce-scatter, and host-synchronised
     from sdk_amd.sharding import scatter_fold_query
-    for overlap in (True, False, True):
-        run = sp.QueryRun(p, gpp, q)
-        assert scatter_fold_query(run, gdb, rank, world, overlap=overlap) == expect, "scatter_fold_query overlap=%s" % overlap
+    for overlap, per_plane in ((True, False), (False, False), (True, True), (True, False)):
+        run = sp.QueryRun(p, gpp, q, db=gdb)
+        assert scatter_fold_query(run, gdb, rank, world, overlap=overlap, fold_per_plane=per_plane) == expect, \
+            "scatter_fold_query overlap=%s fold_per_plane=%s" % (overlap, per_plane)
         run.free()
 
     # reduce: sweep -> dist.reduce -> finish
