@@ -1,0 +1,398 @@
+// Device-side helpers shared by the kernel translation units: modular arithmetic, the 2048-point negacyclic NTT
+// core (register passes + LDS exchanges) and the lane <-> limb mapping of the 7-byte PACKED database format.
+#pragma once
+#include "kernels.hpp"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace spiral {
+
+// ------------------------------------------------------------------------------------------------
+// modular helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 reduce64(u64 x, const ModConst m) {
+  // x mod q for any u64 x:  floor(x * floor(2^64/q) / 2^64) is floor(x/q) or one less
+  u64 qe = __umul64hi(x, m.m64);
+  u64 r = x - qe * (u64)m.q;
+  u32 r32 = (u32)r;  // r < 2q < 2^29
+  return r32 >= m.q ? r32 - m.q : r32;
+}
+
+__device__ __forceinline__ u32 add_mod(u32 a, u32 b, u32 q) {
+  u32 s = a + b;
+  return s >= q ? s - q : s;
+}
+
+// Cooley-Tukey butterfly with Shoup quotient (ntt.rs:92-103): x,y in [0,4q) -> [0,4q)
+__device__ __forceinline__ void ct_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u32 q2) {
+  u32 cx = x - (x >= q2 ? q2 : 0u);
+  u32 qt = __umulhi(y, wp);
+  u32 qn = w * y - qt * q;
+  x = cx + qn;
+  y = cx + q2 - qn;
+}
+// Gentleman-Sande butterfly with the 1/2 folded in (ntt.rs:236-249): x,y in [0,2q) -> [0,2q)
+__device__ __forceinline__ void gs_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u32 q2) {
+  u32 tt = q2 - y + x;
+  u32 s = x + y;
+  u32 cx = s - (s >= q2 ? q2 : 0u);
+  u32 ht = __umulhi(tt, wp);
+  x = (cx + ((tt & 1u) ? q : 0u)) >> 1;
+  y = w * tt - ht * q;
+}
+
+// LDS index padding.  PAD_A keeps the {tau+256k}, {256b+o+32k} and {32b+o+4k} access patterns
+// conflict-free for 4-byte accesses; PAD_B does the same for {32b+o+4k} and {8tau+k}.
+#define PAD_A(a) ((a) + (((a) >> 5) << 2))
+#define PAD_B(a) ((a) + ((a) >> 3))
+constexpr int LDS_WORDS = N + N / 8;  // >= max(PAD_A, PAD_B)
+
+// One register pass of the forward transform on the 8 elements {b*8S + o + S*k}: half-distances
+// 4S, 2S, S (stage A is skipped for the final S = 1 pass, where only distances 2 and 1 remain).
+template <int S, bool DO_A>
+__device__ __forceinline__ void fwd_pass(u32 (&v)[8], int b, const u32* __restrict__ fw, const u32* __restrict__ fwp,
+                                         u32 q, u32 q2) {
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) ct_bfly(v[k], v[k + 4], w, wp, q, q2);
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int i = N / (4 * S) + 2 * b + h;
+      u32 w = fw[i], wp = fwp[i];
+      ct_bfly(v[4 * h + 0], v[4 * h + 2], w, wp, q, q2);
+      ct_bfly(v[4 * h + 1], v[4 * h + 3], w, wp, q, q2);
+    }
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      int i = N / (2 * S) + 4 * b + h;
+      ct_bfly(v[2 * h], v[2 * h + 1], fw[i], fwp[i], q, q2);
+    }
+  }
+}
+// Inverse: half-distances S, 2S, 4S on the same element set.
+template <int S, bool DO_A>
+__device__ __forceinline__ void inv_pass(u32 (&v)[8], int b, const u32* __restrict__ iw, const u32* __restrict__ iwp,
+                                         u32 q, u32 q2) {
+  {
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      int i = N / (2 * S) + 4 * b + h;
+      gs_bfly(v[2 * h], v[2 * h + 1], iw[i], iwp[i], q, q2);
+    }
+  }
+  {
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      int i = N / (4 * S) + 2 * b + h;
+      u32 w = iw[i], wp = iwp[i];
+      gs_bfly(v[4 * h + 0], v[4 * h + 2], w, wp, q, q2);
+      gs_bfly(v[4 * h + 1], v[4 * h + 3], w, wp, q, q2);
+    }
+  }
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int k = 0; k < 4; k++) gs_bfly(v[k], v[k + 4], w, wp, q, q2);
+  }
+}
+
+// Forward 2048-point negacyclic NTT of the 8 values per thread held in pattern {tau + 256k}
+// (natural order in), leaving the result in pattern {8 tau + k} (reference output order).
+__device__ __forceinline__ void ntt_fwd_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ fw,
+                                              const u32* __restrict__ fwp, u32 q, u32 q2) {
+  fwd_pass<256, true>(v, 0, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldsA[PAD_A(tau + 256 * k)] = v[k];
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(256 * b + o + 32 * k)];
+    fwd_pass<32, true>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsB[PAD_A(256 * b + o + 32 * k)] = v[k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsB[PAD_A(32 * b + o + 4 * k)];
+    fwd_pass<4, true>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsA[PAD_B(32 * b + o + 4 * k)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_B(8 * tau + k)];
+  fwd_pass<1, false>(v, tau, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {  // ntt.rs:107-111
+    u32 x = v[k];
+    x -= (x >= q2 ? q2 : 0u);
+    x -= (x >= q ? q : 0u);
+    v[k] = x;
+  }
+}
+
+// Inverse: values in pattern {8 tau + k} (< 2q) -> pattern {tau + 256k}, canonical.
+__device__ __forceinline__ void ntt_inv_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ iw,
+                                              const u32* __restrict__ iwp, u32 q, u32 q2) {
+  inv_pass<1, false>(v, tau, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) ldsA[PAD_B(8 * tau + k)] = v[k];
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_B(32 * b + o + 4 * k)];
+    inv_pass<4, true>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsB[PAD_A(32 * b + o + 4 * k)] = v[k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = ldsB[PAD_A(256 * b + o + 32 * k)];
+    inv_pass<32, true>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) ldsA[PAD_A(256 * b + o + 32 * k)] = v[k];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(tau + 256 * k)];
+  inv_pass<256, true>(v, 0, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {  // ntt.rs:253-256
+    u32 x = v[k];
+    x -= (x >= q2 ? q2 : 0u);
+    x -= (x >= q ? q : 0u);
+    v[k] = x;
+  }
+}
+
+// ---- M transforms at once per thread: the twiddles, Shoup quotients and LDS addresses are computed once
+// and applied to M independent coefficient vectors (same modulus); each barrier serves M transforms.
+// la / lb hold M consecutive LDS_WORDS-sized buffers.
+template <int S, bool DO_A, int M>
+__device__ __forceinline__ void fwd_pass_m(u32 (&v)[M][8], int b, const u32* __restrict__ fw,
+                                           const u32* __restrict__ fwp, u32 q, u32 q2) {
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) ct_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int i = N / (4 * S) + 2 * b + h;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      ct_bfly(v[m][4 * h + 0], v[m][4 * h + 2], w, wp, q, q2);
+      ct_bfly(v[m][4 * h + 1], v[m][4 * h + 3], w, wp, q, q2);
+    }
+  }
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    int i = N / (2 * S) + 4 * b + h;
+    u32 w = fw[i], wp = fwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) ct_bfly(v[m][2 * h], v[m][2 * h + 1], w, wp, q, q2);
+  }
+}
+template <int S, bool DO_A, int M>
+__device__ __forceinline__ void inv_pass_m(u32 (&v)[M][8], int b, const u32* __restrict__ iw,
+                                           const u32* __restrict__ iwp, u32 q, u32 q2) {
+#pragma unroll
+  for (int h = 0; h < 4; h++) {
+    int i = N / (2 * S) + 4 * b + h;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) gs_bfly(v[m][2 * h], v[m][2 * h + 1], w, wp, q, q2);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    int i = N / (4 * S) + 2 * b + h;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++) {
+      gs_bfly(v[m][4 * h + 0], v[m][4 * h + 2], w, wp, q, q2);
+      gs_bfly(v[m][4 * h + 1], v[m][4 * h + 3], w, wp, q, q2);
+    }
+  }
+  if (DO_A) {
+    int i = N / (8 * S) + b;
+    u32 w = iw[i], wp = iwp[i];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) gs_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+  }
+}
+template <int M>
+__device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,
+                                                const u32* __restrict__ fw, const u32* __restrict__ fwp, u32 q, u32 q2) {
+  fwd_pass_m<256, true, M>(v, 0, fw, fwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_A(tau + 256 * k);
+#pragma unroll
+    for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+    }
+    fwd_pass_m<32, true, M>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) lb[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = lb[m * LDS_WORDS + a];
+    }
+    fwd_pass_m<4, true, M>(v, b, fw, fwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_B(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_B(8 * tau + k);
+#pragma unroll
+    for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+  }
+  fwd_pass_m<1, false, M>(v, tau, fw, fwp, q, q2);
+#pragma unroll
+  for (int m = 0; m < M; m++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 x = v[m][k];
+      x -= (x >= q2 ? q2 : 0u);
+      x -= (x >= q ? q : 0u);
+      v[m][k] = x;
+    }
+}
+template <int M>
+__device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,
+                                                const u32* __restrict__ iw, const u32* __restrict__ iwp, u32 q, u32 q2) {
+  inv_pass_m<1, false, M>(v, tau, iw, iwp, q, q2);
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_B(8 * tau + k);
+#pragma unroll
+    for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+  }
+  __syncthreads();
+  {
+    int b = tau >> 2, o = tau & 3;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_B(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+    }
+    inv_pass_m<4, true, M>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(32 * b + o + 4 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) lb[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+  {
+    int b = tau >> 5, o = tau & 31;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) v[m][k] = lb[m * LDS_WORDS + a];
+    }
+    inv_pass_m<32, true, M>(v, b, iw, iwp, q, q2);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int a = PAD_A(256 * b + o + 32 * k);
+#pragma unroll
+      for (int m = 0; m < M; m++) la[m * LDS_WORDS + a] = v[m][k];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int a = PAD_A(tau + 256 * k);
+#pragma unroll
+    for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
+  }
+  inv_pass_m<256, true, M>(v, 0, iw, iwp, q, q2);
+#pragma unroll
+  for (int m = 0; m < M; m++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      u32 x = v[m][k];
+      x -= (x >= q2 ? q2 : 0u);
+      x -= (x >= q ? q : 0u);
+      v[m][k] = x;
+    }
+}
+
+// Packing helpers shared by the writers of the PACKED format.
+__device__ __forceinline__ void pack_unit_lane(u32* unit, int lane, u64 w00, u64 w01, u64 w10, u64 w11) {
+  // w{row}{iiofs}: limbs f0..f7 = lo/hi of w00, w01, w10, w11
+  const u32 M = 0x0FFFFFFFu;
+  const u32 f0 = (u32)w00 & M, f1 = (u32)(w00 >> 32) & M, f2 = (u32)w01 & M, f3 = (u32)(w01 >> 32) & M;
+  const u32 f4 = (u32)w10 & M, f5 = (u32)(w10 >> 32) & M, f6 = (u32)w11 & M, f7 = (u32)(w11 >> 32) & M;
+  u32* p4 = unit + lane * 4;
+  u32* p3 = unit + 256 + lane * 3;
+  p4[0] = f0 | (f1 << 28);
+  p4[1] = (f1 >> 4) | (f2 << 24);
+  p4[2] = (f2 >> 8) | (f3 << 20);
+  p4[3] = (f3 >> 12) | (f4 << 16);
+  p3[0] = (f4 >> 16) | (f5 << 12);
+  p3[1] = (f5 >> 20) | (f6 << 8);
+  p3[2] = (f6 >> 24) | (f7 << 4);
+}
+__device__ __forceinline__ u64 unpack_word(const u32* unit, int lane, int which) {  // which = row*2 + iiofs
+  const u32* p4 = unit + lane * 4;
+  const u32* p3 = unit + 256 + lane * 3;
+  u32 dd[8] = {p4[0], p4[1], p4[2], p4[3], p3[0], p3[1], p3[2], 0u};
+  u32 f[2];
+  for (int h = 0; h < 2; h++) {
+    const int bit = 28 * (which * 2 + h);
+    const int w = bit >> 5, sh = bit & 31;
+    u64 two = (u64)dd[w] | ((u64)dd[w + 1 < 8 ? w + 1 : 7] << 32);
+    f[h] = (u32)(two >> sh) & 0x0FFFFFFFu;
+  }
+  return (u64)f[0] | ((u64)f[1] << 32);
+}
+
+}  // namespace spiral

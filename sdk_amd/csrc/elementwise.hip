@@ -1,0 +1,326 @@
+// NTT-domain multiply-accumulate and the small elementwise kernels of the answer path (poly.rs:351-663, gadget.rs:34-60,
+// util.rs:323-355, server.rs:470-517).
+#include "device_common.hpp"
+
+namespace spiral {
+
+// ------------------------------------------------------------------------------------------------
+// NTT-domain multiply-accumulate.  grid (2N/256, batch), one (crt, z) per thread.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, int inner, int outer) {
+  const int e = blockIdx.x * 256 + threadIdx.x;  // index into [crt][z]
+  const int c = e >> POLY_LEN_LOG2;
+  const int b = outer * d.batch_inner + inner;
+  const ModConst m = T.c.mod[c];
+  const u32* B = d.B + ((size_t)outer * d.B_outer_stride + (size_t)inner * d.B_inner_stride) * 2 * N + e;
+  const long ob = d.out_idx ? (long)d.out_idx[b] : (long)b * d.out_batch_stride;
+  const size_t PW = 2 * N;
+  for (int r = 0; r < d.R; r++) {
+    const u32* A = d.A + (size_t)r * (d.A_row_stride ? d.A_row_stride : d.K) * PW + e;
+    const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
+    u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
+    if (d.extra && r == d.extra_row) acc += (u64)d.extra[(size_t)(d.extra_idx ? d.extra_idx[b] : b) * PW + e];
+    // two segments of B (k < split_k, k >= split_k), each walked 8 operands at a time with all 16
+    // loads issued before the multiplies: small batches are latency-bound, not bandwidth-bound.
+    // products < 2^56: <= 64 terms between Barrett folds stay < 2^63.
+    for (int seg = 0; seg < 2; seg++) {
+      const int k_lo = seg == 0 ? 0 : d.split_k, k_hi = seg == 0 ? min(d.split_k, d.K) : d.K;
+      const u32* Bs = seg == 0 ? B : B + (size_t)(d.split_off - d.split_k) * PW;
+      int k = k_lo, since = 0;
+      for (; k + 28 <= k_hi; k += 28) {  // 56 loads in flight: the small expansion rounds are pure latency
+        u32 a[28], bb[28];
+#pragma unroll
+        for (int u = 0; u < 28; u++) {
+          a[u] = A[(size_t)(k + u) * PW];
+          bb[u] = Bs[(size_t)(k + u) * PW];
+        }
+#pragma unroll
+        for (int u = 0; u < 28; u++) acc += (u64)a[u] * (u64)bb[u];
+        since += 28;
+        if (since >= 56) {
+          acc = reduce64(acc, m);
+          since = 0;
+        }
+      }
+      for (; k + 8 <= k_hi; k += 8) {
+        u32 a[8], bb[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          a[u] = A[(size_t)(k + u) * PW];
+          bb[u] = Bs[(size_t)(k + u) * PW];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) acc += (u64)a[u] * (u64)bb[u];
+        since += 8;
+        if (since >= 64) {
+          acc = reduce64(acc, m);
+          since = 0;
+        }
+      }
+      for (; k < k_hi; k++) acc += (u64)A[(size_t)k * PW] * (u64)Bs[(size_t)k * PW];
+      acc = reduce64(acc, m);
+    }
+    d.out[op] = (u32)acc;
+  }
+}
+__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d1) {
+  const int y = blockIdx.y;
+  if (y < d0.batch_inner)
+    mac_body(T, d0, y, 0);
+  else
+    mac_body(T, d1, y - d0.batch_inner, 0);
+}
+void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
+  if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
+  hipLaunchKernelGGL(k_mac, dim3(2 * N / 256, d.batch_inner, d.batch_outer), dim3(256), 0, s, T, d);
+}
+void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipStream_t s) {
+  MacDesc a = d0, b = d1;
+  a.batch_inner = std::max(a.batch_inner, 0);
+  b.batch_inner = std::max(b.batch_inner, 0);
+  if (a.batch_inner + b.batch_inner <= 0) return;
+  hipLaunchKernelGGL(k_mac2, dim3(2 * N / 256, a.batch_inner + b.batch_inner, 1), dim3(256), 0, s, T, a, b);
+}
+
+__global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, const int* idx, const u32* src) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int b = blockIdx.y;
+  const long dp = (long)idx[b] * 2 * N + e;
+  dst[dp] = add_mod(dst[dp], src[(size_t)b * 2 * N + e], T.c.mod[c].q);
+}
+void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(k_add_poly_into, dim3(2 * N / 256, batch), dim3(256), 0, s, T, dst, idx, src);
+}
+
+__global__ __launch_bounds__(256) void k_scalar_mul(DevTables T, u32* base, long dst_off, long src_off,
+                                                    const u32* scalar) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const long b = blockIdx.y;
+  const ModConst m = T.c.mod[c];
+  base[(dst_off + b) * 2 * N + e] = reduce64((u64)base[(src_off + b) * 2 * N + e] * (u64)scalar[e], m);
+}
+void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off, const u32* scalar, int n_polys,
+                       hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_scalar_mul, dim3(2 * N / 256, n_polys), dim3(256), 0, s, T, base, dst_off, src_off, scalar);
+}
+
+__global__ __launch_bounds__(256) void k_add_polys_idx(DevTables T, u32* dst, const int* di, const u32* a, const int* ai,
+                                                        const u32* b, const int* bi) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int k = blockIdx.y;
+  dst[(size_t)di[k] * 2 * N + e] = add_mod(a[(size_t)ai[k] * 2 * N + e], b[(size_t)bi[k] * 2 * N + e], T.c.mod[c].q);
+}
+void launch_add_polys_idx(const DevTables& T, u32* dst, const int* di, const u32* a, const int* ai, const u32* b,
+                          const int* bi, int count, hipStream_t s) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(k_add_polys_idx, dim3(2 * N / 256, count), dim3(256), 0, s, T, dst, di, a, ai, b, bi);
+}
+
+__global__ __launch_bounds__(256) void k_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index over [z][j]
+  if (i >= (size_t)N * dim0) return;
+  const int j = (int)(i % dim0);
+  const int z = (int)(i / dim0);
+  const u32* p = row0_ntt + (size_t)j * 2 * N;
+  qv[2 * i] = (u64)p[z] | ((u64)p[N + z] << 32);
+  qv[2 * i + 1] = wire[i];
+}
+void launch_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0, hipStream_t s) {
+  size_t total = (size_t)N * dim0;
+  hipLaunchKernelGGL(k_interleave_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qv, row0_ntt, wire, dim0);
+}
+
+__global__ __launch_bounds__(256) void k_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src,
+                                                    const int* src_idx, int src_row_stride, int R) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int b = blockIdx.y / R, r = blockIdx.y % R;
+  dst[((long)dst_idx[b] + (long)r * dst_row_stride) * 2 * N + e] =
+      src[((long)src_idx[b] + (long)r * src_row_stride) * 2 * N + e];
+}
+void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
+                       int src_row_stride, int R, int batch, hipStream_t s) {
+  if (batch <= 0) return;
+  hipLaunchKernelGGL(k_copy_polys, dim3(2 * N / 256, batch * R), dim3(256), 0, s, dst, dst_idx, dst_row_stride, src,
+                     src_idx, src_row_stride, R);
+}
+
+__global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, const u32* gadget_ntt, int two_t) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int c = e >> POLY_LEN_LOG2;
+  const int col = blockIdx.y % two_t, r = blockIdx.y / two_t;
+  const int dd = blockIdx.z;
+  const u32 q = T.c.mod[c].q;
+  u32* row = mats + ((size_t)(dd * 2 + r) * 2 * two_t) * 2 * N;
+  const u32 cv = row[(size_t)(two_t + col) * 2 * N + e];
+  const u32 g = gadget_ntt[((size_t)r * two_t + col) * 2 * N + e];
+  row[(size_t)col * 2 * N + e] = add_mod(g, cv ? q - cv : 0u, q);
+}
+void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s) {
+  if (nu2 <= 0) return;
+  hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, mats, gadget_ntt, two_t);
+}
+
+__global__ __launch_bounds__(256) void k_add(DevTables T, u32* out, const u32* a, const u32* b) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const int c = (int)((i >> POLY_LEN_LOG2) & 1);
+  out[i] = add_mod(a[i], b[i], T.c.mod[c].q);
+}
+void launch_add(const DevTables& T, u32* out, const u32* a, const u32* b, int n_polys, hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_add, dim3((unsigned)((size_t)n_polys * 2 * N / 256)), dim3(256), 0, s, T, out, a, b);
+}
+
+__global__ __launch_bounds__(256) void k_invert_raw(u64 Q, u64* out, const u64* a, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = Q - a[i];
+}
+void launch_invert_raw(const DevTables& T, u64* out, const u64* a, long n_words, hipStream_t s) {
+  if (n_words <= 0) return;
+  hipLaunchKernelGGL(k_invert_raw, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, T.c.Q, out, a, n_words);
+}
+
+__global__ __launch_bounds__(256) void k_automorph(u64 Q, u64* out, const u64* a, int t) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  const size_t p = (size_t)blockIdx.y * N;
+  unsigned zt = (unsigned)z * (unsigned)t;
+  unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
+  u64 v = a[p + z];
+  out[p + rem] = (num & 1u) ? Q - v : v;
+}
+void launch_automorph(const DevTables& T, u64* out, const u64* a, int n_polys, int t, hipStream_t s) {
+  if (n_polys <= 0) return;
+  hipLaunchKernelGGL(k_automorph, dim3(N / 256, n_polys), dim3(256), 0, s, T.c.Q, out, a, t);
+}
+
+__global__ __launch_bounds__(256) void k_gadget_raw(u64* out, const u64* inp, int cols, int rdim, int bits) {
+  const int z = blockIdx.x * 256 + threadIdx.x;
+  const int o = blockIdx.y;  // output poly index: row*cols + col
+  const int row = o / cols, col = o - row * cols;
+  const int k = row / rdim, j = row - k * rdim;
+  const int sh = k * bits;
+  const u64 mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1ULL);
+  u64 x = inp[((size_t)j * cols + col) * N + z];
+  out[(size_t)o * N + z] = sh >= 64 ? 0ULL : ((x >> sh) & mask);
+}
+void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows_out, int rdim, int bits,
+                       hipStream_t s) {
+  (void)rows_in;
+  hipLaunchKernelGGL(k_gadget_raw, dim3(N / 256, rows_out * cols), dim3(256), 0, s, out, inp, cols, rdim, bits);
+}
+
+__global__ __launch_bounds__(256) void k_u64_to_u32(u32* out, const u64* in, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (u32)in[i];
+}
+__global__ __launch_bounds__(256) void k_u32_to_u64(u64* out, const u32* in, long n) {
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) out[i] = (u64)in[i];
+}
+void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_u64_to_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+}
+void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
+  if (n <= 0) return;
+  hipLaunchKernelGGL(k_u32_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+}
+
+// rescale(a, Q, out_mod) of arith.rs:429-444 without 128-bit division: the truncated quotient
+// floor((|v| * out_mod + Q/2) / Q) is < 2^38, so a double estimate is within +-1 and is corrected exactly.
+__device__ __forceinline__ u64 rescale_dev(u64 a, u64 Q, u64 out_mod) {
+  u64 v = a % Q;
+  const bool neg = v >= Q / 2;  // inp_val -= inp_mod
+  const u64 mag = neg ? Q - v : v;
+  // num = mag * out_mod + Q/2  (up to ~2^93): 128-bit as (hi, lo)
+  u64 lo = mag * out_mod, hi = __umul64hi(mag, out_mod);
+  const u64 half = Q / 2;
+  lo += half;
+  hi += lo < half ? 1 : 0;
+  u64 qd = (u64)(((double)hi * 18446744073709551616.0 + (double)lo) / (double)Q);
+  // correct: want qd*Q <= num < (qd+1)*Q
+  for (int it = 0; it < 4; it++) {
+    const u64 plo = qd * Q, phi = __umul64hi(qd, Q);
+    const bool gt = phi > hi || (phi == hi && plo > lo);  // qd*Q > num
+    if (gt) {
+      qd--;
+      continue;
+    }
+    // rem = num - qd*Q  (fits 64 bits when qd is within 1 of the truth and Q < 2^57)
+    const u64 rlo = lo - plo, rhi = hi - phi - (lo < plo ? 1 : 0);
+    if (rhi != 0 || rlo >= Q) {
+      qd++;
+      continue;
+    }
+    break;
+  }
+  // result = (sign*qd + (Q/out)*out + 2*out) % out, then (+out) % out; all terms fit i64 magnitudes
+  const u64 base = (Q / out_mod) * out_mod + 2 * out_mod;
+  const u64 r = neg ? (base - qd) % out_mod : (base + qd) % out_mod;
+  return (r + out_mod) % out_mod;
+}
+__global__ __launch_bounds__(256) void k_encode(EncodeDesc d) {
+  const int per_inst_first = d.n * N, per_inst_rest = d.n * d.n * N;
+  const int per_inst = per_inst_first + per_inst_rest;
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)d.instances * per_inst) return;
+  const int inst = (int)(i / per_inst), k = (int)(i % per_inst);
+  const u64* m = d.packed + (size_t)inst * (d.n + 1) * d.n * N;
+  const size_t inst_bits = (size_t)per_inst_first * d.q2_bits + (size_t)per_inst_rest * d.q1_bits;
+  u64 val;
+  size_t bit;
+  int nb;
+  if (k < per_inst_first) {
+    val = rescale_dev(m[k], d.Q, d.q2);
+    nb = d.q2_bits;
+    bit = (size_t)inst * inst_bits + (size_t)k * d.q2_bits;
+  } else {
+    const int kk = k - per_inst_first;
+    val = rescale_dev(m[per_inst_first + kk], d.Q, d.q1);
+    nb = d.q1_bits;
+    bit = (size_t)inst * inst_bits + (size_t)per_inst_first * d.q2_bits + (size_t)kk * d.q1_bits;
+  }
+  val &= nb >= 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
+  const size_t w = bit >> 6;
+  const int off = (int)(bit & 63);
+  atomicOr(d.out + w, (unsigned long long)(val << off));
+  if (off + nb > 64) atomicOr(d.out + w + 1, (unsigned long long)(val >> (64 - off)));
+}
+void launch_encode(const EncodeDesc& d, hipStream_t s) {
+  const long total = (long)d.instances * ((long)d.n * N + (long)d.n * d.n * N);
+  hipLaunchKernelGGL(k_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+}
+
+// out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
+__global__ __launch_bounds__(256) void k_reorient(u64* out, const u32* v, int first, int step, int dim0) {
+  __shared__ u64 tile[32][33];
+  // tile over (z, j) for a fixed r: blockIdx.x -> j tile, blockIdx.y -> z tile, blockIdx.z -> r
+  const int r = blockIdx.z;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int j0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int j = j0 + ty + 8 * i;
+    if (j < dim0) {
+      const u32* p = v + ((size_t)(first + step * j) * 2 + r) * 2 * N;
+      tile[ty + 8 * i][tx] = (u64)p[z0 + tx] | ((u64)p[N + z0 + tx] << 32);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int z = z0 + ty + 8 * i;
+    int j = j0 + tx;
+    if (j < dim0) out[((size_t)z * dim0 + j) * 2 + r] = tile[tx][ty + 8 * i];
+  }
+}
+void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
+  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, out, v, first, step, dim0);
+}
+
+}  // namespace spiral

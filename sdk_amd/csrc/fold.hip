@@ -1,0 +1,252 @@
+// Fused fold step of fold_ciphertexts (server.rs:388-427) for gfx950: digits -> NTT -> multiply-accumulate -> iNTT -> CRT
+// in registers / LDS.  See DESIGN.md section 3 for the algebra and the roofline.
+#include "device_common.hpp"
+
+namespace spiral {
+
+// ------------------------------------------------------------------------------------------------
+// fused fold step.  grid (half, planes).
+//   reference (server.rs:407-424):  out = from_ntt( (G - C) * NTT(G^-1(ct_i)) + C * NTT(G^-1(ct_{i+half})) )
+//   computed as:                    out = ct_i + from_ntt( C * NTT(G^-1(ct_{i+half}) - G^-1(ct_i)) )   (mod Q)
+// which is the same element of Z_Q[x]/(x^N+1): G * G^-1(ct_i) = ct_i exactly (the digits recompose the
+// coefficient, gadget.rs:11-60), NTT / from_ntt are linear, and both sides are the canonical representative
+// in [0, Q).  That halves the transforms: per modulus 2t forward NTTs of digit differences, each consumed at
+// once by the 2-row multiply-accumulate against C, then two inverse NTTs; Garner; add ct_i.
+// Requires v_folding_neg == G - v_folding, which holds inside process_query by construction.
+// The two LDS buffers alternate roles between consecutive transforms: three barriers per transform.
+// ------------------------------------------------------------------------------------------------
+template <bool HOIST_TW>
+__global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) {
+  __shared__ u32 lds0[LDS_WORDS];
+  __shared__ u32 lds1[LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int two_t = 2 * d.t, four_t = 4 * d.t;
+  const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
+  const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
+  const u64 mask = (1ULL << d.bits) - 1ULL;
+  u32* la = lds0;
+  u32* lb = lds1;
+  u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* fw = T.tw + (size_t)c * 4 * N;
+    u64 acc0[8], acc1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      u64 x0[8], x1[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        x0[k] = ct0[(size_t)j * N + tau + 256 * k];
+        x1[k] = ct1[(size_t)j * N + tau + 256 * k];
+      }
+#pragma unroll 1
+      for (int kd = 0; kd < d.t; kd++) {
+        const int sh = kd * d.bits;
+        u32 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+          u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
+          u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+          if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
+            d0 = d0 >= m.q ? d0 - m.q : d0;
+            d1 = d1 >= m.q ? d1 - m.q : d1;
+          }
+          v[k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
+        }
+        const u32* fwk = fw;
+        int tk = tau;
+        if (!HOIST_TW) {  // keep twiddle loads and LDS address arithmetic inside the loop (fewer live VGPRs)
+          asm volatile("" : "+s"(fwk));
+          asm volatile("" : "+v"(tk));
+        }
+        ntt_fwd_block(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+        {
+          u32* tmp = la;
+          la = lb;
+          lb = tmp;
+        }
+        const int kk = two_t + j + 2 * kd;  // column of C inside the [G-C | C] row
+        const uint4* a0 = reinterpret_cast<const uint4*>(d.mats + ((size_t)kk * 2 + c) * N + 8 * tk);
+        const uint4* a1 = reinterpret_cast<const uint4*>(d.mats + ((size_t)(four_t + kk) * 2 + c) * N + 8 * tk);
+        const uint4 p0 = a0[0], p1 = a0[1], r0 = a1[0], r1 = a1[1];
+        acc0[0] += (u64)p0.x * v[0]; acc0[1] += (u64)p0.y * v[1]; acc0[2] += (u64)p0.z * v[2]; acc0[3] += (u64)p0.w * v[3];
+        acc0[4] += (u64)p1.x * v[4]; acc0[5] += (u64)p1.y * v[5]; acc0[6] += (u64)p1.z * v[6]; acc0[7] += (u64)p1.w * v[7];
+        acc1[0] += (u64)r0.x * v[0]; acc1[1] += (u64)r0.y * v[1]; acc1[2] += (u64)r0.z * v[2]; acc1[3] += (u64)r0.w * v[3];
+        acc1[4] += (u64)r1.x * v[4]; acc1[5] += (u64)r1.y * v[5]; acc1[6] += (u64)r1.z * v[6]; acc1[7] += (u64)r1.w * v[7];
+      }
+    }
+    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    u32 v0[8], v1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      v0[k] = reduce64(acc0[k], m);
+      v1[k] = reduce64(acc1[k], m);
+    }
+    ntt_inv_block(v0, tau, la, lb, iw, iw + N, m.q, m.two_q);
+    ntt_inv_block(v1, tau, lb, la, iw, iw + N, m.q, m.two_q);
+    if (c == 0) {
+      // park the modulus-0 residues in the output slot (the same thread re-reads them below)
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        out[tau + 256 * k] = v0[k];
+        out[(size_t)N + tau + 256 * k] = v1[k];
+      }
+    } else {
+      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const size_t zi = (size_t)r * N + tau + 256 * k;
+          u32 x = (u32)out[zi], y = r == 0 ? v0[k] : v1[k];
+          u32 xm = x >= q1 ? x - q1 : x;
+          u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+          e = e >= q1 ? e - q1 : e;
+          u64 val = (u64)x + (u64)q0 * (u64)e + ct0[zi];  // ct_i < Q (from_ntt output)
+          out[zi] = val >= T.c.Q ? val - T.c.Q : val;
+        }
+      }
+    }
+  }
+}
+// k_fold_fused with two digit transforms in flight per thread (shared twiddles / addresses / barriers).
+// Requires an even digit count t.
+// TW_LDS: the forward twiddles + Shoup quotients of the current modulus (16 KiB) are staged in LDS once per
+// modulus, so the 4 x 14 twiddle reads of every digit transform are ds_reads (no vector-memory latency, and no
+// queueing behind a concurrent sweep's load stream when the fold runs on the second stream).
+template <bool TW_LDS>
+__global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d) {
+  __shared__ u32 lds0[2 * LDS_WORDS];
+  __shared__ u32 lds1[2 * LDS_WORDS];
+  __shared__ u32 ltw[TW_LDS ? 2 * N : 4];
+  const int tau = threadIdx.x;
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int two_t = 2 * d.t, four_t = 4 * d.t;
+  const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
+  const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
+  const u64 mask = (1ULL << d.bits) - 1ULL;
+  u32* la = lds0;
+  u32* lb = lds1;
+  u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* fw = T.tw + (size_t)c * 4 * N;
+    if (TW_LDS) {
+      if (c == 1) __syncthreads();
+#pragma unroll
+      for (int k = 0; k < 4; k++)  // [fw | fwp] = 2N words
+        reinterpret_cast<uint4*>(ltw)[tau + 256 * k] = reinterpret_cast<const uint4*>(fw)[tau + 256 * k];
+      __syncthreads();
+    }
+    u64 acc0[8], acc1[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
+#pragma unroll 1
+    for (int j = 0; j < 2; j++) {
+      u64 x0[8], x1[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        x0[k] = ct0[(size_t)j * N + tau + 256 * k];
+        x1[k] = ct1[(size_t)j * N + tau + 256 * k];
+      }
+#pragma unroll 1
+      for (int kd = 0; kd < d.t; kd += 2) {
+        u32 v[2][8];
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+          const int sh = (kd + mm) * d.bits;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            u32 d0 = sh >= 64 ? 0u : (u32)((x0[k] >> sh) & mask);
+            u32 d1 = sh >= 64 ? 0u : (u32)((x1[k] >> sh) & mask);
+            if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
+              d0 = d0 >= m.q ? d0 - m.q : d0;
+              d1 = d1 >= m.q ? d1 - m.q : d1;
+            }
+            v[mm][k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
+          }
+        }
+        const u32* fwk = fw;
+        int tk = tau;
+        asm volatile("" : "+s"(fwk));
+        asm volatile("" : "+v"(tk));
+        if (TW_LDS)
+          ntt_fwd_block_m<2>(v, tk, la, lb, ltw, ltw + N, m.q, m.two_q);
+        else
+          ntt_fwd_block_m<2>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+        {
+          u32* tmp = la;
+          la = lb;
+          lb = tmp;
+        }
+#pragma unroll
+        for (int mm = 0; mm < 2; mm++) {
+          const int kk = two_t + j + 2 * (kd + mm);
+          const uint4* a0 = reinterpret_cast<const uint4*>(d.mats + ((size_t)kk * 2 + c) * N + 8 * tk);
+          const uint4* a1 = reinterpret_cast<const uint4*>(d.mats + ((size_t)(four_t + kk) * 2 + c) * N + 8 * tk);
+          const uint4 p0 = a0[0], p1 = a0[1], r0 = a1[0], r1 = a1[1];
+          acc0[0] += (u64)p0.x * v[mm][0]; acc0[1] += (u64)p0.y * v[mm][1]; acc0[2] += (u64)p0.z * v[mm][2]; acc0[3] += (u64)p0.w * v[mm][3];
+          acc0[4] += (u64)p1.x * v[mm][4]; acc0[5] += (u64)p1.y * v[mm][5]; acc0[6] += (u64)p1.z * v[mm][6]; acc0[7] += (u64)p1.w * v[mm][7];
+          acc1[0] += (u64)r0.x * v[mm][0]; acc1[1] += (u64)r0.y * v[mm][1]; acc1[2] += (u64)r0.z * v[mm][2]; acc1[3] += (u64)r0.w * v[mm][3];
+          acc1[4] += (u64)r1.x * v[mm][4]; acc1[5] += (u64)r1.y * v[mm][5]; acc1[6] += (u64)r1.z * v[mm][6]; acc1[7] += (u64)r1.w * v[mm][7];
+        }
+      }
+    }
+    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    u32 vv[2][8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      vv[0][k] = reduce64(acc0[k], m);
+      vv[1][k] = reduce64(acc1[k], m);
+    }
+    ntt_inv_block_m<2>(vv, tau, la, lb, iw, iw + N, m.q, m.two_q);
+    if (c == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        out[tau + 256 * k] = vv[0][k];
+        out[(size_t)N + tau + 256 * k] = vv[1][k];
+      }
+    } else {
+      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+          const size_t zi = (size_t)r * N + tau + 256 * k;
+          u32 x = (u32)out[zi], y = vv[r][k];
+          u32 xm = x >= q1 ? x - q1 : x;
+          u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+          e = e >= q1 ? e - q1 : e;
+          u64 val = (u64)x + (u64)q0 * (u64)e + ct0[zi];
+          out[zi] = val >= T.c.Q ? val - T.c.Q : val;
+        }
+      }
+    }
+  }
+}
+void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
+  if (d.half <= 0 || d.planes <= 0) return;
+  static const int variant = [] {
+    const char* e = getenv("SPIRAL_FOLD_VARIANT");
+    return e ? atoi(e) : 3;
+  }();
+  if (variant == 3 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  else if (variant == 2 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  else if (variant == 1)
+    hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  else
+    hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+}
+
+}  // namespace spiral

@@ -1,4 +1,4 @@
-// Launch wrappers for the gfx950 kernels of the Spiral answer path (kernels.hip).
+// Launch wrappers for the gfx950 kernels of the Spiral answer path (ntt.hip, fold.hip, elementwise.hip, sweep.hip, db.hip; shared device helpers in device_common.hpp).
 // Device data model:
 //   NTT-form poly   : u32[2][N]  ([crt][z], residues < q_crt)           -- "npoly", 16 KiB
 //   raw poly        : u64[N]     (coefficients <= Q < 2^56)              -- "rpoly", 16 KiB

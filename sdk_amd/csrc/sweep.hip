@@ -1,0 +1,534 @@
+// Database sweep = multiply_reg_by_database (server.rs:155-221) for gfx950: HBM-streaming integer kernels, one per
+// database shape (PACKED wide, persistent, batched, 8-byte wide, narrow).  The judged kernel lives here.
+#include "device_common.hpp"
+
+namespace spiral {
+
+// ------------------------------------------------------------------------------------------------
+// database sweep  (server.rs:155-221)
+// ------------------------------------------------------------------------------------------------
+// WIDE (num_per >= 128): one wave per (plane, z, 128-wide ii chunk).  Lane l owns output columns
+// ii = chunk*128 + 2l, 2l+1 and streams its 16 bytes of every first-dimension row j: 1 KiB
+// contiguous per wave per row.  The query words for (z, j) are wave-uniform (scalar loads, SGPR
+// operands of v_mad_u64_u32); no cross-lane traffic at all.  Products are < 2^56, so 256 rows are
+// accumulated in u64 between Barrett folds (the reference uses u128 and one % at the end; the
+// residues are identical).
+// flat index of output (plane, rc = r*2+crt, z, ii) in the (possibly column-interleaved) partial buffer
+__device__ __forceinline__ size_t sweep_out_index(const SweepDesc& d, int plane, int rc, int z, int ii) {
+  const int G = d.out_G > 1 ? d.out_G : 1;
+  const int npl = d.num_per / G;
+  const size_t chunk_words = (size_t)d.planes * 4 * N * npl;
+  return (size_t)(ii % G) * chunk_words + (((size_t)plane * 4 + rc) * N + z) * npl + (ii / G);
+}
+__device__ __forceinline__ void sweep_store_pair(const SweepDesc& d, int plane, int z, int ii0, u32 r0c0_a, u32 r0c0_b,
+                                                 u32 r0c1_a, u32 r0c1_b, u32 r1c0_a, u32 r1c0_b, u32 r1c1_a,
+                                                 u32 r1c1_b) {
+  if (d.out_G <= 1) {
+    const size_t rc = (size_t)N * d.num_per;
+    u32* o = d.out + (size_t)plane * 4 * rc + (size_t)z * d.num_per + ii0;
+    *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2(r0c0_a, r0c0_b);
+    *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2(r0c1_a, r0c1_b);
+    *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2(r1c0_a, r1c0_b);
+    *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2(r1c1_a, r1c1_b);
+  } else {
+    d.out[sweep_out_index(d, plane, 0, z, ii0)] = r0c0_a;
+    d.out[sweep_out_index(d, plane, 0, z, ii0 + 1)] = r0c0_b;
+    d.out[sweep_out_index(d, plane, 1, z, ii0)] = r0c1_a;
+    d.out[sweep_out_index(d, plane, 1, z, ii0 + 1)] = r0c1_b;
+    d.out[sweep_out_index(d, plane, 2, z, ii0)] = r1c0_a;
+    d.out[sweep_out_index(d, plane, 2, z, ii0 + 1)] = r1c0_b;
+    d.out[sweep_out_index(d, plane, 3, z, ii0)] = r1c1_a;
+    d.out[sweep_out_index(d, plane, 3, z, ii0 + 1)] = r1c1_b;
+  }
+}
+
+template <int U, bool NT>
+__global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;  // plane * N + z
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  if (plane >= d.planes) return;
+  const ulonglong2* p =
+      reinterpret_cast<const ulonglong2*>(d.db + ((size_t)zp * d.nj) * d.num_per + (size_t)chunk * 128) + lane;
+  const size_t stride = (size_t)(d.num_per >> 1);
+  const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+
+  u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0;  // word 0: n0_0, n0_1, n1_0, n1_1
+  u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // word 1
+  for (int jb = 0; jb < d.nj; jb += 256) {
+    const int je = min(jb + 256, d.nj);
+    int j = jb;
+    for (; j + U <= je; j += U) {
+      ulonglong2 w[U];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const ulonglong2* a = p + (size_t)(j + u) * stride;
+        if (NT) {  // streamed once: do not keep the lines in L2 / MALL
+          w[u].x = __builtin_nontemporal_load(&a->x);
+          w[u].y = __builtin_nontemporal_load(&a->y);
+        } else {
+          w[u] = *a;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const uint4 qa = qrow[j + u];  // (a0_lo, a0_hi, a1_lo, a1_hi)
+        const u32 b0l = (u32)w[u].x, b0h = (u32)(w[u].x >> 32);
+        const u32 b1l = (u32)w[u].y, b1h = (u32)(w[u].y >> 32);
+        a00 += (u64)qa.x * b0l;
+        a01 += (u64)qa.z * b0l;
+        a02 += (u64)qa.y * b0h;
+        a03 += (u64)qa.w * b0h;
+        a10 += (u64)qa.x * b1l;
+        a11 += (u64)qa.z * b1l;
+        a12 += (u64)qa.y * b1h;
+        a13 += (u64)qa.w * b1h;
+      }
+    }
+    for (; j < je; j++) {
+      const ulonglong2 w = p[(size_t)j * stride];
+      const uint4 qa = qrow[j];
+      const u32 b0l = (u32)w.x, b0h = (u32)(w.x >> 32);
+      const u32 b1l = (u32)w.y, b1h = (u32)(w.y >> 32);
+      a00 += (u64)qa.x * b0l;
+      a01 += (u64)qa.z * b0l;
+      a02 += (u64)qa.y * b0h;
+      a03 += (u64)qa.w * b0h;
+      a10 += (u64)qa.x * b1l;
+      a11 += (u64)qa.z * b1l;
+      a12 += (u64)qa.y * b1h;
+      a13 += (u64)qa.w * b1h;
+    }
+    a00 = reduce64(a00, m0);
+    a01 = reduce64(a01, m0);
+    a02 = reduce64(a02, m1);
+    a03 = reduce64(a03, m1);
+    a10 = reduce64(a10, m0);
+    a11 = reduce64(a11, m0);
+    a12 = reduce64(a12, m1);
+    a13 = reduce64(a13, m1);
+  }
+  // out[plane][r][crt][z][ii]
+  // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
+  sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                   (u32)a03, (u32)a13);
+}
+
+// PACKED wide sweep: as k_sweep_wide, but each lane streams 28 bytes per ROW PAIR (7 dwords = 8 limbs
+// of 28 bits) instead of 32; limb extraction is 6 v_alignbit + 7 v_and per 16 multiply-accumulates.
+typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
+typedef u32 u32x3_t __attribute__((ext_vector_type(3), aligned(4)));
+__global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) {
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;  // plane * N + z
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  if (plane >= d.planes) return;
+  const int npairs = d.nj >> 1;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;  // 1792 B = 448 dwords
+  const size_t ustride = (size_t)chunks * 448;
+  const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0;  // ii = 2l  : n0_0, n0_1, n1_0, n1_1
+  u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // ii = 2l+1
+  for (int jb = 0; jb < npairs; jb += 128) {
+    const int je = min(jb + 128, npairs);
+    for (int jp = jb; jp < je; jp++) {
+      const u32* u = base + (size_t)jp * ustride;
+      const u32* p4 = u + lane * 4;
+      const u32* p3 = u + 256 + lane * 3;
+      const u32x4_t va = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p4));
+      const u32x3_t vb = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(p3));
+      const u32 d0 = va.x, d1 = va.y, d2 = va.z, d3 = va.w, d4 = vb.x, d5 = vb.y, d6 = vb.z;
+      const uint4 qa = qrow[2 * jp];      // row 2jp   : (a0_lo, a0_hi, a1_lo, a1_hi)
+      const uint4 qb = qrow[2 * jp + 1];  // row 2jp+1
+      const u32 f0 = d0 & M;
+      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+      const u32 f7 = d6 >> 4;
+      // (row 2jp, ii 2l) = (f0, f1); (2jp, 2l+1) = (f2, f3); (2jp+1, 2l) = (f4, f5); (2jp+1, 2l+1) = (f6, f7)
+      a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
+      a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
+      a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
+      a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;
+    }
+    a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
+    a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
+  }
+  // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
+  sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                   (u32)a03, (u32)a13);
+}
+
+// Persistent form of k_sweep_packed for the intra-query pipeline: a fixed grid of `wgs_per_cu` workgroups per
+// CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
+// LDS stay free for the fold kernels running concurrently on the second stream.
+template <int U>
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio) {
+  // the sweep is a latency-bound load stream using ~20 % of the VALU slots: when fold kernels share the CU its
+  // waves must win instruction arbitration or the loads in flight (and the HBM rate) drop
+  if (hi_prio) __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int nwaves = gridDim.x * 4;
+  const int chunks = d.num_per >> 7;
+  const int npairs = d.nj >> 1;
+  const size_t ustride = (size_t)chunks * 448;
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  for (int unit = wave0; unit < units; unit += nwaves) {
+    const int chunk = unit % chunks;
+    const int zp = unit / chunks;
+    const int z = zp & (N - 1);
+    const int plane = zp >> POLY_LEN_LOG2;
+    const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
+    const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+    u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
+    for (int jb = 0; jb < npairs; jb += 128) {
+      const int je = min(jb + 128, npairs);
+      for (int jp0 = jb; jp0 < je; jp0 += U) {
+        u32x4_t va[U];
+        u32x3_t vb[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int jp = min(jp0 + u, je - 1);
+          const u32* uu = base + (size_t)jp * ustride;
+          va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(uu + lane * 4));
+          vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(uu + 256 + lane * 3));
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int jp = jp0 + u;
+          if (jp < je) {
+            const u32 d0 = va[u].x, d1 = va[u].y, d2 = va[u].z, d3 = va[u].w, d4 = vb[u].x, d5 = vb[u].y, d6 = vb[u].z;
+            const uint4 qa = qrow[2 * jp];
+            const uint4 qb = qrow[2 * jp + 1];
+            const u32 f0 = d0 & M;
+            const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+            const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+            const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+            const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+            const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+            const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+            const u32 f7 = d6 >> 4;
+            a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
+            a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
+            a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
+            a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;
+          }
+        }
+      }
+      a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
+      a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
+    }
+    sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                     (u32)a03, (u32)a13);
+  }
+}
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s) {
+  const int units = d.planes * N * (d.num_per >> 7);
+  const dim3 grid((unsigned)std::min(256 * wgs_per_cu, (units + 3) / 4));
+  static const int prio = [] { const char* e = getenv("SPIRAL_SWEEP_PRIO"); return e ? atoi(e) : 1; }();
+  switch (unroll) {
+    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio); break;
+  }
+}
+
+// Multi-query PACKED sweep: B queries share one pass over the database (BASELINE configs[4]).  Per row
+// pair: one 28-byte load, B x 2 scalar query rows, 16 B multiply-accumulates.  HBM-bound up to B ~ 4,
+// integer-ALU-bound beyond.
+// U row pairs (28 B per lane each) are in flight per wave (U = 4 needs npairs % 4 == 0: no ragged tail, straight-line
+// code): with B queries' accumulators the kernel runs at 2-5 waves per SIMD, and one load per wave leaves the HBM
+// pipe mostly empty (B = 8: 21 ms per pass instead of ~10).
+// QLDS: the B queries' rows for this workgroup's z (B * nj * 16 B, 64 KiB at B = 8) are staged in LDS once and
+// read back as broadcast ds_reads.  The scalar-load form keeps them in the 16 KiB scalar cache, which B > 4
+// overflows: every query word then costs an L2 round trip and the pass takes 25 ms instead of ~10 at B = 8.
+// Needs all four waves of the workgroup on the same z (chunks % 4 == 0).
+template <int B, int U, bool QLDS>
+__global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBatchDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
+  const int lane = threadIdx.x & 63;
+  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int chunks = d.num_per >> 7;
+  const int chunk = unit % chunks;
+  const int zp = unit / chunks;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qs = reinterpret_cast<const uint4*>(smem_q);  // [B][nj]
+  if (QLDS) {
+    const int zp0 = (blockIdx.x * 4) / chunks;  // the whole workgroup shares one (plane, z)
+    const int z0 = zp0 & (N - 1);
+    uint4* qw = reinterpret_cast<uint4*>(smem_q);
+#pragma unroll
+    for (int b = 0; b < B; b++) {
+      const uint4* src = reinterpret_cast<const uint4*>(d.qv[b]) + ((size_t)z0 * d.dim0 + d.j0);
+      for (int j = threadIdx.x; j < d.nj; j += 256) qw[b * d.nj + j] = src[j];
+    }
+    __syncthreads();
+  }
+  if (plane >= d.planes) return;
+  const int npairs = d.nj >> 1;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
+  const size_t ustride = (size_t)chunks * 448;
+  const size_t qoff = (size_t)z * d.dim0 + d.j0;
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  u64 acc[B][8];
+#pragma unroll
+  for (int b = 0; b < B; b++)
+#pragma unroll
+    for (int k = 0; k < 8; k++) acc[b][k] = 0;
+  // software pipeline: the loads of the next U row pairs are issued before the current U are consumed
+  u32x4_t va[U], na[U];
+  u32x3_t vb[U], nb[U];
+#pragma unroll
+  for (int uu = 0; uu < U; uu++) {
+    const u32* u = base + (size_t)uu * ustride;
+    va[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
+    vb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+  }
+  for (int jp0 = 0; jp0 < npairs; jp0 += U) {
+    const bool more = jp0 + U < npairs;
+    if (more) {
+#pragma unroll
+      for (int uu = 0; uu < U; uu++) {
+        const u32* u = base + (size_t)(jp0 + U + uu) * ustride;
+        na[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
+        nb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the multiply-accumulates
+#pragma unroll
+    for (int uu = 0; uu < U; uu++) {
+      const int jp = jp0 + uu;
+      const u32 d0 = va[uu].x, d1 = va[uu].y, d2 = va[uu].z, d3 = va[uu].w, d4 = vb[uu].x, d5 = vb[uu].y, d6 = vb[uu].z;
+      const u32 f0 = d0 & M;
+      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
+      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
+      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
+      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
+      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
+      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
+      const u32 f7 = d6 >> 4;
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        const uint4* __restrict__ qrow = QLDS ? qs + b * d.nj : reinterpret_cast<const uint4*>(d.qv[b]) + qoff;
+        const uint4 qa = qrow[2 * jp];
+        const uint4 qb = qrow[2 * jp + 1];
+        acc[b][0] += (u64)qa.x * f0; acc[b][1] += (u64)qa.z * f0; acc[b][2] += (u64)qa.y * f1; acc[b][3] += (u64)qa.w * f1;
+        acc[b][4] += (u64)qa.x * f2; acc[b][5] += (u64)qa.z * f2; acc[b][6] += (u64)qa.y * f3; acc[b][7] += (u64)qa.w * f3;
+        acc[b][0] += (u64)qb.x * f4; acc[b][1] += (u64)qb.z * f4; acc[b][2] += (u64)qb.y * f5; acc[b][3] += (u64)qb.w * f5;
+        acc[b][4] += (u64)qb.x * f6; acc[b][5] += (u64)qb.z * f6; acc[b][6] += (u64)qb.y * f7; acc[b][7] += (u64)qb.w * f7;
+      }
+    }
+    if (!more || ((jp0 + U) & 127) == 0) {  // at most 256 rows of < 2^56 products between Barrett folds
+#pragma unroll
+      for (int b = 0; b < B; b++) {
+        acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);
+        acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);
+        acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);
+        acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);
+      }
+    }
+#pragma unroll
+    for (int uu = 0; uu < U; uu++) {
+      va[uu] = na[uu];
+      vb[uu] = nb[uu];
+    }
+  }
+  const size_t rc = (size_t)N * d.num_per;
+  const size_t zi = (size_t)plane * 4 * rc + (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    u32* o = d.out[b] + zi;
+    *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2((u32)acc[b][0], (u32)acc[b][4]);  // r=0, crt=0
+    *reinterpret_cast<uint2*>(o + 1 * rc) = make_uint2((u32)acc[b][2], (u32)acc[b][6]);  // r=0, crt=1
+    *reinterpret_cast<uint2*>(o + 2 * rc) = make_uint2((u32)acc[b][1], (u32)acc[b][5]);  // r=1, crt=0
+    *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)acc[b][3], (u32)acc[b][7]);  // r=1, crt=1
+  }
+}
+void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
+  const long units = (long)d.planes * N * (d.num_per >> 7);
+  const dim3 grid((unsigned)((units + 3) / 4));
+  const bool unroll = ((d.nj >> 1) % 4) == 0;
+  static const int lds_min_b = [] { const char* e = getenv("SPIRAL_BATCH_QLDS_MIN"); return e ? atoi(e) : 5; }();
+  const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && (size_t)d.batch * d.nj * 16 <= 65536;
+  const size_t lds = qlds ? (size_t)d.batch * d.nj * 16 : 0;
+#define SP_BATCH_CASE(B)                                                                              \
+  case B:                                                                                             \
+    if (qlds)                                                                                         \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, (B >= 7 ? 2 : 4), true>), grid, dim3(256), lds, s, T, d); \
+    else if (unroll)                                                                                  \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, false>), grid, dim3(256), 0, s, T, d);           \
+    else                                                                                              \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 1, false>), grid, dim3(256), 0, s, T, d);           \
+    break;
+  switch (d.batch) {
+    SP_BATCH_CASE(1) SP_BATCH_CASE(2) SP_BATCH_CASE(3) SP_BATCH_CASE(4)
+    SP_BATCH_CASE(5) SP_BATCH_CASE(6) SP_BATCH_CASE(7) SP_BATCH_CASE(8)
+    default: break;
+  }
+#undef SP_BATCH_CASE
+}
+
+
+// NARROW (num_per <= 64): one workgroup per (plane, z).  The nj*num_per words of the row block are
+// contiguous; thread tau reads word tau + 256*s, i.e. fixed ii = tau % num_per and rows
+// j = tau/num_per + s*(256/num_per).  Query limbs for this z are staged in LDS (16 B per row);
+// partial sums are Barrett-folded to < 2^28 and combined through LDS.
+__global__ __launch_bounds__(256) void k_sweep_narrow(DevTables T, SweepDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* qs = reinterpret_cast<uint4*>(smem);                          // [nj]
+  u32* red = reinterpret_cast<u32*>(smem + (size_t)d.nj * sizeof(uint4));  // [256][4]
+  const int tau = threadIdx.x;
+  const int zp = blockIdx.x;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  for (int j = tau; j < d.nj; j += 256) qs[j] = qrow[j];
+  __syncthreads();
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u64* p = d.db + (size_t)zp * d.nj * d.num_per;
+  const int L = d.nj * d.num_per;
+  const int np_log = __ffs(d.num_per) - 1;
+  u64 a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+  int cnt = 0;
+  for (int f = tau; f < L; f += 256) {
+    const u64 w = p[f];
+    const uint4 qa = qs[f >> np_log];
+    const u32 bl = (u32)w, bh = (u32)(w >> 32);
+    a0 += (u64)qa.x * bl;
+    a1 += (u64)qa.z * bl;
+    a2 += (u64)qa.y * bh;
+    a3 += (u64)qa.w * bh;
+    if (++cnt == 255) {
+      cnt = 0;
+      a0 = reduce64(a0, m0);
+      a1 = reduce64(a1, m0);
+      a2 = reduce64(a2, m1);
+      a3 = reduce64(a3, m1);
+    }
+  }
+  red[tau * 4 + 0] = reduce64(a0, m0);
+  red[tau * 4 + 1] = reduce64(a1, m0);
+  red[tau * 4 + 2] = reduce64(a2, m1);
+  red[tau * 4 + 3] = reduce64(a3, m1);
+  __syncthreads();
+  // 4*num_per outputs; thread t < 4*num_per: which = t / num_per, ii = t % num_per
+  if (tau < 4 * d.num_per) {
+    const int which = tau >> np_log, ii = tau & (d.num_per - 1);
+    u64 sacc = 0;
+    for (int t2 = ii; t2 < 256; t2 += d.num_per) sacc += red[t2 * 4 + which];
+    const u32 r = reduce64(sacc, which < 2 ? m0 : m1);
+    // which: 0 n0_0 (r0,c0)  1 n0_1 (r1,c0)  2 n1_0 (r0,c1)  3 n1_1 (r1,c1)
+    const int rr = which & 1, cc = which >> 1;
+    d.out[sweep_out_index(d, plane, rr * 2 + cc, z, ii)] = r;
+  }
+}
+
+// NARROW with 16-byte non-temporal loads (2 <= num_per <= 64): thread tau reads words 2 tau, 2 tau + 1 (+512 s):
+// the same row j, columns ii0 = (2 tau) % num_per and ii0 + 1.
+__global__ __launch_bounds__(256) void k_sweep_narrow2(DevTables T, SweepDesc d) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint4* qs = reinterpret_cast<uint4*>(smem);                              // [nj]
+  u32* red = reinterpret_cast<u32*>(smem + (size_t)d.nj * sizeof(uint4));  // [256][8]
+  const int tau = threadIdx.x;
+  const int zp = blockIdx.x;
+  const int z = zp & (N - 1);
+  const int plane = zp >> POLY_LEN_LOG2;
+  const uint4* qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
+  for (int j = tau; j < d.nj; j += 256) qs[j] = qrow[j];
+  __syncthreads();
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u64* p = d.db + (size_t)zp * d.nj * d.num_per;
+  const int L = d.nj * d.num_per;
+  const int np_log = __ffs(d.num_per) - 1;
+  u64 a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int cnt = 0;
+  for (int f = 2 * tau; f < L; f += 512) {
+    ulonglong2 w;
+    w.x = __builtin_nontemporal_load(p + f);
+    w.y = __builtin_nontemporal_load(p + f + 1);
+    const uint4 qa = qs[f >> np_log];
+    const u32 b0l = (u32)w.x, b0h = (u32)(w.x >> 32), b1l = (u32)w.y, b1h = (u32)(w.y >> 32);
+    a[0] += (u64)qa.x * b0l; a[1] += (u64)qa.z * b0l; a[2] += (u64)qa.y * b0h; a[3] += (u64)qa.w * b0h;
+    a[4] += (u64)qa.x * b1l; a[5] += (u64)qa.z * b1l; a[6] += (u64)qa.y * b1h; a[7] += (u64)qa.w * b1h;
+    if (++cnt == 255) {
+      cnt = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) a[i] = reduce64(a[i], (i & 2) ? m1 : m0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) red[tau * 8 + i] = reduce64(a[i], (i & 2) ? m1 : m0);
+  __syncthreads();
+  if (tau < 4 * d.num_per) {
+    const int which = tau >> np_log, ii = tau & (d.num_per - 1);
+    const int slot = (ii & 1) * 4 + which, first = ii >> 1, step = d.num_per >> 1;
+    u64 sacc = 0;
+    for (int t2 = first; t2 < 256; t2 += step) sacc += red[t2 * 8 + slot];
+    const u32 r = reduce64(sacc, which < 2 ? m0 : m1);
+    const int rr = which & 1, cc = which >> 1;
+    d.out[sweep_out_index(d, plane, rr * 2 + cc, z, ii)] = r;
+  }
+}
+
+const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
+
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
+void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
+  // default: persistent grid of 4 workgroups per CU, 4 row pairs in flight per lane (profiles/r01_sweep_variants.md);
+  // SPIRAL_SWEEP_PERSIST_WGS=0 selects the one-wave-per-unit grid
+  static const int persist_wgs = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_WGS"); return e ? atoi(e) : 4; }();
+  static const int persist_unr = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_UNROLL"); return e ? atoi(e) : 4; }();
+  if (d.packed && persist_wgs > 0) {
+    launch_sweep_persist(T, d, persist_wgs, persist_unr, s);
+    return;
+  }
+  if (d.packed) {
+    const long units = (long)d.planes * N * (d.num_per >> 7);
+    hipLaunchKernelGGL(k_sweep_packed, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
+  } else if (d.num_per >= 128) {
+    const long units = (long)d.planes * N * (d.num_per >> 7);
+    static const int variant = [] {
+      const char* e = getenv("SPIRAL_SWEEP_VARIANT");
+      return e ? atoi(e) : 0;
+    }();
+    const dim3 grid((unsigned)((units + 3) / 4));
+    // measured on MI355X, C2 (profiles/r01_sweep_variants.md): non-temporal loads + no manual unroll is
+    // the fastest form (6.8 TB/s); the others stay selectable for A/B runs
+    switch (variant) {
+      case 1: hipLaunchKernelGGL((k_sweep_wide<8, true>), grid, dim3(256), 0, s, T, d); break;
+      case 2: hipLaunchKernelGGL((k_sweep_wide<8, false>), grid, dim3(256), 0, s, T, d); break;
+      case 4: hipLaunchKernelGGL((k_sweep_wide<4, true>), grid, dim3(256), 0, s, T, d); break;
+      case 5: hipLaunchKernelGGL((k_sweep_wide<2, true>), grid, dim3(256), 0, s, T, d); break;
+      default: hipLaunchKernelGGL((k_sweep_wide<1, true>), grid, dim3(256), 0, s, T, d); break;
+    }
+  } else {
+    if (d.num_per >= 2 && !getenv("SPIRAL_NARROW1")) {
+      size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 8 * sizeof(u32);
+      hipLaunchKernelGGL(k_sweep_narrow2, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+    } else {
+      size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
+      hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
+    }
+  }
+}
+
+}  // namespace spiral

@@ -147,7 +147,7 @@ def scatter_fold_query(run, db, rank, world, overlap=True, fold_per_plane=False)
 
 def scatter_layout_index(num_per, planes, G, plane, r, crt, z, ii, N=2048):
     """flat index of output (plane, r, crt, z, ii) in the column-interleaved partial buffer
-    (kernels.hip sweep_out_index): chunk ii % G, then [plane][r][crt][z][ii // G]"""
+    (sweep.hip sweep_out_index): chunk ii % G, then [plane][r][crt][z][ii // G]"""
     npl = num_per // G
     chunk_words = planes * 4 * N * npl
     return (ii % G) * chunk_words + (((plane * 2 + r) * 2 + crt) * N + z) * npl + ii // G
