@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_db_relayout_packed(u32* dst, int plane,
     const u64* s = src + ((size_t)zl * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + 2 * jp;
     const size_t nx = (size_t)cm.stride * dim0;  // next local column
     const u64 w00 = s[0], w10 = s[1], w01 = s[nx], w11 = s[nx + 1];
-    u32* unit = dst + ((((size_t)plane * N + (z0 + zl)) * npairs + jp) * chunks + chunk) * 448;
+    u32* unit = dst + packed_unit_offset((size_t)plane * N + (z0 + zl), jp, chunk, npairs, chunks);
     pack_unit_lane(unit, lane, w00, w01, w10, w11);
   }
 }
@@ -76,11 +76,11 @@ __global__ __launch_bounds__(256) void k_db_synth_packed(u32* dst, u64 seed, int
   const int chunks = num_per >> 7, npairs = nj >> 1;
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total_lanes; i += (size_t)gridDim.x * 256) {
     const int lane = (int)(i & 63);
-    size_t t = i >> 6;  // unit index = (zp * npairs + jp) * chunks + chunk
-    const int chunk = (int)(t % chunks);
-    const size_t t2 = t / chunks;
-    const int jp = (int)(t2 % npairs);
-    const size_t zp = t2 / npairs;
+    size_t t = i >> 6;  // unit index in memory order = (zp * chunks + chunk) * npairs + jp (packed_unit_offset)
+    const int jp = (int)(t % npairs);
+    const size_t t2 = t / npairs;
+    const int chunk = (int)(t2 % chunks);
+    const size_t zp = t2 / chunks;
     const size_t ii = (size_t)chunk * 128 + 2 * lane;
     const size_t r0 = (zp * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + 2 * jp;  // (row 2jp, ii)
     const size_t r1 = r0 + (size_t)cm.stride * dim0;                                         // (row 2jp, ii+1)
@@ -110,7 +110,7 @@ __global__ void k_db_read(u64* out, const u64* db, int plane, int z, int ii, int
     const int chunks = num_per >> 7, npairs = nj >> 1;
     const int chunk = ii >> 7, lane = (ii & 127) >> 1, iiofs = ii & 1;
     const u32* unit = reinterpret_cast<const u32*>(db) +
-                      ((((size_t)plane * N + z) * npairs + (jl >> 1)) * chunks + chunk) * 448;
+                      packed_unit_offset((size_t)plane * N + z, jl >> 1, chunk, npairs, chunks);
     out[t] = unpack_word(unit, lane, (jl & 1) * 2 + iiofs);
   } else {
     out[t] = db[(((size_t)plane * N + z) * nj + jl) * num_per + ii];
@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
           if (d.packed) {
             const int chunks = d.num_per >> 7, npairs = d.nj >> 1;
             const u32* unit = reinterpret_cast<const u32*>(d.db) +
-                              ((((size_t)plane * N + z) * npairs + jp) * chunks + (ii >> 7)) * 448;
+                              packed_unit_offset((size_t)plane * N + z, jp, ii >> 7, npairs, chunks);
             cur = unpack_word(unit, (ii & 127) >> 1, a * 2 + b);
           } else {
             cur = d.db[(((size_t)plane * N + z) * d.nj + jl) * d.num_per + ii];
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
     if (d.packed) {
       const int chunks = d.num_per >> 7, npairs = d.nj >> 1;
       u32* unit = reinterpret_cast<u32*>(d.db) +
-                  ((((size_t)plane * N + z) * npairs + jp) * chunks + (ii0 >> 7)) * 448;
+                  packed_unit_offset((size_t)plane * N + z, jp, ii0 >> 7, npairs, chunks);
       pack_unit_lane(unit, (ii0 & 127) >> 1, w[0][k], w[1][k], w[2][k], w[3][k]);
     } else {
 #pragma unroll

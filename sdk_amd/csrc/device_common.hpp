@@ -365,6 +365,14 @@ __device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la
     }
 }
 
+// Dword offset of unit (zp = plane*N + z, row pair jp, 128-column chunk) in the PACKED database.  The units one
+// sweep wave reads (fixed zp and chunk, jp = 0 .. npairs-1) are contiguous: every wave walks ONE sequential stream of
+// npairs * 1792 bytes instead of striding chunks * 1792 bytes between row pairs (measured 9.5 -> 9.0 ms per C2 sweep on
+// the boxes where the strided order was slow, profiles/r01_overlap.md section 7).
+__device__ __forceinline__ size_t packed_unit_offset(size_t zp, int jp, int chunk, int npairs, int chunks) {
+  return ((zp * (size_t)chunks + (size_t)chunk) * (size_t)npairs + (size_t)jp) * 448;
+}
+
 // Packing helpers shared by the writers of the PACKED format.
 __device__ __forceinline__ void pack_unit_lane(u32* unit, int lane, u64 w00, u64 w01, u64 w10, u64 w11) {
   // w{row}{iiofs}: limbs f0..f7 = lo/hi of w00, w01, w10, w11

@@ -178,7 +178,8 @@ void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipS
 // (row 2jp, ii 2l), (2jp, 2l+1), (2jp+1, 2l), (2jp+1, 2l+1); their 8 28-bit limbs
 // (lo, hi of each, in that order) form a 224-bit little-endian string = 7 dwords; dwords 0-3 of all 64
 // lanes are stored first (16 B per lane, one global_load_dwordx4), then dwords 4-6 (12 B per lane).
-// Units are ordered [plane][z][jp][chunk].  12.5 % less HBM traffic than the 8-byte words.
+// Units are ordered [plane][z][chunk][jp] (device_common.hpp packed_unit_offset): the row pairs one sweep wave
+// reads are one sequential stream.  12.5 % less HBM traffic than the 8-byte words.
 struct SweepDesc {
   const u64* db;  // plane 0 of this shard
   const u64* qv;

@@ -133,8 +133,8 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
   const int plane = zp >> POLY_LEN_LOG2;
   if (plane >= d.planes) return;
   const int npairs = d.nj >> 1;
-  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;  // 1792 B = 448 dwords
-  const size_t ustride = (size_t)chunks * 448;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);  // 1792 B = 448 dwords
+  const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
   const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const int nwaves = gridDim.x * 4;
   const int chunks = d.num_per >> 7;
   const int npairs = d.nj >> 1;
-  const size_t ustride = (size_t)chunks * 448;
+  const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
   for (int unit = wave0; unit < units; unit += nwaves) {
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
     const int zp = unit / chunks;
     const int z = zp & (N - 1);
     const int plane = zp >> POLY_LEN_LOG2;
-    const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
+    const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);
     const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
     u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
     for (int jb = 0; jb < npairs; jb += 128) {
@@ -284,8 +284,8 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
   }
   if (plane >= d.planes) return;
   const int npairs = d.nj >> 1;
-  const u32* base = reinterpret_cast<const u32*>(d.db) + ((size_t)zp * npairs * chunks + chunk) * 448;
-  const size_t ustride = (size_t)chunks * 448;
+  const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);
+  const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
   const size_t qoff = (size_t)z * d.dim0 + d.j0;
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;

@@ -22,7 +22,8 @@ class SpiralError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libspiral_hip.so")
+    # SPIRAL_HIP_LIB: load another build of the same C ABI (A/B measurements of kernel or layout changes)
+    return os.environ.get("SPIRAL_HIP_LIB") or os.path.join(_HERE, "libspiral_hip.so")
 
 
 def build_library(force=False):
