@@ -37,12 +37,24 @@ extern "C" {
 #define SP_E_OOM (-3)    /* device or host allocation failed */
 #define SP_E_STATE (-4)  /* call sequence error */
 
+/* Row shards per database: each shard emits partial residues < q < 2^28 that the exchange step sums element-wise in
+ * 32 bits (ncclSum on ncclUint32); 8 * (q - 1) < 2^31, so 8 is the largest shard count that can never overflow.
+ * sp_db_create and the sp_query_sweep_scatter / fold_local family reject larger counts with SP_E_ARG. */
+#define SP_MAX_ROW_SHARDS 8
+
 typedef struct sp_params sp_params_t; /* spiral_rs::params::Params           params.rs:49-82   */
 typedef struct sp_pp sp_pp_t;         /* spiral_rs::client::PublicParameters client.rs:146-152 */
 typedef struct sp_db sp_db_t;         /* the `db: &[u64]` argument of process_query, device-resident */
 typedef struct sp_query sp_query_t;   /* one in-flight query (expanded), for the multi-GPU split */
 
 const char* sp_last_error(void);
+/* Diagnostics: bit mask of the kernels / flows the CALLING THREAD's library calls went through since the last reset
+ * (bit b is named by sp_path_name(b): sweep_packed_persist, from_sweep4, fold_fused, fold_tail_delta,
+ * pipelined_fold_overlap, expand_pruned, ...).  Tests use it to assert that the bytes they compared were produced by
+ * the production code path (e.g. the persistent PACKED sweep + fused fold + fold/sweep overlap at full size) and not
+ * by a silently selected fallback kernel.  reset != 0 clears the mask after reading it. */
+uint64_t sp_paths_taken(int reset);
+const char* sp_path_name(int bit); /* NULL past the last defined bit */
 /* Number of visible HIP devices (0 if none); selects `device` for this thread's subsequent calls. */
 int sp_device_count(void);
 int sp_set_device(int device);
@@ -178,6 +190,48 @@ void* sp_query_stream(sp_query_t*);
  * [0] expand+conversion+folding_neg, [1] db sweep, [2] from_ntt+fold, [3] pack+encode(+D2H). */
 int sp_query_timings(const sp_query_t*, float* ms4);
 
+/* ----------------------------------------------------------------- multi-GPU, collectives inside the library
+ * One process per GPU, the database row-sharded (sp_db_create(params, rank, world)).  The reference has no
+ * multi-node / multi-device code (it is CPU-only); the caller this serves is lib/server's request handler
+ * (lib/server/src/bin/server.rs:98-141), which would call sp_process_query_sharded where it calls process_query
+ * (server.rs:650-655) today -- on every rank, with the same query bytes; rank 0 gets the response.
+ * Built-in transport: RCCL (librccl linked directly): ncclReduceScatter(ncclUint32, ncclSum) of each plane's partial
+ * Regev ciphertexts on the communicator's own stream while the next plane is swept, then ncclAllGather(ncclUint64)
+ * of one locally folded ciphertext per plane per rank.  world must be a power of two <= SP_MAX_ROW_SHARDS.
+ *   rank 0   : sp_comm_unique_id(id)  -> hand the SP_COMM_ID_BYTES bytes to every rank (any side channel)
+ *   all ranks: sp_comm_create(rank, world, id)   (collective: returns when every rank has joined)
+ * One sharded query at a time per communicator (calls are serialised inside; every rank must issue them in the
+ * same order).  *out_len = 0 on ranks other than 0. */
+typedef struct sp_comm sp_comm_t;
+#define SP_COMM_ID_BYTES 128
+int sp_comm_unique_id(uint8_t* id128);
+sp_comm_t* sp_comm_create(int rank, int world, const uint8_t* id128);
+/* Custom transport: the host supplies the two collectives (its own RCCL/MPI setup, or an in-process loopback for
+ * tests).  Both are ENQUEUE operations on `hip_stream` (hipStream_t): they must order their device work after what
+ * is already on that stream and must not block the host on it.  Return 0 on success.
+ *   reduce_scatter_u32: send = world chunks of recv_count u32 each; recv (recv_count u32) = element-wise sum over
+ *                       ranks of chunk[rank]                      (ncclReduceScatter semantics)
+ *   all_gather_u64    : recv = world blocks of send_count u64, block g = rank g's send   (ncclAllGather semantics) */
+typedef struct sp_comm_ops {
+  int (*reduce_scatter_u32)(void* user, const void* send, void* recv, size_t recv_count, void* hip_stream);
+  int (*all_gather_u64)(void* user, const void* send, void* recv, size_t send_count, void* hip_stream);
+  void* user;
+} sp_comm_ops_t;
+sp_comm_t* sp_comm_create_custom(int rank, int world, const sp_comm_ops_t* ops);
+void sp_comm_free(sp_comm_t*);
+int sp_comm_rank(const sp_comm_t*);
+int sp_comm_world(const sp_comm_t*);
+void* sp_comm_stream(sp_comm_t*); /* hipStream_t the collectives are enqueued on */
+int sp_comm_barrier(sp_comm_t*);  /* one tiny all-gather + host wait: every rank has reached this call */
+/* process_query (server.rs:650-741) over a row-sharded database; `shard` = this rank's sp_db_create(params, rank,
+ * world).  Byte-identical to sp_process_query over the unsharded database. */
+int sp_process_query_sharded(sp_comm_t*, const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
+                             const sp_db_t* shard, uint8_t* out, size_t out_cap, size_t* out_len);
+/* milliseconds of the last sharded query on this rank (HIP events on the query stream): [0] the per-plane sweep
+ * launches (the exchanges of the earlier planes run beside them), [1] exchange tail + local fold + all-gather,
+ * [2] reserved */
+int sp_comm_timings(const sp_comm_t*, float* ms3);
+
 /* Stand-alone timed sweep for the roofline measurement: issues the db-sweep launches of one query over `db`
  * (the same kernel and launch shapes sp_process_query uses) `iters` times with the query slice of `q`, HIP events
  * on the launch stream around the whole batch; returns average milliseconds per kernel launch in *ms_per_launch.
@@ -234,6 +288,13 @@ int sp_expand_query(const sp_params_t*, const sp_pp_t*, const uint8_t* query, si
  * entries are scratch in the reference too and are returned unmodified here) */
 int sp_fold_ciphertexts(const sp_params_t*, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
                         const uint64_t* v_folding_neg);
+/* The same fold the way process_query runs it: v_folding_neg is formed on the device as G - v_folding
+ * (get_v_folding_neg, server.rs:505-523) and levels with at least `fused_min_pairs` pairs go through the fused
+ * one-workgroup-per-step kernel (0: the library's default threshold, 1: every level fused); the remaining levels use
+ * the three-launch tree tail.  Result in cts[0 .. 2N); byte-identical to
+ * fold_ciphertexts(cts, v_folding, get_v_folding_neg(v_folding)). */
+int sp_fold_ciphertexts_fused(const sp_params_t*, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
+                              long fused_min_pairs);
 /* server.rs:429-468 pack: v_ct[n*n] raw 2x1, v_w = pp.v_packing -> (n+1) x n NTT */
 int sp_pack(const sp_params_t*, const sp_pp_t*, const uint64_t* v_ct, uint64_t* out);
 /* server.rs:470-503 encode: v_packed[instances] raw (n+1) x n -> response bytes */

@@ -59,7 +59,7 @@ def lib():
             getattr(L, name).restype = C.c_uint64
         for name in ("orc_client_generate_keys", "orc_client_generate_query", "orc_client_decode_response",
                      "orc_item_to_vec", "orc_process_query", "orc_pp_deserialize_flat", "orc_encode",
-                     "orc_process_query_timed"):
+                     "orc_process_query_timed", "orc_process_query_synth"):
             getattr(L, name).restype = C.c_int64
     return _LIB
 
@@ -251,6 +251,28 @@ class Params:
                                          _p(out, u8p), _u64(out.size)))
         return out[:n].tobytes()
 
+    def process_query_synth(self, pp_bytes, q_bytes, seed, fold_classes=None, timed=False):
+        """process_query (server.rs:650-741) over the synthetic database word(i) = synth_word(seed, i) (reference-layout
+        index), generated row by row: response-byte parity at sizes (64-256 GiB encoded) no host buffer holds."""
+        pp = np.frombuffer(pp_bytes, dtype=np.uint8)
+        q = np.frombuffer(q_bytes, dtype=np.uint8)
+        out = np.zeros(self.response_bytes() + 64, dtype=np.uint8)
+        t = (C.c_double * 4)()
+        if fold_classes is None:
+            fold_classes = int(os.environ.get("OMP_NUM_THREADS", "1"))
+        n = _chk(lib().orc_process_query_synth(_vp(self.h), _p(pp, u8p), _u64(pp.size), _p(q, u8p), _u64(q.size),
+                                               _u64(seed), _u64(fold_classes), _p(out, u8p), _u64(out.size), t))
+        return (out[:n].tobytes(), list(t)) if timed else out[:n].tobytes()
+
+    def sweep_synth_row(self, seed, plane, z, v_reg, j0=0, nj=None):
+        """(num_per, 4) partial first-dimension residues of rows [j0, j0 + nj) for one (plane, z) of the synthetic db:
+        columns n0_0 (r0,crt0), n0_1 (r1,crt0), n1_0 (r0,crt1), n1_1 (r1,crt1)"""
+        nj = self.dim0 - j0 if nj is None else nj
+        v = np.ascontiguousarray(v_reg, dtype=np.uint64)
+        out = np.zeros(self.num_per * 4, dtype=np.uint64)
+        lib().orc_sweep_synth_row(_vp(self.h), _u64(seed), _u64(plane), _u64(z), _p(v), _u64(j0), _u64(nj), _p(out))
+        return out.reshape(self.num_per, 4)
+
     def pp_poly_count(self):
         n_pack = self.n * (self.n + 1) * self.t_conv
         if not self.expand_queries:
@@ -321,6 +343,18 @@ class Params:
         _chk(lib().orc_fold_ciphertexts(_vp(self.h), _p(cts), _u64(num_per), _p(v_folding), _p(v_folding_neg), _u64(nu)))
         return cts
 
+    def from_ntt_fold_parallel(self, cts_ntt, v_folding, v_folding_neg, nu=None, classes=1):
+        """from_ntt of every ciphertext + fold_ciphertexts with the tree split over `classes` threads (results are
+        those of the sequential fold); returns the folded raw ciphertext (2N words)"""
+        cts = np.ascontiguousarray(cts_ntt, dtype=np.uint64)
+        nu = self.db_dim_2 if nu is None else nu
+        out = np.zeros(2 * self.poly_len, dtype=np.uint64)
+        _chk(lib().orc_from_ntt_fold_parallel(_vp(self.h), _p(cts), _u64(cts.size // (2 * self.ntt_words)),
+                                              _p(np.ascontiguousarray(v_folding, dtype=np.uint64)),
+                                              _p(np.ascontiguousarray(v_folding_neg, dtype=np.uint64)), _u64(nu),
+                                              _u64(classes), _p(out)))
+        return out
+
     def pack(self, v_ct, v_w):
         v_ct = np.ascontiguousarray(v_ct, dtype=np.uint64)
         v_w = np.ascontiguousarray(v_w, dtype=np.uint64)
@@ -347,6 +381,20 @@ def sweep_rows(db_zslice, v_firstdim_zslice, nz, dim0, num_per, q0=268369921, q1
     out = np.zeros(nz * num_per * 4, dtype=np.uint64)
     lib().orc_sweep_rows(_p(db_zslice), _p(v), _u64(nz), _u64(dim0), _u64(num_per), _u64(q0), _u64(q1), _p(out))
     return out.reshape(nz, num_per, 4)
+
+
+def sweep_rows_avx2(db_zslice, v_firstdim_zslice, nz, dim0, num_per, q0=268369921, q1=249561089):
+    """all-core AVX2 form of sweep_rows (same results), for bench.py's cpu_baseline"""
+    db_zslice = np.ascontiguousarray(db_zslice, dtype=np.uint64)
+    v = np.ascontiguousarray(v_firstdim_zslice, dtype=np.uint64)
+    out = np.zeros(nz * num_per * 4, dtype=np.uint64)
+    lib().orc_sweep_rows_avx2(_p(db_zslice), _p(v), _u64(nz), _u64(dim0), _u64(num_per), _u64(q0), _u64(q1), _p(out))
+    return out.reshape(nz, num_per, 4)
+
+
+def synth_word(seed, idx):
+    lib().orc_synth_word.restype = C.c_uint64
+    return int(lib().orc_synth_word(_u64(seed), _u64(idx)))
 
 
 class Client:

@@ -5,6 +5,9 @@
 // reference's own layouts (PolyMatrixRaw: rows*cols*N u64; PolyMatrixNTT:
 // rows*cols*crt*N u64, poly.rs:31-35, 263-265).
 // ============================================================================
+#include <immintrin.h>
+#include <omp.h>
+
 #include <chrono>
 #include <cstring>
 #include <string>
@@ -421,6 +424,93 @@ void orc_sweep_rows(const uint64_t* db_zslice, const uint64_t* v_firstdim_zslice
     }
 }
 
+// "All-core" CPU form of the same sweep, for bench.py's cpu_baseline (not used for parity): spiral-rs's own layout
+// and loop nest (server.rs:155-221), with the u128 scalar accumulation replaced by AVX2 u64 lanes the way lib/server
+// does it (lib/server/src/compute/dot_product.rs:59-95: _mm256_mul_epu32 of the low / high 32-bit halves, u64 lane
+// sums) and the rows z spread over all cores (lib/server/src/server.rs:53-55 parallelises instance x trial; z-blocks
+// are the finer independent unit).  Safe reduction cadence: products are < 2^56, each of the 4 lanes sums every 4th
+// row, so lanes are folded mod q every 4 * 64 rows (dot_product.rs:10 MAX_SUMMED = 64 additions per lane) -- unlike
+// the reference's counter, which is reset before it can fire, this one is per accumulator.
+// Same output format as orc_sweep_rows; the results are identical for words whose limbs are residues (< q), which is
+// what the databases and queries hold (tests/test_oracle_kat.py).
+}  // extern "C"
+template <bool FIXED>
+static void sweep_rows_avx2_impl(const uint64_t* db_zslice, const uint64_t* v_firstdim_zslice, uint64_t nz, uint64_t dim0,
+                                 uint64_t num_per, uint64_t q0_, uint64_t q1_, uint64_t* out) {
+  // FIXED: the spiral moduli as compile-time constants (util.rs:245-248) so that % compiles to a multiply
+  const u64 q0 = FIXED ? 268369921ULL : q0_, q1 = FIXED ? 249561089ULL : q1_;
+#pragma omp parallel
+  {
+    std::vector<u64> qa(2 * dim0 + 8, 0);
+    u64* a0 = qa.data();
+    u64* a1 = qa.data() + dim0 + 4;
+#pragma omp for schedule(static)
+    for (uint64_t z = 0; z < nz; z++) {
+      // de-interleave the query slice once per z: a0[j], a1[j]
+      const u64* a = v_firstdim_zslice + z * dim0 * 2;
+      for (uint64_t j = 0; j < dim0; j++) {
+        a0[j] = a[2 * j];
+        a1[j] = a[2 * j + 1];
+      }
+      for (uint64_t i = 0; i < num_per; i++) {
+        const u64* b = db_zslice + (z * num_per + i) * dim0;
+        u64 r[4] = {0, 0, 0, 0};
+        uint64_t j = 0;
+        while (j + 4 <= dim0) {
+          const uint64_t jend = std::min<uint64_t>(dim0 & ~(uint64_t)3, j + 4 * 64);
+          __m256i s00 = _mm256_setzero_si256(), s01 = s00, s10 = s00, s11 = s00;
+          for (; j < jend; j += 4) {
+            const __m256i vb = _mm256_loadu_si256((const __m256i*)(b + j));
+            const __m256i va0 = _mm256_loadu_si256((const __m256i*)(a0 + j));
+            const __m256i va1 = _mm256_loadu_si256((const __m256i*)(a1 + j));
+            const __m256i vbh = _mm256_srli_epi64(vb, 32);
+            s00 = _mm256_add_epi64(s00, _mm256_mul_epu32(va0, vb));
+            s01 = _mm256_add_epi64(s01, _mm256_mul_epu32(va1, vb));
+            s10 = _mm256_add_epi64(s10, _mm256_mul_epu32(_mm256_srli_epi64(va0, 32), vbh));
+            s11 = _mm256_add_epi64(s11, _mm256_mul_epu32(_mm256_srli_epi64(va1, 32), vbh));
+          }
+          alignas(32) u64 l[4][4];
+          _mm256_store_si256((__m256i*)l[0], s00);
+          _mm256_store_si256((__m256i*)l[1], s01);
+          _mm256_store_si256((__m256i*)l[2], s10);
+          _mm256_store_si256((__m256i*)l[3], s11);
+          // each lane sum is < 64 * 2^64 / ... : 64 products of two 32-bit values can reach 2^70 for arbitrary words, so
+          // lanes are only trusted for limbs < 2^29 (the caller's words are residues < q < 2^28): 64 * 2^56 = 2^62
+          r[0] = (r[0] + l[0][0] % q0 + l[0][1] % q0 + l[0][2] % q0 + l[0][3] % q0) % q0;
+          r[1] = (r[1] + l[1][0] % q0 + l[1][1] % q0 + l[1][2] % q0 + l[1][3] % q0) % q0;
+          r[2] = (r[2] + l[2][0] % q1 + l[2][1] % q1 + l[2][2] % q1 + l[2][3] % q1) % q1;
+          r[3] = (r[3] + l[3][0] % q1 + l[3][1] % q1 + l[3][2] % q1 + l[3][3] % q1) % q1;
+        }
+        for (; j < dim0; j++) {  // ragged tail
+          const u64 bw = b[j];
+          r[0] = (r[0] + (u64)(u32)a0[j] * (u64)(u32)bw % q0) % q0;
+          r[1] = (r[1] + (u64)(u32)a1[j] * (u64)(u32)bw % q0) % q0;
+          r[2] = (r[2] + (a0[j] >> 32) * (bw >> 32) % q1) % q1;
+          r[3] = (r[3] + (a1[j] >> 32) * (bw >> 32) % q1) % q1;
+        }
+        u64* o = out + (z * num_per + i) * 4;
+        o[0] = r[0];
+        o[1] = r[1];
+        o[2] = r[2];
+        o[3] = r[3];
+      }
+    }
+  }
+}
+extern "C" {
+void orc_sweep_rows_avx2(const uint64_t* db_zslice, const uint64_t* v_firstdim_zslice, uint64_t nz, uint64_t dim0,
+                         uint64_t num_per, uint64_t q0, uint64_t q1, uint64_t* out) {
+  if (q0 == 268369921ULL && q1 == 249561089ULL)
+    sweep_rows_avx2_impl<true>(db_zslice, v_firstdim_zslice, nz, dim0, num_per, q0, q1, out);
+  else
+    sweep_rows_avx2_impl<false>(db_zslice, v_firstdim_zslice, nz, dim0, num_per, q0, q1, out);
+}
+
+// from_ntt of num_per ciphertexts + fold_ciphertexts, the tree split over `classes` threads (see fold_parallel): the
+// all-core form of server.rs:707-711 for bench.py's cpu_baseline.  cts_ntt: [num_per] 2x1 NTT; result raw ct -> out[2N]
+int orc_from_ntt_fold_parallel(void* h, const uint64_t* cts_ntt, uint64_t num_per, const uint64_t* v_folding,
+                               const uint64_t* v_folding_neg, uint64_t nu, uint64_t classes, uint64_t* out);
+
 // fold: cts[num_per] raw 2x1 (in/out; result in cts[0]); v_folding / v_folding_neg [nu] 2 x 2t_gsw NTT
 int orc_fold_ciphertexts(void* h, uint64_t* cts, uint64_t num_per, const uint64_t* v_folding, const uint64_t* v_folding_neg,
                          uint64_t nu) {
@@ -528,6 +618,169 @@ int64_t orc_process_query_timed(void* h, const uint8_t* pp_bytes, uint64_t pp_le
   memcpy(out, r.data(), r.size());
   return (int64_t)r.size();
   ORC_CATCH(-1)
+}
+
+// ---------------------------------------------------------------------------------------------
+// process_query (server.rs:650-741) over a SYNTHETIC database that is never materialised: reference-layout
+// word index i holds synth_word(seed, i) -- the same splitmix64-style hash the product's sp_synth_word /
+// sp_db_fill_synthetic use (a test-data generator, not reference code; tests pin the two copies against each
+// other).  This is what makes response-byte parity checkable at the full benchmark sizes (64-256 GiB of
+// encoded database): the u128 multiply-accumulate of multiply_reg_by_database runs row by row (z) over words
+// generated on the fly, everything after it is the unmodified restatement.
+// Parallelism (OpenMP) is over independent pieces only and cannot change results: sweep rows z; from_ntt per
+// ciphertext; the fold tree split into G residue classes i = g (mod G) -- each class is itself a call of the
+// unmodified fold_ciphertexts with the top nu_2 - log2 G selector matrices (pairs (i, i + half) stay inside a
+// class while half is a multiple of G), followed by one fold_ciphertexts over the G class results with the
+// remaining log2 G matrices (server.rs:407-424 evaluated in a different order, same operations).
+static inline u64 synth_word_ref(u64 seed, u64 idx) {
+  u64 z = seed + 0x9E3779B97F4A7C15ULL * (idx + 1);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+  z ^= z >> 31;
+  u64 lo = (u32)z % (u32)268369921u;
+  u64 hi = (u32)(z >> 32) % (u32)249561089u;
+  return lo | (hi << 32);
+}
+uint64_t orc_synth_word(uint64_t seed, uint64_t idx) { return synth_word_ref(seed, idx); }
+
+// first-dimension outputs of one plane over the synthetic database; rows j outside [j0, j0 + nj) are skipped
+// (a row shard's partial sums); out[i] as multiply_reg_by_database writes them (server.rs:205-217)
+static void sweep_plane_synth(const Params& p, u64 seed, size_t plane, const u64* v_reg, size_t j0, size_t nj,
+                              std::vector<PolyMatrixNTT>& out) {
+  const size_t dim0 = (size_t)1 << p.db_dim_1, num_per = (size_t)1 << p.db_dim_2, N = p.poly_len;
+#pragma omp parallel
+  {
+    std::vector<u64> row(num_per * nj), vq(nj * 2), res(num_per * 4);
+#pragma omp for schedule(dynamic, 4)
+    for (size_t z = 0; z < N; z++) {
+      const u64 base = ((u64)plane * N + z) * num_per;
+      for (size_t i = 0; i < num_per; i++)
+        for (size_t j = 0; j < nj; j++) row[i * nj + j] = synth_word_ref(seed, (base + i) * dim0 + j0 + j);
+      memcpy(vq.data(), v_reg + (z * dim0 + j0) * 2, nj * 2 * 8);
+      orc_sweep_rows(row.data(), vq.data(), 1, nj, num_per, p.moduli[0], p.moduli[1], res.data());
+      for (size_t i = 0; i < num_per; i++) {
+        u64* d = out[i].data.data();
+        d[0 * N + z] = res[i * 4 + 0];          // n0_0: row 0, crt 0
+        d[2 * N + 0 * N + z] = res[i * 4 + 1];  // n0_1: row 1, crt 0
+        d[1 * N + z] = res[i * 4 + 2];          // n1_0: row 0, crt 1
+        d[2 * N + 1 * N + z] = res[i * 4 + 3];  // n1_1: row 1, crt 1
+      }
+    }
+  }
+}
+
+static void fold_parallel(const Params& p, std::vector<PolyMatrixRaw>& cts, const std::vector<PolyMatrixNTT>& vf,
+                          const std::vector<PolyMatrixNTT>& vfn, size_t classes) {
+  const size_t num_per = cts.size();
+  size_t G = 1, lg = 0;
+  while (G * 2 <= classes && G * 2 <= num_per / 2) { G *= 2; lg++; }
+  if (G == 1) {
+    fold_ciphertexts(p, cts, vf, vfn);
+    return;
+  }
+  const std::vector<PolyMatrixNTT> vf_loc(vf.begin() + lg, vf.end()), vfn_loc(vfn.begin() + lg, vfn.end());
+  const std::vector<PolyMatrixNTT> vf_top(vf.begin(), vf.begin() + lg), vfn_top(vfn.begin(), vfn.begin() + lg);
+  std::vector<PolyMatrixRaw> tops(G, PolyMatrixRaw(&p, 2, 1));
+#pragma omp parallel for schedule(dynamic, 1)
+  for (size_t g = 0; g < G; g++) {
+    std::vector<PolyMatrixRaw> mine;
+    for (size_t i = g; i < num_per; i += G) mine.push_back(cts[i]);
+    fold_ciphertexts(p, mine, vf_loc, vfn_loc);
+    tops[g] = mine[0];
+  }
+  fold_ciphertexts(p, tops, vf_top, vfn_top);
+  cts[0] = tops[0];
+}
+
+int orc_from_ntt_fold_parallel(void* h, const uint64_t* cts_ntt, uint64_t num_per, const uint64_t* v_folding,
+                               const uint64_t* v_folding_neg, uint64_t nu, uint64_t classes, uint64_t* out) {
+  ORC_TRY
+  const Params& p = *(Params*)h;
+  const size_t nw = 2 * p.crt_count * p.poly_len, words = 2 * 2 * p.t_gsw * p.crt_count * p.poly_len;
+  std::vector<PolyMatrixNTT> vf, vfn;
+  for (size_t i = 0; i < nu; i++) {
+    vf.push_back(ntt_from_flat(&p, 2, 2 * p.t_gsw, v_folding + i * words));
+    vfn.push_back(ntt_from_flat(&p, 2, 2 * p.t_gsw, v_folding_neg + i * words));
+  }
+  std::vector<PolyMatrixRaw> raw(num_per, PolyMatrixRaw(&p, 2, 1));
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < num_per; i++) from_ntt(raw[i], ntt_from_flat(&p, 2, 1, cts_ntt + i * nw));
+  fold_parallel(p, raw, vf, vfn, classes ? classes : 1);
+  memcpy(out, raw[0].data.data(), 2 * p.poly_len * 8);
+  return 0;
+  ORC_CATCH(-1)
+}
+
+// t_out[4]: seconds in expand(+folding_neg), sweep, from_ntt+fold, pack+encode.  fold_classes: parallel split of the
+// fold tree (1 = the reference's sequential order).
+int64_t orc_process_query_synth(void* h, const uint8_t* pp_bytes, uint64_t pp_len, const uint8_t* q_bytes,
+                                uint64_t q_len, uint64_t seed, uint64_t fold_classes, uint8_t* out, uint64_t cap,
+                                double* t_out) {
+  ORC_TRY
+  using clk = std::chrono::steady_clock;
+  auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+  const Params& p = *(Params*)h;
+  PublicParameters pp = PublicParameters::deserialize(p, pp_bytes, pp_len);
+  Query q = Query::deserialize(p, q_bytes, q_len);
+  const size_t dim0 = (size_t)1 << p.db_dim_1, num_per = (size_t)1 << p.db_dim_2;
+  for (int i = 0; i < 4; i++) t_out[i] = 0;
+  auto t0 = clk::now();
+  std::vector<u64> v_reg;
+  std::vector<PolyMatrixNTT> v_folding;
+  if (p.expand_queries) {
+    expand_query(p, pp, q, v_reg, v_folding);
+  } else {
+    v_reg = q.v_buf;
+    for (auto& x : q.v_ct) v_folding.push_back(to_ntt_alloc(x));
+  }
+  std::vector<PolyMatrixNTT> v_folding_neg = get_v_folding_neg(p, v_folding);
+  t_out[0] = secs(t0, clk::now());
+  std::vector<PolyMatrixRaw> v_packed(p.instances);
+  std::vector<PolyMatrixNTT> inter;
+  std::vector<PolyMatrixRaw> inter_raw;
+  for (size_t i = 0; i < num_per; i++) {
+    inter.emplace_back(&p, 2, 1);
+    inter_raw.emplace_back(&p, 2, 1);
+  }
+  for (size_t instance = 0; instance < p.instances; instance++) {
+    std::vector<PolyMatrixRaw> v_ct;
+    for (size_t trial = 0; trial < p.n * p.n; trial++) {
+      auto a = clk::now();
+      sweep_plane_synth(p, seed, instance * p.n * p.n + trial, v_reg.data(), 0, dim0, inter);
+      auto b = clk::now();
+#pragma omp parallel for schedule(static)
+      for (size_t i = 0; i < num_per; i++) from_ntt(inter_raw[i], inter[i]);
+      fold_parallel(p, inter_raw, v_folding, v_folding_neg, fold_classes ? fold_classes : 1);
+      auto c = clk::now();
+      t_out[1] += secs(a, b);
+      t_out[2] += secs(b, c);
+      v_ct.push_back(inter_raw[0]);
+    }
+    auto a = clk::now();
+    v_packed[instance] = from_ntt_alloc(pack_dispatch(p, v_ct, pp.v_packing));
+    t_out[3] += secs(a, clk::now());
+  }
+  auto a = clk::now();
+  std::vector<uint8_t> r = encode(p, v_packed);
+  t_out[3] += secs(a, clk::now());
+  if (r.size() > cap) return -(int64_t)r.size();
+  memcpy(out, r.data(), r.size());
+  return (int64_t)r.size();
+  ORC_CATCH(-1)
+}
+
+// The partial first-dimension residues a row shard [j0, j0 + nj) contributes for one (plane, z): out[ii*4 + which]
+// (which as orc_sweep_rows) -- sampled parity of the multi-GPU partial buffer at sizes no host database can hold.
+void orc_sweep_synth_row(void* h, uint64_t seed, uint64_t plane, uint64_t z, const uint64_t* v_reg, uint64_t j0,
+                         uint64_t nj, uint64_t* out) {
+  const Params& p = *(Params*)h;
+  const size_t dim0 = (size_t)1 << p.db_dim_1, num_per = (size_t)1 << p.db_dim_2, N = p.poly_len;
+  std::vector<u64> row(num_per * nj);
+  const u64 base = ((u64)plane * N + z) * num_per;
+#pragma omp parallel for schedule(static)
+  for (size_t i = 0; i < num_per; i++)
+    for (size_t j = 0; j < nj; j++) row[i * nj + j] = synth_word_ref(seed, (base + i) * dim0 + j0 + j);
+  orc_sweep_rows(row.data(), v_reg + (z * dim0 + j0) * 2, 1, nj, num_per, p.moduli[0], p.moduli[1], out);
 }
 
 }  // extern "C"

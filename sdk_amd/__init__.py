@@ -19,6 +19,7 @@ from .spiral import (  # noqa: F401
     encode,
     expand_query,
     fold_ciphertexts,
+    fold_ciphertexts_fused,
     from_ntt,
     get_v_folding_neg,
     lib,
@@ -29,6 +30,7 @@ from .spiral import (  # noqa: F401
     ntt_inverse,
     pack,
     params_from_json,
+    paths_taken,
     process_query,
     process_query_batch,
     regev_to_gsw,

@@ -104,6 +104,20 @@ extern "C" {
 
 const char* sp_last_error(void) { return g_last_error.c_str(); }
 
+uint64_t sp_paths_taken(int reset) { return paths_taken(reset != 0); }
+// internal hooks for comm.cpp (not declared in the public header)
+void sp_set_last_error_(const char* msg) { g_last_error = msg ? msg : ""; }
+void sp_note_path_(uint64_t bits) { note_path(bits); }
+
+const char* sp_path_name(int bit) {
+  static const char* names[] = {"sweep_packed_persist", "sweep_packed", "sweep_wide", "sweep_narrow", "sweep_batch",
+                                "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
+                                "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
+                                "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
+                                "rccl_in_library", "fold_fused_lowreg"};
+  return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
+}
+
 int sp_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) {
@@ -191,6 +205,7 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
       d->j0 = 0;
     } else {
       need(p.dim0() % (size_t)num_shards == 0, "dim0 not divisible by num_shards");
+      need(num_shards <= SP_MAX_ROW_SHARDS, "at most SP_MAX_ROW_SHARDS (8) row shards: the partial residues are summed in 32 bits");
       d->shard = shard;
       d->num_shards = num_shards;
       d->nj = (int)(p.dim0() / num_shards);
@@ -514,8 +529,8 @@ int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
     need(q->rows_nj == 0 || (db->col_G == 1 && db->j0 == q->rows_j0 && db->nj == q->rows_nj),
          "the query was expanded for another row shard (sp_query_begin_for_db)");
     const Params& p = q->params->p;
-    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
-         "G must be a power of two <= num_per and equal to the db's num_shards");
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G && G <= SP_MAX_ROW_SHARDS,
+         "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS) and equal to the db's num_shards");
     need(db->col_G == 1, "sweep_scatter works on row shards");
     check_device(db->device);
     Workspace& W = *q->ws;
@@ -534,8 +549,8 @@ int sp_query_sweep_scatter_plane(sp_query_t* q, const sp_db_t* db, int G, int pl
     need(q->rows_nj == 0 || (db->col_G == 1 && db->j0 == q->rows_j0 && db->nj == q->rows_nj),
          "the query was expanded for another row shard (sp_query_begin_for_db)");
     const Params& p = q->params->p;
-    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G,
-         "G must be a power of two <= num_per and equal to the db's num_shards");
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G && G <= SP_MAX_ROW_SHARDS,
+         "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS) and equal to the db's num_shards");
     need(db->col_G == 1, "sweep_scatter works on row shards");
     need(plane >= 0 && (size_t)plane < p.planes(), "plane out of range");
     need(q->state == 1 && q->next_plane == plane, "sp_query_sweep_scatter_plane: planes must be swept in order after begin");
@@ -563,7 +578,8 @@ int sp_query_fold_local(sp_query_t* q, const void* reduced_chunk, int G) {
     need(q && reduced_chunk, "null argument");
     need(q->state == 2, "sp_query_fold_local: sweep has not run");
     const Params& p = q->params->p;
-    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per(), "bad G");
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && G <= SP_MAX_ROW_SHARDS,
+         "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS)");
     run_fold_local(*q->ws, (const u32*)reduced_chunk, G);
     q->state = 4;
   });
@@ -572,7 +588,8 @@ int sp_query_fold_local_plane(sp_query_t* q, const void* reduced_plane_chunk, in
   return guarded([&] {
     need(q && reduced_plane_chunk, "null argument");
     const Params& p = q->params->p;
-    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per(), "bad G");
+    need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && G <= SP_MAX_ROW_SHARDS,
+         "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS)");
     need(plane >= 0 && (size_t)plane < p.planes(), "plane out of range");
     // plane `plane` must have been swept (its exchange is the caller's to order on sp_query_stream2)
     need((q->state == 1 && plane < q->next_plane) || q->state == 2, "sp_query_fold_local_plane: plane has not been swept");
@@ -1086,7 +1103,6 @@ int sp_fold_ciphertexts(const sp_params_t* h, uint64_t* cts, size_t num_per, con
     size_t further = 0;
     while (((size_t)1 << further) < num_per) further++;
     if (further == 0) return;
-    need(further <= p.db_dim_2 || true, "");
     const size_t two_t = 2 * p.t_gsw;
     Scoped W(h);
     W->ensure_expand();
@@ -1114,6 +1130,47 @@ int sp_fold_ciphertexts(const sp_params_t* h, uint64_t* cts, size_t num_per, con
     u64* res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
     W->fused_min_pairs = saved;
     W->delta_tail = true;
+    download_raw(*W, res, 2 * POLY_LEN, cts);
+  });
+}
+
+int sp_fold_ciphertexts_fused(const sp_params_t* h, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
+                              long fused_min_pairs) {
+  return guarded([&] {
+    need(h && cts && v_folding, "null argument");
+    const Params& p = h->p;
+    need(num_per >= 1 && (num_per & (num_per - 1)) == 0, "num_per must be a power of two");
+    size_t further = 0;
+    while (((size_t)1 << further) < num_per) further++;
+    if (further == 0) return;
+    const size_t two_t = 2 * p.t_gsw;
+    Scoped W(h);
+    W->ensure_expand();
+    W->foldX.ensure(num_per * 2 * POLY_LEN);
+    W->foldY.ensure(std::max<size_t>(num_per / 2, 1) * 2 * POLY_LEN);
+    W->fold_dig.ensure(num_per * two_t * 2 * POLY_LEN);
+    W->fold_ntt.ensure(std::max<size_t>(num_per / 2, 1) * 2 * 2 * POLY_LEN);
+    W->fold_mats.ensure(further * 2 * 2 * two_t * 2 * POLY_LEN);
+    DevBuf<u64> tmp;
+    DevBuf<u32> dF;
+    upload_ntt(*W, v_folding, further * 2 * two_t * 2 * POLY_LEN, dF, tmp);
+    for (size_t d = 0; d < further; d++)
+      for (size_t r = 0; r < 2; r++) {
+        u32* row = W->fold_mats.p + ((d * 2 + r) * 2 * two_t) * 2 * POLY_LEN;
+        HIP_CHECK(hipMemcpyAsync(row + two_t * 2 * POLY_LEN, dF.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
+      }
+    launch_folding_neg(W->D->T, W->fold_mats.p, W->D->gadget_gsw.p, (int)further, (int)two_t, W->stream);
+    HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
+    const long saved = W->fused_min_pairs;
+    if (fused_min_pairs > 0) W->fused_min_pairs = fused_min_pairs;
+    u64* res = nullptr;
+    try {
+      res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
+    } catch (...) {
+      W->fused_min_pairs = saved;
+      throw;
+    }
+    W->fused_min_pairs = saved;
     download_raw(*W, res, 2 * POLY_LEN, cts);
   });
 }

@@ -1,0 +1,273 @@
+// Multi-GPU answer path behind the C ABI: the row-sharded process_query with its exchange step issued by the library
+// itself (RCCL over xGMI, linked directly) instead of by the caller.  One process per GPU; every rank calls
+// sp_process_query_sharded with the same query, rank 0 receives the response.
+//
+// Reference shape: the reference is single-node CPU code with no collectives; the host that
+// would call this is lib/server's request loop (lib/server/src/bin/server.rs:98-141), which today calls one
+// process_query per request (server.rs:650-655).  The flow:
+//
+//   every rank : Query::deserialize + expand_query pruned to the shard's rows          (sp_query_begin_for_db)
+//   per plane p: sweep the shard's rows -> partial residues, columns interleaved by destination rank
+//                reduce-scatter (ncclSum, u32) of plane p on the communicator's stream WHILE plane p+1 is swept
+//   every rank : % q, from_ntt, the top nu_2 - log2 G fold levels on its num_per / G columns (sp_query_fold_local)
+//   all-gather : one ciphertext per plane per rank (G * planes * 32 KiB)
+//   rank 0     : the last log2 G fold levels, pack, encode                              (sp_query_finish_gathered)
+//
+// Everything is ordered with HIP events between the query's stream and the communicator's stream; the host only
+// waits once, for the response (rank 0) or for the rank's last enqueued work (other ranks).
+// This unit uses nothing but the public C ABI of the library + HIP + RCCL: it is exactly what a host program
+// driving sp_query_* itself would do.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/spiral_hip.h"
+
+extern "C" void sp_set_last_error_(const char* msg);  // capi.cpp
+extern "C" void sp_note_path_(uint64_t bits);         // capi.cpp
+
+namespace {
+
+struct Fail {
+  int rc;
+  std::string msg;
+};
+void hip_ok(hipError_t e, const char* what) {
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw Fail{SP_E_HIP, std::string(what) + ": " + hipGetErrorString(e)};
+  }
+}
+void nccl_ok(ncclResult_t r, const char* what) {
+  if (r != ncclSuccess) throw Fail{SP_E_HIP, std::string(what) + ": " + ncclGetErrorString(r)};
+}
+void sp_ok(int rc, const char* what) {
+  if (rc != SP_OK) throw Fail{rc, std::string(what) + ": " + sp_last_error()};
+}
+
+}  // namespace
+
+struct sp_comm {
+  int rank = 0, world = 1, device = 0;
+  ncclComm_t nccl = nullptr;      // built-in transport
+  sp_comm_ops_t ops{};            // custom transport (ops.reduce_scatter_u32 != nullptr)
+  bool custom = false;
+  hipStream_t stream = nullptr;   // the exchange stream: collectives are enqueued here, in the same order on every rank
+  std::vector<hipEvent_t> ev_plane;
+  hipEvent_t ev_x = nullptr, ev_f = nullptr, ev_g = nullptr, ev_t[3] = {nullptr, nullptr, nullptr};
+  void* mine = nullptr;           // this rank's summed chunk of every plane: [plane][r][crt][z][ii / G] u32
+  size_t mine_bytes = 0;
+  void* gathered = nullptr;       // [g][plane][2][N] u64
+  size_t gathered_bytes = 0;
+  float ms[3] = {0, 0, 0};
+  std::mutex mu;                  // one sharded query at a time per communicator (collective order must match on all ranks)
+
+  int reduce_scatter(const void* send, void* recv, size_t recv_count) {
+    if (custom) return ops.reduce_scatter_u32(ops.user, send, recv, recv_count, (void*)stream);
+    nccl_ok(ncclReduceScatter(send, recv, recv_count, ncclUint32, ncclSum, nccl, stream), "ncclReduceScatter");
+    return 0;
+  }
+  int all_gather(const void* send, void* recv, size_t send_count) {
+    if (custom) return ops.all_gather_u64(ops.user, send, recv, send_count, (void*)stream);
+    nccl_ok(ncclAllGather(send, recv, send_count, ncclUint64, nccl, stream), "ncclAllGather");
+    return 0;
+  }
+  void ensure(void*& p, size_t& have, size_t need) {
+    if (have >= need) return;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    have = 0;
+    hipError_t e = hipMalloc(&p, need);
+    if (e != hipSuccess) {
+      (void)hipGetLastError();
+      throw Fail{SP_E_OOM, "hipMalloc of the exchange buffer failed"};
+    }
+    have = need;
+  }
+  ~sp_comm() {
+    if (stream) (void)hipStreamSynchronize(stream);
+    if (nccl) (void)ncclCommDestroy(nccl);
+    for (auto e : ev_plane)
+      if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : {ev_x, ev_f, ev_g, ev_t[0], ev_t[1], ev_t[2]})
+      if (e) (void)hipEventDestroy(e);
+    if (mine) (void)hipFree(mine);
+    if (gathered) (void)hipFree(gathered);
+    if (stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+template <typename F>
+static int guarded_comm(F&& f) {
+  try {
+    f();
+    return SP_OK;
+  } catch (const Fail& e) {
+    sp_set_last_error_(e.msg.c_str());
+    return e.rc;
+  } catch (const std::exception& e) {
+    sp_set_last_error_(e.what());
+    return SP_E_ARG;
+  }
+}
+
+static sp_comm_t* comm_new(int rank, int world) {
+  if (world < 1 || world > SP_MAX_ROW_SHARDS || (world & (world - 1)) != 0 || rank < 0 || rank >= world)
+    throw Fail{SP_E_ARG, "world must be a power of two <= SP_MAX_ROW_SHARDS and 0 <= rank < world"};
+  auto c = new sp_comm();
+  try {
+    c->rank = rank;
+    c->world = world;
+    hip_ok(hipGetDevice(&c->device), "hipGetDevice");
+    hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
+    for (hipEvent_t* e : {&c->ev_x, &c->ev_f, &c->ev_g}) hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
+    for (auto& e : c->ev_t) hip_ok(hipEventCreate(&e), "hipEventCreate");
+  } catch (...) {
+    delete c;
+    throw;
+  }
+  return c;
+}
+
+extern "C" {
+
+int sp_comm_unique_id(uint8_t* id128) {
+  return guarded_comm([&] {
+    if (!id128) throw Fail{SP_E_ARG, "null argument"};
+    static_assert(SP_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "id size");
+    ncclUniqueId id;
+    nccl_ok(ncclGetUniqueId(&id), "ncclGetUniqueId");
+    memcpy(id128, id.internal, SP_COMM_ID_BYTES);
+  });
+}
+
+sp_comm_t* sp_comm_create(int rank, int world, const uint8_t* id128) {
+  sp_comm_t* out = nullptr;
+  int rc = guarded_comm([&] {
+    if (!id128) throw Fail{SP_E_ARG, "null argument"};
+    sp_comm_t* c = comm_new(rank, world);
+    ncclUniqueId id;
+    memcpy(id.internal, id128, SP_COMM_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&c->nccl, world, id, rank);
+    if (r != ncclSuccess) {
+      c->nccl = nullptr;
+      delete c;
+      nccl_ok(r, "ncclCommInitRank");
+    }
+    out = c;
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+
+sp_comm_t* sp_comm_create_custom(int rank, int world, const sp_comm_ops_t* ops) {
+  sp_comm_t* out = nullptr;
+  int rc = guarded_comm([&] {
+    if (!ops || !ops->reduce_scatter_u32 || !ops->all_gather_u64) throw Fail{SP_E_ARG, "ops must provide both collectives"};
+    sp_comm_t* c = comm_new(rank, world);
+    c->ops = *ops;
+    c->custom = true;
+    out = c;
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+
+void sp_comm_free(sp_comm_t* c) { delete c; }
+int sp_comm_rank(const sp_comm_t* c) { return c ? c->rank : -1; }
+int sp_comm_world(const sp_comm_t* c) { return c ? c->world : 0; }
+void* sp_comm_stream(sp_comm_t* c) { return c ? (void*)c->stream : nullptr; }
+
+int sp_comm_timings(const sp_comm_t* c, float* ms3) {
+  if (!c || !ms3) return SP_E_ARG;
+  memcpy(ms3, c->ms, sizeof(c->ms));
+  return SP_OK;
+}
+
+int sp_process_query_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query,
+                             size_t query_len, const sp_db_t* shard, uint8_t* out, size_t out_cap, size_t* out_len) {
+  if (!c || !h || !pp || !query || !shard || !out_len || (c->rank == 0 && !out)) {
+    sp_set_last_error_("null argument");
+    return SP_E_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  sp_query_t* q = nullptr;
+  int rc = guarded_comm([&] {
+    const int G = c->world;
+    int dev = 0;
+    hip_ok(hipGetDevice(&dev), "hipGetDevice");
+    if (dev != c->device) throw Fail{SP_E_ARG, "the communicator was created on another HIP device"};
+    const size_t planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
+    if ((size_t)G > ((size_t)1 << sp_params_get(h, "db_dim_2")))
+      throw Fail{SP_E_ARG, "more ranks than second-dimension columns (num_per): use fewer shards"};
+    if (c->ev_plane.size() < planes) {
+      const size_t old = c->ev_plane.size();
+      c->ev_plane.resize(planes, nullptr);
+      for (size_t i = old; i < planes; i++) hip_ok(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming), "hipEventCreate");
+    }
+    q = sp_query_begin_for_db(h, pp, query, query_len, shard);
+    if (!q) throw Fail{SP_E_ARG, std::string("sp_query_begin_for_db: ") + sp_last_error()};
+    hipStream_t main = (hipStream_t)sp_query_stream(q);
+    uint32_t* part = (uint32_t*)sp_query_partial_ptr(q);
+    if (!part) throw Fail{SP_E_OOM, std::string("partial buffer: ") + sp_last_error()};
+    const size_t words = sp_query_partial_words(q), pw = words / planes, chunk = pw / (size_t)G;
+    const size_t local_words = sp_query_local_cts_words(q);
+    c->ensure(c->mine, c->mine_bytes, planes * chunk * sizeof(uint32_t));
+    c->ensure(c->gathered, c->gathered_bytes, (size_t)G * local_words * sizeof(uint64_t));
+    hip_ok(hipEventRecord(c->ev_t[0], main), "hipEventRecord");
+    for (size_t pl = 0; pl < planes; pl++) {
+      sp_ok(sp_query_sweep_scatter_plane(q, shard, G, (int)pl), "sp_query_sweep_scatter_plane");
+      hip_ok(hipEventRecord(c->ev_plane[pl], main), "hipEventRecord");
+      hip_ok(hipStreamWaitEvent(c->stream, c->ev_plane[pl], 0), "hipStreamWaitEvent");
+      // plane pl's region is [g][r][crt][z][ii / G]: rank g receives the sum of everybody's chunk g
+      if (c->reduce_scatter(part + pl * pw, (uint32_t*)c->mine + pl * chunk, chunk) != 0)
+        throw Fail{SP_E_HIP, "custom reduce_scatter_u32 failed"};
+    }
+    hip_ok(hipEventRecord(c->ev_t[1], main), "hipEventRecord");
+    hip_ok(hipEventRecord(c->ev_x, c->stream), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(main, c->ev_x, 0), "hipStreamWaitEvent");
+    sp_ok(sp_query_fold_local(q, c->mine, G), "sp_query_fold_local");
+    hip_ok(hipEventRecord(c->ev_f, main), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(c->stream, c->ev_f, 0), "hipStreamWaitEvent");
+    if (c->all_gather(sp_query_local_cts_ptr(q), c->gathered, local_words) != 0)
+      throw Fail{SP_E_HIP, "custom all_gather_u64 failed"};
+    hip_ok(hipEventRecord(c->ev_g, c->stream), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(main, c->ev_g, 0), "hipStreamWaitEvent");
+    hip_ok(hipEventRecord(c->ev_t[2], main), "hipEventRecord");
+    if (c->rank == 0) {
+      sp_ok(sp_query_finish_gathered(q, c->gathered, G, out, out_cap, out_len), "sp_query_finish_gathered");
+    } else {
+      *out_len = 0;
+      sp_ok(sp_query_sync(q), "sp_query_sync");
+    }
+    hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    // [0] sweep launches incl. the exchanges overlapped with them, [1] exchange tail + local fold + all-gather
+    (void)hipEventElapsedTime(&c->ms[0], c->ev_t[0], c->ev_t[1]);
+    (void)hipEventElapsedTime(&c->ms[1], c->ev_t[1], c->ev_t[2]);
+    sp_note_path_(1ull << 19);  // PATH_RCCL (kernels.hpp)
+  });
+  if (q) {
+    if (rc != SP_OK) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)sp_query_sync(q);
+    }
+    sp_query_free(q);
+  }
+  return rc;
+}
+
+int sp_comm_barrier(sp_comm_t* c) {
+  if (!c) return SP_E_ARG;
+  std::lock_guard<std::mutex> lk(c->mu);
+  return guarded_comm([&] {
+    c->ensure(c->gathered, c->gathered_bytes, (size_t)c->world * sizeof(uint64_t));
+    c->ensure(c->mine, c->mine_bytes, sizeof(uint64_t));
+    hip_ok(hipMemsetAsync(c->mine, 0, sizeof(uint64_t), c->stream), "hipMemsetAsync");
+    if (c->all_gather(c->mine, c->gathered, 1) != 0) throw Fail{SP_E_HIP, "custom all_gather_u64 failed"};
+    hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+  });
+}
+
+}  // extern "C"

@@ -16,7 +16,7 @@ __global__ __launch_bounds__(256) void k_db_relayout(u64* dst_plane, const u64* 
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     int ii = it + ty + 8 * i, j = jt + tx;
-    if (ii < num_per && j < nj) tile[ty + 8 * i][tx] = s[(size_t)(cm.off + cm.stride * ii) * dim0 + j0 + j];
+    if (ii < num_per && j < nj) tile[ty + 8 * i][tx] = canon_word(s[(size_t)(cm.off + cm.stride * ii) * dim0 + j0 + j]);
   }
   __syncthreads();
 #pragma unroll
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void k_db_relayout_packed(u32* dst, int plane,
     const int ii = chunk * 128 + 2 * lane;
     const u64* s = src + ((size_t)zl * cm.np_global + cm.off + cm.stride * ii) * dim0 + j0 + 2 * jp;
     const size_t nx = (size_t)cm.stride * dim0;  // next local column
-    const u64 w00 = s[0], w10 = s[1], w01 = s[nx], w11 = s[nx + 1];
+    const u64 w00 = canon_word(s[0]), w10 = canon_word(s[1]), w01 = canon_word(s[nx]), w11 = canon_word(s[nx + 1]);
     u32* unit = dst + packed_unit_offset((size_t)plane * N + (z0 + zl), jp, chunk, npairs, chunks);
     pack_unit_lane(unit, lane, w00, w01, w10, w11);
   }
@@ -52,10 +52,12 @@ void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int
   if (packed) {
     hipLaunchKernelGGL(k_db_relayout_packed, dim3(4096), dim3(256), 0, s, reinterpret_cast<u32*>(dst), plane, src, z0,
                        nz, num_per, dim0, j0, nj, cm);
+    launched(0, "k_db_relayout_packed");
   } else {
     u64* dst_plane = dst + (size_t)plane * N * nj * num_per;
     hipLaunchKernelGGL(k_db_relayout, dim3((nj + 31) / 32, (num_per + 31) / 32, nz), dim3(256), 0, s, dst_plane, src,
                        z0, num_per, dim0, j0, nj, cm);
+    launched(0, "k_db_relayout");
   }
 }
 
@@ -99,6 +101,7 @@ void launch_db_synth(u64* dst, u64 seed, int planes, int num_per, int dim0, int 
     size_t total = (size_t)planes * N * nj * num_per;
     hipLaunchKernelGGL(k_db_synth, dim3(256 * 32), dim3(256), 0, s, dst, seed, num_per, dim0, j0, nj, total, cm);
   }
+  launched(0, "k_db_synth");
 }
 
 __global__ void k_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, int count, int num_per, int nj,
@@ -121,6 +124,7 @@ void launch_db_read(u64* out, const u64* db, int plane, int z, int ii, int jl0, 
   if (count <= 0) return;
   hipLaunchKernelGGL(k_db_read, dim3((count + 63) / 64), dim3(64), 0, s, out, db, plane, z, ii, jl0, count, num_per, nj,
                      packed);
+  launched(0, "k_db_read");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -151,8 +155,10 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
   __shared__ u32 lds0[LDS_WORDS];
   __shared__ u32 lds1[LDS_WORDS];
   const int tau = threadIdx.x;
-  const int qd = d.only_item >= 0 ? d.only_q : blockIdx.x;
-  const int jp = d.jp0 + blockIdx.y, plane = blockIdx.z;
+  // grid.x runs over (quad column, row pair): both are unbounded (nu_1 up to 20 on direct-upload configs), grid.y / z are not
+  const int gx = d.only_item >= 0 ? 1 : (d.num_per + 1) / 2;
+  const int qd = d.only_item >= 0 ? d.only_q : (int)(blockIdx.x % (unsigned)gx);
+  const int jp = d.jp0 + (int)(blockIdx.x / (unsigned)gx), plane = blockIdx.z;
   u64 w[4][8];  // [row a * 2 + ii b][k]: words at z = 8 tau + k
   u32* la = lds0;
   u32* lb = lds1;
@@ -233,7 +239,8 @@ __global__ __launch_bounds__(256) void k_db_encode(DevTables T, DbEncodeDesc d) 
 void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s) {
   if (d.njp <= 0) return;
   const unsigned gx = d.only_item >= 0 ? 1u : (unsigned)((d.num_per + 1) / 2);
-  hipLaunchKernelGGL(k_db_encode, dim3(gx, d.njp, d.planes), dim3(256), 0, s, T, d);
+  hipLaunchKernelGGL(k_db_encode, dim3(gx * (unsigned)d.njp, 1, d.planes), dim3(256), 0, s, T, d);
+  launched(0, "k_db_encode");
 }
 
 __global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* in, int num_per) {
@@ -249,6 +256,7 @@ __global__ __launch_bounds__(256) void k_sweep_out_to_ref(u64* out, const u32* i
 void launch_sweep_out_to_ref(u64* out, const u32* in, int num_per, hipStream_t s) {
   size_t total = (size_t)4 * N * num_per;
   hipLaunchKernelGGL(k_sweep_out_to_ref, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, in, num_per);
+  launched(0, "k_sweep_out_to_ref");
 }
 
 }  // namespace spiral

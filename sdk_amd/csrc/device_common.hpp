@@ -19,6 +19,14 @@ __device__ __forceinline__ u32 reduce64(u64 x, const ModConst m) {
   return r32 >= m.q ? r32 - m.q : r32;
 }
 
+// A database / query word as the sweep kernels need it: both 32-bit limbs reduced mod their prime.  The reference
+// multiplies the limbs as they come into u128 sums and takes one % q at the end (server.rs:196-217), so reducing
+// them first yields the same residues for ANY input word, while the kernels' u64 accumulation of 256 products and
+// the 28-bit PACKED format both rely on limbs < q < 2^28.
+__device__ __forceinline__ u64 canon_word(u64 w) {
+  return (u64)((u32)w % (u32)MODULUS_0) | ((u64)((u32)(w >> 32) % (u32)MODULUS_1) << 32);
+}
+
 __device__ __forceinline__ u32 add_mod(u32 a, u32 b, u32 q) {
   u32 s = a + b;
   return s >= q ? s - q : s;

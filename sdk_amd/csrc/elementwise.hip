@@ -5,10 +5,11 @@
 namespace spiral {
 
 // ------------------------------------------------------------------------------------------------
-// NTT-domain multiply-accumulate.  grid (2N/256, batch), one (crt, z) per thread.
+// NTT-domain multiply-accumulate.  grid (batch, 2N/256[, outer]), one (crt, z) per thread.  The batch runs along
+// grid.x: it is unbounded (num_per * planes on the unfused fold path), grid.y / grid.z are limited to 65535.
 // ------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, int inner, int outer) {
-  const int e = blockIdx.x * 256 + threadIdx.x;  // index into [crt][z]
+  const int e = blockIdx.y * 256 + threadIdx.x;  // index into [crt][z]
   const int c = e >> POLY_LEN_LOG2;
   const int b = outer * d.batch_inner + inner;
   const ModConst m = T.c.mod[c];
@@ -63,9 +64,9 @@ __device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, i
     d.out[op] = (u32)acc;
   }
 }
-__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.y, blockIdx.z); }
+__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.x, blockIdx.z); }
 __global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d1) {
-  const int y = blockIdx.y;
+  const int y = blockIdx.x;
   if (y < d0.batch_inner)
     mac_body(T, d0, y, 0);
   else
@@ -73,81 +74,93 @@ __global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d
 }
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
   if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
-  hipLaunchKernelGGL(k_mac, dim3(2 * N / 256, d.batch_inner, d.batch_outer), dim3(256), 0, s, T, d);
+  hipLaunchKernelGGL(k_mac, dim3(d.batch_inner, 2 * N / 256, d.batch_outer), dim3(256), 0, s, T, d);
+  launched(0, "k_mac");
 }
 void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipStream_t s) {
   MacDesc a = d0, b = d1;
   a.batch_inner = std::max(a.batch_inner, 0);
   b.batch_inner = std::max(b.batch_inner, 0);
   if (a.batch_inner + b.batch_inner <= 0) return;
-  hipLaunchKernelGGL(k_mac2, dim3(2 * N / 256, a.batch_inner + b.batch_inner, 1), dim3(256), 0, s, T, a, b);
+  hipLaunchKernelGGL(k_mac2, dim3(a.batch_inner + b.batch_inner, 2 * N / 256, 1), dim3(256), 0, s, T, a, b);
+  launched(0, "k_mac2");
 }
 
 __global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, const int* idx, const u32* src) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   const int c = e >> POLY_LEN_LOG2;
-  const int b = blockIdx.y;
+  const int b = blockIdx.x;
   const long dp = (long)idx[b] * 2 * N + e;
   dst[dp] = add_mod(dst[dp], src[(size_t)b * 2 * N + e], T.c.mod[c].q);
 }
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s) {
   if (batch <= 0) return;
-  hipLaunchKernelGGL(k_add_poly_into, dim3(2 * N / 256, batch), dim3(256), 0, s, T, dst, idx, src);
+  hipLaunchKernelGGL(k_add_poly_into, dim3(batch, 2 * N / 256), dim3(256), 0, s, T, dst, idx, src);
+  launched(0, "k_add_poly_into");
 }
 
 __global__ __launch_bounds__(256) void k_scalar_mul(DevTables T, u32* base, long dst_off, long src_off,
                                                     const u32* scalar) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   const int c = e >> POLY_LEN_LOG2;
-  const long b = blockIdx.y;
+  const long b = blockIdx.x;
   const ModConst m = T.c.mod[c];
   base[(dst_off + b) * 2 * N + e] = reduce64((u64)base[(src_off + b) * 2 * N + e] * (u64)scalar[e], m);
 }
 void launch_scalar_mul(const DevTables& T, u32* base, long dst_off, long src_off, const u32* scalar, int n_polys,
                        hipStream_t s) {
   if (n_polys <= 0) return;
-  hipLaunchKernelGGL(k_scalar_mul, dim3(2 * N / 256, n_polys), dim3(256), 0, s, T, base, dst_off, src_off, scalar);
+  hipLaunchKernelGGL(k_scalar_mul, dim3(n_polys, 2 * N / 256), dim3(256), 0, s, T, base, dst_off, src_off, scalar);
+  launched(0, "k_scalar_mul");
 }
 
 __global__ __launch_bounds__(256) void k_add_polys_idx(DevTables T, u32* dst, const int* di, const u32* a, const int* ai,
                                                         const u32* b, const int* bi) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int e = blockIdx.y * 256 + threadIdx.x;
   const int c = e >> POLY_LEN_LOG2;
-  const int k = blockIdx.y;
+  const int k = blockIdx.x;
   dst[(size_t)di[k] * 2 * N + e] = add_mod(a[(size_t)ai[k] * 2 * N + e], b[(size_t)bi[k] * 2 * N + e], T.c.mod[c].q);
 }
 void launch_add_polys_idx(const DevTables& T, u32* dst, const int* di, const u32* a, const int* ai, const u32* b,
                           const int* bi, int count, hipStream_t s) {
   if (count <= 0) return;
-  hipLaunchKernelGGL(k_add_polys_idx, dim3(2 * N / 256, count), dim3(256), 0, s, T, dst, di, a, ai, b, bi);
+  hipLaunchKernelGGL(k_add_polys_idx, dim3(count, 2 * N / 256), dim3(256), 0, s, T, dst, di, a, ai, b, bi);
+  launched(0, "k_add_polys_idx");
 }
 
-__global__ __launch_bounds__(256) void k_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0) {
+__global__ __launch_bounds__(256) void k_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0, u32 q0,
+                                                          u32 q1) {
   const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;  // index over [z][j]
   if (i >= (size_t)N * dim0) return;
   const int j = (int)(i % dim0);
   const int z = (int)(i / dim0);
   const u32* p = row0_ntt + (size_t)j * 2 * N;
   qv[2 * i] = (u64)p[z] | ((u64)p[N + z] << 32);
-  qv[2 * i + 1] = wire[i];
+  // wire words are used as they come in the reference's u128 sums followed by one % q (server.rs:196-217); the sweep
+  // kernels accumulate 256 products in u64 and need limbs < q, so the limbs are reduced here: same residues.
+  const u64 w = wire[i];
+  qv[2 * i + 1] = (u64)((u32)w % q0) | ((u64)((u32)(w >> 32) % q1) << 32);
 }
 void launch_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int dim0, hipStream_t s) {
   size_t total = (size_t)N * dim0;
-  hipLaunchKernelGGL(k_interleave_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qv, row0_ntt, wire, dim0);
+  hipLaunchKernelGGL(k_interleave_query, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, qv, row0_ntt, wire, dim0,
+                     (u32)MODULUS_0, (u32)MODULUS_1);
+  launched(0, "k_interleave_query");
 }
 
 __global__ __launch_bounds__(256) void k_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src,
                                                     const int* src_idx, int src_row_stride, int R) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int b = blockIdx.y / R, r = blockIdx.y % R;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int b = blockIdx.x / R, r = blockIdx.x % R;
   dst[((long)dst_idx[b] + (long)r * dst_row_stride) * 2 * N + e] =
       src[((long)src_idx[b] + (long)r * src_row_stride) * 2 * N + e];
 }
 void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
                        int src_row_stride, int R, int batch, hipStream_t s) {
   if (batch <= 0) return;
-  hipLaunchKernelGGL(k_copy_polys, dim3(2 * N / 256, batch * R), dim3(256), 0, s, dst, dst_idx, dst_row_stride, src,
+  hipLaunchKernelGGL(k_copy_polys, dim3(batch * R, 2 * N / 256), dim3(256), 0, s, dst, dst_idx, dst_row_stride, src,
                      src_idx, src_row_stride, R);
+  launched(0, "k_copy_polys");
 }
 
 __global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, const u32* gadget_ntt, int two_t) {
@@ -164,6 +177,7 @@ __global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, con
 void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s) {
   if (nu2 <= 0) return;
   hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, mats, gadget_ntt, two_t);
+  launched(0, "k_folding_neg");
 }
 
 __global__ __launch_bounds__(256) void k_add(DevTables T, u32* out, const u32* a, const u32* b) {
@@ -174,6 +188,7 @@ __global__ __launch_bounds__(256) void k_add(DevTables T, u32* out, const u32* a
 void launch_add(const DevTables& T, u32* out, const u32* a, const u32* b, int n_polys, hipStream_t s) {
   if (n_polys <= 0) return;
   hipLaunchKernelGGL(k_add, dim3((unsigned)((size_t)n_polys * 2 * N / 256)), dim3(256), 0, s, T, out, a, b);
+  launched(0, "k_add");
 }
 
 __global__ __launch_bounds__(256) void k_invert_raw(u64 Q, u64* out, const u64* a, long n) {
@@ -183,11 +198,12 @@ __global__ __launch_bounds__(256) void k_invert_raw(u64 Q, u64* out, const u64* 
 void launch_invert_raw(const DevTables& T, u64* out, const u64* a, long n_words, hipStream_t s) {
   if (n_words <= 0) return;
   hipLaunchKernelGGL(k_invert_raw, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, T.c.Q, out, a, n_words);
+  launched(0, "k_invert_raw");
 }
 
 __global__ __launch_bounds__(256) void k_automorph(u64 Q, u64* out, const u64* a, int t) {
-  const int z = blockIdx.x * 256 + threadIdx.x;
-  const size_t p = (size_t)blockIdx.y * N;
+  const int z = blockIdx.y * 256 + threadIdx.x;
+  const size_t p = (size_t)blockIdx.x * N;
   unsigned zt = (unsigned)z * (unsigned)t;
   unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
   u64 v = a[p + z];
@@ -195,12 +211,13 @@ __global__ __launch_bounds__(256) void k_automorph(u64 Q, u64* out, const u64* a
 }
 void launch_automorph(const DevTables& T, u64* out, const u64* a, int n_polys, int t, hipStream_t s) {
   if (n_polys <= 0) return;
-  hipLaunchKernelGGL(k_automorph, dim3(N / 256, n_polys), dim3(256), 0, s, T.c.Q, out, a, t);
+  hipLaunchKernelGGL(k_automorph, dim3(n_polys, N / 256), dim3(256), 0, s, T.c.Q, out, a, t);
+  launched(0, "k_automorph");
 }
 
 __global__ __launch_bounds__(256) void k_gadget_raw(u64* out, const u64* inp, int cols, int rdim, int bits) {
-  const int z = blockIdx.x * 256 + threadIdx.x;
-  const int o = blockIdx.y;  // output poly index: row*cols + col
+  const int z = blockIdx.y * 256 + threadIdx.x;
+  const int o = blockIdx.x;  // output poly index: row*cols + col
   const int row = o / cols, col = o - row * cols;
   const int k = row / rdim, j = row - k * rdim;
   const int sh = k * bits;
@@ -211,7 +228,8 @@ __global__ __launch_bounds__(256) void k_gadget_raw(u64* out, const u64* inp, in
 void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows_out, int rdim, int bits,
                        hipStream_t s) {
   (void)rows_in;
-  hipLaunchKernelGGL(k_gadget_raw, dim3(N / 256, rows_out * cols), dim3(256), 0, s, out, inp, cols, rdim, bits);
+  hipLaunchKernelGGL(k_gadget_raw, dim3(rows_out * cols, N / 256), dim3(256), 0, s, out, inp, cols, rdim, bits);
+  launched(0, "k_gadget_raw");
 }
 
 __global__ __launch_bounds__(256) void k_u64_to_u32(u32* out, const u64* in, long n) {
@@ -225,10 +243,12 @@ __global__ __launch_bounds__(256) void k_u32_to_u64(u64* out, const u32* in, lon
 void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_u64_to_u32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+  launched(0, "k_u64_to_u32");
 }
 void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
   if (n <= 0) return;
   hipLaunchKernelGGL(k_u32_to_u64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, out, in, n);
+  launched(0, "k_u32_to_u64");
 }
 
 // rescale(a, Q, out_mod) of arith.rs:429-444 without 128-bit division: the truncated quotient
@@ -294,6 +314,7 @@ __global__ __launch_bounds__(256) void k_encode(EncodeDesc d) {
 void launch_encode(const EncodeDesc& d, hipStream_t s) {
   const long total = (long)d.instances * ((long)d.n * N + (long)d.n * d.n * N);
   hipLaunchKernelGGL(k_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
+  launched(0, "k_encode");
 }
 
 // out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
@@ -321,6 +342,7 @@ __global__ __launch_bounds__(256) void k_reorient(u64* out, const u32* v, int fi
 }
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
   hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, out, v, first, step, dim0);
+  launched(0, "k_reorient");
 }
 
 }  // namespace spiral

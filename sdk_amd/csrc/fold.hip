@@ -247,6 +247,7 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
     hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else
     hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+  launched(PATH_FOLD_FUSED, "k_fold_fused");
 }
 
 }  // namespace spiral

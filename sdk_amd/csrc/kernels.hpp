@@ -18,6 +18,36 @@ struct DevTables {
   DevConsts c;
 };
 
+// ---- which kernels / flows the calling thread's work went through (sp_paths_taken, include/spiral_hip.h) ----------
+// Every launch wrapper reports here right after its hipLaunchKernelGGL: the bit is recorded (thread-local, tests assert
+// which code path produced the bytes they compared) and the launch is checked -- a rejected launch (bad grid, too
+// much LDS ...) throws HipError instead of leaving stale workspace contents to be packed into a "successful" response.
+enum PathBit : u64 {
+  PATH_SWEEP_PERSIST = 1ull << 0,     // k_sweep_packed_persist (PACKED database, capped-footprint grid)
+  PATH_SWEEP_PACKED = 1ull << 1,      // k_sweep_packed (one wave per unit)
+  PATH_SWEEP_WIDE = 1ull << 2,        // k_sweep_wide (8-byte words, num_per >= 128)
+  PATH_SWEEP_NARROW = 1ull << 3,      // k_sweep_narrow / k_sweep_narrow2 (num_per < 128, LDS-staged query)
+  PATH_SWEEP_BATCH = 1ull << 4,       // k_sweep_packed_batch (several queries per database pass)
+  PATH_FROM_SWEEP4 = 1ull << 5,       // k_from_sweep4 (4 columns per workgroup)
+  PATH_FROM_SWEEP1 = 1ull << 6,       // k_ntt_inv in sweep-source mode
+  PATH_FOLD_FUSED = 1ull << 7,        // k_fold_fused* (one workgroup per fold step)
+  PATH_FOLD_TAIL = 1ull << 8,         // three-launch tree tail (delta form)
+  PATH_FOLD_TAIL_LITERAL = 1ull << 9, // three-launch tree tail (two-matrix form)
+  PATH_PIPELINED = 1ull << 10,        // per-plane sweep launches with the fold of plane p beside the sweep of p+1
+  PATH_EXPAND_PRUNED = 1ull << 11,    // expansion pruned to a row shard's rows
+  PATH_PACK_V1 = 1ull << 12,
+  PATH_DIRECT_UPLOAD = 1ull << 13,
+  PATH_SCATTER_OUT = 1ull << 14,      // column-interleaved sweep output (multi-GPU reduce-scatter layout)
+  PATH_SWEEP_XCD_FROM = 1ull << 15,   // k_from_sweep4 with the XCD-aware block order
+  PATH_FOLD_TAIL_PERSIST = 1ull << 16,// k_fold_tail (all small levels in one launch, grid barrier per level)
+  PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_head (first expansion rounds in one launch)
+  PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
+  PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
+  PATH_FOLD_FUSED_LOWREG = 1ull << 20 // k_fold_fused3 (4 waves per SIMD form)
+};
+void launched(u64 path_bits, const char* kernel);  // server.cpp
+void note_path(u64 path_bits);
+
 // ---- forward NTT family -------------------------------------------------------------------
 // Generic source descriptor for a batch of forward NTTs: output poly `o` (0 <= o < n_out) is the
 // NTT of digit `k` of raw poly `src`, where with out matrix (rdim*t x cols) per batch element

@@ -126,6 +126,7 @@ __global__ __launch_bounds__(256) void k_ntt_fwd3(DevTables T, FwdDesc d0, FwdDe
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
   if (d.n_out <= 0) return;
   hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
+  launched(0, "k_ntt_fwd");
 }
 void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, hipStream_t s) {
   const int total = std::max(d0.n_out, 0) + std::max(d1.n_out, 0) + std::max(d2.n_out, 0);
@@ -135,6 +136,7 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
   b.n_out = std::max(b.n_out, 0);
   c.n_out = std::max(c.n_out, 0);
   hipLaunchKernelGGL(k_ntt_fwd3, dim3(total, 2), dim3(256), 0, s, T, a, b, c);
+  launched(0, "k_ntt_fwd3");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -247,6 +249,7 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
   const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);
   if (blocks <= 0) return;
   hipLaunchKernelGGL(k_ntt_inv, dim3(blocks), dim3(256), 0, s, T, d);
+  launched(d.sweep_np > 0 ? PATH_FROM_SWEEP1 : 0, "k_ntt_inv");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -315,6 +318,7 @@ void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes
   static const int want = [] { const char* e = getenv("SPIRAL_FROM_SWEEP_XCD"); return e ? atoi(e) : 1; }();
   const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
+  launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
 
 }  // namespace spiral

@@ -20,6 +20,19 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
   }
 }
 
+static thread_local u64 g_paths = 0;
+void note_path(u64 bits) { g_paths |= bits; }
+u64 paths_taken(bool reset) {
+  const u64 v = g_paths;
+  if (reset) g_paths = 0;
+  return v;
+}
+void launched(u64 bits, const char* kernel) {
+  g_paths |= bits;
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) throw HipError(std::string("launch of ") + kernel + " failed: " + hipGetErrorString(e));
+}
+
 // ---------------------------------------------------------------------------------- ChaCha20
 static inline u32 rotl(u32 v, int c) { return (v << c) | (v >> (32 - c)); }
 static inline void quarter(u32* s, int a, int b, int c, int d) {
@@ -524,6 +537,7 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
+  note_path(PATH_DIRECT_UPLOAD);
   const size_t dim0 = p.dim0(), nu2 = p.db_dim_2, two_t = 2 * p.t_gsw;
   const size_t n_reg = dim0 * POLY_LEN;
   const size_t gsw_polys = nu2 * 2 * two_t;
@@ -583,6 +597,7 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   const size_t g = p.g();
   // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
   const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
+  if (prune) note_path(PATH_EXPAND_PRUNED);
   run_coefficient_expansion(W, pp, g, prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
   if (p.db_dim_2 > 0) {
@@ -668,6 +683,7 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   }
   HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
   W.pipelined = true;
+  note_path(PATH_PIPELINED);
 }
 
 // k_fold_fused* keep gadget digits in u32 and need digit < 2q, i.e. at most 28 bits per digit (t_gsw >= 2)
@@ -746,6 +762,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
       inv.add_inner2 = half * 2;
       inv.add_outer_stride = cur * 2;
       launch_ntt_inv(D.T, inv, s);
+      note_path(PATH_FOLD_TAIL);
       std::swap(X, Y);
       cur = half;
       continue;
@@ -785,6 +802,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
     inv.dst = Y;
     inv.n_polys = np * half * 2;
     launch_ntt_inv(D.T, inv, s);
+    note_path(PATH_FOLD_TAIL_LITERAL);
     std::swap(X, Y);
     cur = half;
   }
@@ -799,6 +817,7 @@ static void run_pack_v1(Workspace& W, const sp_pp& pp) {
   hipStream_t s = W.stream;
   const int* L = D.lists.p;
   const int tc = (int)p.t_conv;
+  note_path(PATH_PACK_V1);
   const int nb = (int)p.planes();         // (inst, c, r)
   const int ne = (int)p.instances * 2;    // (inst, c)
   const size_t PW = 2 * POLY_LEN;

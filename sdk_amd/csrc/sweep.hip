@@ -248,6 +248,7 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
     case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio); break;
     default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio); break;
   }
+  launched(PATH_SWEEP_PERSIST | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_persist");
 }
 
 // Multi-query PACKED sweep: B queries share one pass over the database (BASELINE configs[4]).  Per row
@@ -385,6 +386,7 @@ void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t
     default: break;
   }
 #undef SP_BATCH_CASE
+  launched(PATH_SWEEP_BATCH, "k_sweep_packed_batch");
 }
 
 
@@ -504,6 +506,7 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
   if (d.packed) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
     hipLaunchKernelGGL(k_sweep_packed, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
+    launched(PATH_SWEEP_PACKED | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed");
   } else if (d.num_per >= 128) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
     static const int variant = [] {
@@ -520,6 +523,7 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
       case 5: hipLaunchKernelGGL((k_sweep_wide<2, true>), grid, dim3(256), 0, s, T, d); break;
       default: hipLaunchKernelGGL((k_sweep_wide<1, true>), grid, dim3(256), 0, s, T, d); break;
     }
+    launched(PATH_SWEEP_WIDE | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_wide");
   } else {
     if (d.num_per >= 2 && !getenv("SPIRAL_NARROW1")) {
       size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 8 * sizeof(u32);
@@ -528,6 +532,7 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
       size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
       hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
     }
+    launched(PATH_SWEEP_NARROW | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_narrow");
   }
 }
 

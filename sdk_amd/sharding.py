@@ -176,3 +176,185 @@ def modulus_of_partial_index(idx, num_per, N=2048):
     """q_crt for flat indices into the partial buffer"""
     crt = (np.asarray(idx) // (N * num_per)) % 2
     return np.where(crt == 0, Q0, Q1)
+
+
+# ------------------------------------------------------------------------------------------------
+# The same flow with the exchange issued by the library itself (include/spiral_hip.h sp_comm_*,
+# sdk_amd/csrc/comm.cpp: RCCL linked directly) -- what a non-Python host (lib/server, Rust) calls.
+class Comm:
+    """sp_comm_t: one per process / GPU.  Comm.rccl(rank, world, id128) joins the RCCL communicator whose id rank 0
+    made with Comm.unique_id() (collective); Comm.custom(rank, world, reduce_scatter, all_gather) plugs host-supplied
+    collectives in (callables (send_ptr, recv_ptr, count, hip_stream) -> 0)."""
+
+    def __init__(self, h, keep=None):
+        self.h, self._keep = h, keep
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from .spiral import _chk, lib
+        buf = (C.c_uint8 * 128)()
+        _chk(lib().sp_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def rccl(cls, rank, world, id128):
+        import ctypes as C
+        from .spiral import SpiralError, _err, lib
+        L = lib()
+        L.sp_comm_create.restype = C.c_void_p
+        buf = (C.c_uint8 * 128).from_buffer_copy(bytes(id128))
+        h = L.sp_comm_create(C.c_int(rank), C.c_int(world), buf)
+        if not h:
+            raise SpiralError(_err())
+        return cls(h)
+
+    @classmethod
+    def custom(cls, rank, world, reduce_scatter, all_gather):
+        import ctypes as C
+        from .spiral import SpiralError, _err, lib
+        FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+        class Ops(C.Structure):
+            _fields_ = [("reduce_scatter_u32", FN), ("all_gather_u64", FN), ("user", C.c_void_p)]
+
+        def wrap(f):
+            def g(user, send, recv, count, stream):
+                try:
+                    return int(f(send, recv, count, stream) or 0)
+                except Exception as e:  # an exception must not unwind through the C frames
+                    import sys
+                    print("custom collective raised %r" % (e,), file=sys.stderr, flush=True)
+                    return 1
+            return FN(g)
+        rs, ag = wrap(reduce_scatter), wrap(all_gather)
+        ops = Ops(rs, ag, None)
+        L = lib()
+        L.sp_comm_create_custom.restype = C.c_void_p
+        h = L.sp_comm_create_custom(C.c_int(rank), C.c_int(world), C.byref(ops))
+        if not h:
+            raise SpiralError(_err())
+        return cls(h, keep=(rs, ag, ops))
+
+    def free(self):
+        import ctypes as C
+        from .spiral import lib
+        if getattr(self, "h", None):
+            lib().sp_comm_free(C.c_void_p(self.h))
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def barrier(self):
+        import ctypes as C
+        from .spiral import _chk, lib
+        _chk(lib().sp_comm_barrier(C.c_void_p(self.h)))
+
+    def timings(self):
+        import ctypes as C
+        from .spiral import _chk, lib
+        t = (C.c_float * 3)()
+        _chk(lib().sp_comm_timings(C.c_void_p(self.h), t))
+        return list(t)
+
+    def process_query(self, params, pp, query, shard):
+        """sp_process_query_sharded: the response bytes on rank 0, b"" elsewhere"""
+        import ctypes as C
+        from .spiral import _bytes, _chk, _p, lib, u8p
+        d = _bytes(query.data if hasattr(query, "data") else bytes(query))
+        n = params.get("response_bytes")
+        out = np.zeros(n, dtype=np.uint8)
+        ln = C.c_size_t(0)
+        _chk(lib().sp_process_query_sharded(C.c_void_p(self.h), C.c_void_p(params.h), C.c_void_p(pp.h), _p(d, u8p),
+                                            C.c_size_t(d.size), C.c_void_p(shard.h), _p(out, u8p), C.c_size_t(n),
+                                            C.byref(ln)))
+        return out[:ln.value].tobytes()
+
+
+class LoopbackWorld:
+    """G ranks as G host threads sharing ONE GPU, with in-process stand-ins for the two collectives (device sums /
+    copies ordered with HIP events, ncclReduceScatter / ncclAllGather semantics).  Lets the whole N > 1 flow of
+    sp_process_query_sharded -- G workspaces, 2 G streams, per-plane exchanges overlapping the next plane's sweep --
+    run and be byte-checked on a 1-GPU box.  rank r's thread: world.comm(r).process_query(...)."""
+
+    def __init__(self, world):
+        import threading
+        self.world = world
+        self.bar = threading.Barrier(world, timeout=300)
+        self.slot = [None] * world
+        self.done = [None] * world
+        self.comms = [Comm.custom(r, world, self._rs(r), self._ag(r)) for r in range(world)]
+
+    def comm(self, r):
+        return self.comms[r]
+
+    def _exchange(self, r, send, stream, body):
+        """publish (send, ready-event) -> rendezvous -> body(all sends) on my stream after everybody's data is ready ->
+        rendezvous -> nobody's stream runs on before every reader of its buffer is done"""
+        import torch
+        st = torch.cuda.ExternalStream(stream)
+        ev = torch.cuda.Event()
+        ev.record(st)
+        self.slot[r] = (send, ev)
+        self.bar.wait()
+        for (_, e) in self.slot:
+            st.wait_event(e)
+        with torch.cuda.stream(st):
+            body([s for (s, _) in self.slot])
+        fin = torch.cuda.Event()
+        fin.record(st)
+        self.done[r] = fin
+        self.bar.wait()
+        for e in self.done:
+            st.wait_event(e)
+        self.bar.wait()   # slots may be overwritten by the next collective only after everybody has read them
+        return 0
+
+    def _rs(self, r):
+        def f(send, recv, count, stream):
+            import torch
+
+            def body(sends):
+                out = torch.as_tensor(_DevArray(recv, count), device="cuda")
+                acc = None
+                for s in sends:
+                    t = torch.as_tensor(_DevArray(s + 4 * count * r, count), device="cuda")
+                    acc = t.clone() if acc is None else acc.add_(t)
+                out.copy_(acc)
+            return self._exchange(r, send, stream, body)
+        return f
+
+    def _ag(self, r):
+        def f(send, recv, count, stream):
+            import torch
+
+            def body(sends):
+                out = torch.as_tensor(_DevArray64(recv, count * self.world), device="cuda")
+                for g, s in enumerate(sends):
+                    out[g * count:(g + 1) * count].copy_(torch.as_tensor(_DevArray64(s, count), device="cuda"))
+            return self._exchange(r, send, stream, body)
+        return f
+
+    def run(self, fn):
+        """fn(rank) on every rank thread; returns the list of results (re-raises the first exception)"""
+        import threading
+        res, err = [None] * self.world, []
+
+        def go(r):
+            try:
+                res[r] = fn(r)
+            except Exception as e:  # noqa: BLE001
+                err.append(e)
+                self.bar.abort()
+        ts = [threading.Thread(target=go, args=(r,)) for r in range(self.world)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        if err:
+            raise err[0]
+        return res

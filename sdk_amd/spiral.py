@@ -613,6 +613,34 @@ def fold_ciphertexts(params, v_cts, v_folding, v_folding_neg):
     return cts
 
 
+def fold_ciphertexts_fused(params, v_cts, v_folding, fused_min_pairs=0):
+    """fold_ciphertexts the way process_query runs it (server.rs:388-427 with v_folding_neg = G - v_folding formed
+    on the device): levels with >= fused_min_pairs pairs use the fused kernel (0 = library default, 1 = every level)."""
+    cts = _u64arr(v_cts).copy()
+    num_per = cts.size // (2 * params.poly_len)
+    _chk(lib().sp_fold_ciphertexts_fused(_vp(params.h), _p(cts), C.c_size_t(num_per), _p(_u64arr(v_folding)),
+                                         C.c_long(fused_min_pairs)))
+    return cts
+
+
+def paths_taken(reset=True):
+    """Names of the kernels / flows this thread's library calls went through since the last reset
+    (sp_paths_taken / sp_path_name, include/spiral_hip.h)."""
+    L = lib()
+    L.sp_paths_taken.restype = C.c_uint64
+    L.sp_path_name.restype = C.c_char_p
+    mask = int(L.sp_paths_taken(C.c_int(1 if reset else 0)))
+    names, bit = set(), 0
+    while True:
+        nm = L.sp_path_name(C.c_int(bit))
+        if nm is None:
+            break
+        if mask >> bit & 1:
+            names.add(nm.decode())
+        bit += 1
+    return names
+
+
 def pack(params, public_params, v_ct):
     """server.rs:429-468 with v_w = public_params.v_packing"""
     v_ct = _u64arr(v_ct)

@@ -57,6 +57,18 @@ def main():
             "scatter_fold_query overlap=%s fold_per_plane=%s" % (overlap, per_plane)
         run.free()
 
+    # the same flow with the collectives issued by the library (sp_process_query_sharded, RCCL linked directly):
+    # a real ncclCommInitRank / ncclReduceScatter / ncclAllGather on this process's GPU
+    from sdk_amd.sharding import Comm
+    comm = Comm.rccl(0, 1, Comm.unique_id())
+    sp.paths_taken()
+    for _ in range(2):
+        assert comm.process_query(p, gpp, q, gdb) == expect, "sp_process_query_sharded over RCCL"
+    assert "rccl_in_library" in sp.paths_taken()
+    comm.barrier()
+    assert len(comm.timings()) == 3
+    comm.free()
+
     # reduce: sweep -> dist.reduce -> finish
     run = sp.QueryRun(p, gpp, q).sweep(gdb)
     run.sync()

@@ -305,15 +305,17 @@ def test_process_query_c1(sp, oracle_mod):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
-@pytest.mark.parametrize("variant", ["0", "1"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
 def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
-    """k_fold_fused (used when a level has >= 256 (pair, plane) units, i.e. at C2 scale) forced on for a
-    small tree, both register-allocation variants: stage output and response bytes must not change."""
-    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", "1")
+    """The fused fold kernels (k_fold_fused / k_fold_fused2: the form used when a level has >= 256 (pair, plane)
+    units, i.e. at C2 scale) forced on for a small tree, every kernel variant, through the STAGE export that runs
+    them (sp_fold_ciphertexts_fused: G - C formed on the device as in process_query) and through process_query.
+    sp_fold_ciphertexts itself honours a caller-supplied v_folding_neg and therefore always takes the literal
+    two-matrix tail; both must equal the oracle's fold_ciphertexts.  The path mask proves which kernels ran."""
     monkeypatch.setenv("SPIRAL_FOLD_VARIANT", variant)
     cfg, idx = dict(FAST56, nu_2=4), 777
     o, cl, pp, q = _session(oracle_mod, cfg, idx, 33)
-    p = sp.Params(cfg)          # workspaces of this handle read the env at creation
+    p = sp.Params(cfg)
     item, db = o.generate_random_db_and_get_item(idx)
     gpp = sp.PublicParameters.deserialize(p, pp)
     v_reg, v_fold = o.expand_query(pp, q)
@@ -321,13 +323,30 @@ def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
     N = 2048
     sw = o.dim0 * o.num_per * N
     raw = o.from_ntt(o.multiply_reg_by_database(db[:sw], v_reg))
-    assert (sp.fold_ciphertexts(p, raw, v_fold, v_neg)[:2 * N] == o.fold_ciphertexts(raw, v_fold, v_neg)[:2 * N]).all()
+    expect = o.fold_ciphertexts(raw, v_fold, v_neg)[:2 * N]
+    sp.paths_taken()
+    assert (sp.fold_ciphertexts(p, raw, v_fold, v_neg)[:2 * N] == expect).all()
+    taken = sp.paths_taken()
+    assert "fold_tail_literal" in taken and "fold_fused" not in taken, taken
+    assert (sp.fold_ciphertexts_fused(p, raw, v_fold, fused_min_pairs=1)[:2 * N] == expect).all()
+    taken = sp.paths_taken()
+    assert "fold_fused" in taken and not ({"fold_tail_delta", "fold_tail_literal", "fold_tail_persistent"} & taken), taken
+    # mixed: the first levels fused, the tail of the tree through the non-fused form
+    assert (sp.fold_ciphertexts_fused(p, raw, v_fold, fused_min_pairs=4)[:2 * N] == expect).all()
+    taken = sp.paths_taken()
+    assert "fold_fused" in taken and ({"fold_tail_delta", "fold_tail_persistent"} & taken), taken
     # ragged tree depth (fewer levels than nu_2) through the stage API
     sub = raw[:4 * 2 * N]
-    assert (sp.fold_ciphertexts(p, sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N])[:2 * N] ==
-            o.fold_ciphertexts(sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N], nu=2)[:2 * N]).all()
-    gdb = sp.Database(p).load(db)
-    resp = sp.process_query(p, gpp, q, gdb)
+    e2 = o.fold_ciphertexts(sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N], nu=2)[:2 * N]
+    assert (sp.fold_ciphertexts(p, sub, v_fold[:2 * 32 * 2 * N], v_neg[:2 * 32 * 2 * N])[:2 * N] == e2).all()
+    assert (sp.fold_ciphertexts_fused(p, sub, v_fold[:2 * 32 * 2 * N], fused_min_pairs=1)[:2 * N] == e2).all()
+    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", "1")
+    p2 = sp.Params(cfg)          # workspaces of this handle read the env at creation
+    gpp2 = sp.PublicParameters.deserialize(p2, pp)
+    gdb = sp.Database(p2).load(db)
+    sp.paths_taken()
+    resp = sp.process_query(p2, gpp2, q, gdb)
+    assert "fold_fused" in sp.paths_taken()
     assert resp == o.process_query(pp, q, db)
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
@@ -677,6 +696,44 @@ def test_rccl_world1_paths():
     here = os.path.dirname(os.path.abspath(__file__))
     r = subprocess.run([sys.executable, os.path.join(here, "_rccl_world1.py")], capture_output=True, text=True, timeout=280)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
+
+
+@pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4),
+                                   (dict(FAST56, nu_2=5, t_gsw=3, t_conv=3, t_exp_left=5), 4),
+                                   (dict(FAST, nu_1=6, nu_2=10, t_gsw=2, db_item_size=256), 8)],
+                         ids=["narrow-G2", "narrow-G8", "packed-G4", "odd-gadgets-G4", "wide-G8"])
+def test_process_query_sharded_c_abi_loopback(sp, oracle_mod, cfg, G):
+    """sp_process_query_sharded (sdk_amd/csrc/comm.cpp) -- the whole N > 1 answer path inside the library: G ranks
+    as G host threads on this one GPU, each with its own row shard, workspace and streams; the two collectives are
+    the in-process loopback transport (sp_comm_create_custom) with ncclReduceScatter / ncclAllGather semantics.
+    Rank 0's response must equal the oracle's process_query on the unsharded database; twice, to cover buffer reuse."""
+    from sdk_amd.sharding import LoopbackWorld
+    idx = 77
+    o, cl, pp, q = _session(oracle_mod, cfg, idx, 91)
+    q2 = cl.generate_query(idx + 1, 17)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    expect = [o.process_query(pp, q, db), o.process_query(pp, q2, db)]
+    shards = [sp.Database(p, s, G).load(db) for s in range(G)]
+    world = LoopbackWorld(G)
+
+    def rank_main(r):
+        sp.lib().sp_set_device(0)
+        sp.paths_taken()
+        out = [world.comm(r).process_query(p, gpp, qq, shards[r]) for qq in (q, q2)]
+        return out, sp.paths_taken()
+    res = world.run(rank_main)
+    assert res[0][0] == expect
+    for r in range(1, G):
+        assert res[r][0] == [b"", b""]
+    for r in range(G):
+        assert {"scatter_out", "rccl_in_library"} <= res[r][1], res[r][1]
+        if G > 1 and o.num_per >= 2:
+            assert "expand_pruned" in res[r][1]
+    assert cl.decode_response(expect[0]) == o.item_to_vec(item) or cfg.get("t_gsw") == 2
+    with pytest.raises(sp.SpiralError):
+        world.comm(0).process_query(p, gpp, q[:-8], shards[0])      # bad query length: no collective is entered
 
 
 def test_overlapped_fold_direct_upload_parity(sp, oracle_mod):
