@@ -1,14 +1,25 @@
 #!/usr/bin/env python
 """bench.py -- queries/s of the MI355X Spiral PIR answer path (BASELINE.json metric).
 
-One "step" = one full process_query (Query::deserialize + expand_query + db sweep + fold + pack +
-encode, server.rs:650-741) of ONE query over the resident synthetic database.
-  N = 1 : BASELINE.json configs[1] -- 2^20 items x 256 B (nu = (9,11), 64 GiB encoded DB in HBM).
-  N > 1 : the same database row-sharded over the N GPUs (dim0/N first-dimension rows each); every rank
-          sweeps its shard, the partial Regev ciphertexts (u32 residues) are summed onto rank 0 with one
-          RCCL reduce over xGMI, rank 0 folds/packs/encodes.  Strong scaling: total work is fixed.
-Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region (the 16 KiB query and
-the 20 KiB response are the only host traffic inside a step).
+One "step" = one full process_query (Query::deserialize + expand_query + db sweep + fold + pack + encode,
+lib/spiral-rs/src/server.rs:650-741) over the resident synthetic database (seed 0x123456789: the database whose
+responses tests/test_gpu_fullsize.py compares byte for byte with the oracle).
+
+  --gpus 1 (default)        BASELINE.json configs[1] = C2: 2^20 items x 256 B (nu = (9,11), 64 GiB encoded, 56 GiB
+                            resident), ONE query per step.  --batch B: B queries per step sharing database passes.
+  --gpus N, mode "shard"    (default for N > 1; north star) the same database ROW-SHARDED over the N GPUs, one process
+                            per GPU; every rank expands the query (pruned to its rows), sweeps its dim0/N rows plane by
+                            plane, the partial Regev ciphertexts of plane p are reduce-scattered (RCCL ncclSum over xGMI,
+                            issued by libspiral_hip.so itself: sp_process_query_sharded) while plane p+1 is swept, every
+                            rank folds its num_per/N columns, one all-gather, rank 0 finishes.  Strong scaling.
+                            SPIRAL_MULTIGPU=torch|reduce|columns selects the older torch.distributed flows.
+  --gpus N, mode "replicas" (BASELINE.json configs[4]; --mode replicas or SPIRAL_BENCH_MODE=replicas) every GPU holds the
+                            WHOLE database; a step = 8 N queries (--batch 8 per rank, one database pass per rank);
+                            no collective inside the timed region.  Weak scaling.
+  --config c3               BASELINE.json configs[2] (2^22 x 256 B; 32 GiB of rows per GPU at N = 8; fits one GPU too).
+
+Prints ONE JSON line on rank 0.  Inputs are resident in HBM before the timed region (the 16 KiB query and the 20 KiB
+response are the only host traffic inside a step).
 """
 import argparse
 import ctypes as C
@@ -23,27 +34,25 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+_BASE = {"n": 2, "nu_1": 9, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8, "t_exp_right": 56,
+         "instances": 1, "db_item_size": 256}
 CONFIGS = {
     # BASELINE.json configs[1]: literal 2^20 x 256 B (SURVEY.md 8(d) "C2"); gadget set of CFG_20_256 (util.rs:7-20)
-    "c2": {"n": 2, "nu_1": 9, "nu_2": 11, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
+    "c2": dict(_BASE, nu_2=11),
     # configs[0]: 2^14 x 256 B
-    "c1": {"n": 2, "nu_1": 9, "nu_2": 5, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
+    "c1": dict(_BASE, nu_2=5),
     # the reference's own packed preset CFG_20_256 (2^20 x 256 B packed into 2^15 x 8 KiB)
-    "p2": {"n": 2, "nu_1": 9, "nu_2": 6, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 1, "db_item_size": 8192},
+    "p2": dict(_BASE, nu_2=6, db_item_size=8192),
     # configs[3]: 2^20 items x 32 KiB (SpiralWiki-style payload): 16 planes, 256 GiB encoded (224 GiB packed)
-    "c4": {"n": 2, "nu_1": 9, "nu_2": 11, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 4, "db_item_size": 32768},
-    # configs[2] per-GPU view: 2^22 items x 256 B (nu = (9,13)); run with --gpus 8 (32 GiB of rows per GPU)
-    "c3": {"n": 2, "nu_1": 9, "nu_2": 13, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 1, "db_item_size": 256},
+    "c4": dict(_BASE, nu_2=11, instances=4, db_item_size=32768),
+    # configs[2]: 2^22 items x 256 B (nu = (9,13)); 32 GiB of rows per GPU at --gpus 8, 224 GiB packed on one GPU
+    "c3": dict(_BASE, nu_2=13),
     "fast": {"n": 2, "nu_1": 6, "nu_2": 2, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8,
              "t_exp_right": 8, "instances": 1, "db_item_size": 8192},
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md); ~6300 GB/s is what a copy achieves
 Q = 268369921 * 249561089
+SEED = 0x123456789      # util.rs:171-173
 
 
 def synthetic_wire_bytes(n_bytes, seed):
@@ -56,65 +65,129 @@ def synthetic_wire_bytes(n_bytes, seed):
 
 
 def sweep_algorithmic_bytes(cfg, shards):
-    """BASELINE.md section 2 / SURVEY.md 8(d): per query, per GPU shard (reference 8-byte word format)."""
+    """BASELINE.md section 2 / SURVEY.md 8(d): per query, per GPU shard, in the REFERENCE's 8-byte word format."""
     N = 2048
     T = cfg["instances"] * cfg["n"] ** 2
     dim0, num_per = 1 << cfg["nu_1"], 1 << cfg["nu_2"]
     return T * N * num_per * (dim0 // shards) * 8 + T * N * (dim0 // shards) * 2 * 8 + T * num_per * 4 * N * 8
 
 
+def sweep_moved_bytes(cfg, shards, db_device_bytes):
+    """Bytes the sweep has to move in THIS implementation's resident format, per query per shard: the database as
+    stored (7-byte PACKED words where applicable) + the query slice (16 B per (z, row)) + the u32 outputs."""
+    N = 2048
+    T = cfg["instances"] * cfg["n"] ** 2
+    dim0, num_per = 1 << cfg["nu_1"], 1 << cfg["nu_2"]
+    return db_device_bytes + T * N * (dim0 // shards) * 16 + T * num_per * 4 * N * 4
+
+
 def pmc_traffic(cfg_name, world, launches):
     """HBM bytes per sweep launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled per the
-    gfx950 correction + WRITE_SIZE); bench.py cannot collect counters itself.  None when no matching record."""
+    gfx950 correction + WRITE_SIZE).  bench.py cannot collect counters itself: the figure is REPLAYED from the newest
+    tracked record and `traffic_source` says so.  (None, None) when no matching record exists."""
     if cfg_name != "c2" or world != 1:
-        return None
-    path = os.path.join(ROOT, "profiles", "r01_pmc_sweep_c2_packed.json")
+        return None, None
+    for name in ("r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            rec = json.load(open(path))
+            return (rec["hbm_bytes_per_launch"] * rec.get("launches_per_query", 1) / launches,
+                    "replayed from profiles/%s (separate rocprofv3 --pmc passes on the builder's box; not measured in "
+                    "this run)" % name)
+        except Exception:
+            continue
+    return None, None
+
+
+def cpu_model():
     try:
-        rec = json.load(open(path))
-        return rec["hbm_bytes_per_launch"] * rec.get("launches_per_query", 1) / launches
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
     except Exception:
-        return None
+        pass
+    return "unknown"
 
 
 def cpu_baseline(cfg_name, cfg):
-    """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample."""
+    """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample, two modes:
+    faithful = spiral-rs's own threading (server.rs:682-694: the sweep and the fold of an instance run on ONE thread,
+               expansion uses the rayon loops); all_core = lib/server's shape (AVX2 u64-lane sweep,
+               lib/server/src/compute/dot_product.rs:59-95, every core busy: z-rows of the sweep and subtrees of the
+               fold spread over the threads, lib/server/src/server.rs:53-55).  C1 (configs[0]) is also timed in full."""
     import oracle
-    o = oracle.Params(cfg)
     threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
-    cl = oracle.Client(o)
-    pp = cl.generate_keys(11)
-    q = cl.generate_query(12345 % o.num_items, 12)
-    N, dim0, num_per, planes = 2048, o.dim0, o.num_per, o.instances * o.n * o.n
-    t0 = time.time()
-    v_reg, v_fold = o.expand_query(pp, q)
-    v_neg = o.get_v_folding_neg(v_fold)
-    t_expand = time.time() - t0
-    # sweep: nz z-rows of one plane on random words (the u128 MAC loop is data independent)
+    N = 2048
     rng = np.random.default_rng(5)
-    nz = max(1, min(N, (1 << 25) // (num_per * dim0)))
-    dbs = rng.integers(0, 1 << 28, nz * num_per * dim0, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
-    t0 = time.time()
-    oracle.sweep_rows(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
-    t_sweep = (time.time() - t0) * (N / nz) * planes
-    # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
-    k = min(o.db_dim_2, 5)
-    leaves = 1 << k
-    cts_ntt = np.concatenate([rng.integers(0, 249561089, leaves * 2 * 2 * N, dtype=np.uint64)])
-    t0 = time.time()
-    raw = o.from_ntt(cts_ntt)
-    if k > 0:
-        o.fold_ciphertexts(raw, v_fold[:k * 2 * 2 * o.t_gsw * 2 * N], v_neg[:k * 2 * 2 * o.t_gsw * 2 * N], nu=k)
-    t_sub = time.time() - t0
-    t_fold = t_sub * (num_per / leaves) * planes
-    total = t_expand + t_sweep + t_fold
+
+    def rand_words(n):   # residues < 2^28 in both limbs (the MAC loops are data independent)
+        return rng.integers(0, 1 << 28, n, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
+
+    def one(name, c, full):
+        o = oracle.Params(c)
+        cl = oracle.Client(o)
+        pp = cl.generate_keys(11)
+        q = cl.generate_query(12345 % o.num_items, 12)
+        dim0, num_per, planes = o.dim0, o.num_per, o.instances * o.n * o.n
+        t0 = time.time()
+        v_reg, v_fold = o.expand_query(pp, q)
+        v_neg = o.get_v_folding_neg(v_fold)
+        t_expand = time.time() - t0
+        # full: every z-row of every plane and the whole fold tree of every plane are executed (no scaling);
+        # sampled: nz rows of one plane / a subtree, scaled by row count, step count and planes
+        nz = N if full else max(1, min(N, (1 << 25) // (num_per * dim0)))
+        nz1 = nz if full else min(nz, 32)
+        reps = planes if full else 1
+        dbs = rand_words(nz * num_per * dim0)
+        t0 = time.time()
+        for _ in range(reps):
+            oracle.sweep_rows(dbs[:nz1 * num_per * dim0], v_reg[:nz1 * dim0 * 2], nz1, dim0, num_per)
+        t_sweep_1 = (time.time() - t0) * (1 if full else (N / nz1) * planes)
+        oracle.sweep_rows_avx2(dbs[:num_per * dim0], v_reg[:dim0 * 2], 1, dim0, num_per)   # thread-pool warm-up
+        t0 = time.time()
+        for _ in range(reps):
+            oracle.sweep_rows_avx2(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
+        t_sweep_all = (time.time() - t0) * (1 if full else (N / nz) * planes)
+        # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
+        k1 = o.db_dim_2 if full else min(o.db_dim_2, 5)
+        ka = o.db_dim_2 if full else min(o.db_dim_2, 8)
+        w = 2 * 2 * o.t_gsw * 2 * N
+        cts = np.concatenate([rng.integers(0, 249561089, (1 << ka) * 2 * 2 * N, dtype=np.uint64)])
+        t0 = time.time()
+        for _ in range(reps):
+            o.from_ntt_fold_parallel(cts[:(1 << k1) * 4 * N], v_fold[:k1 * w], v_neg[:k1 * w], nu=k1, classes=1)
+        t_fold_1 = (time.time() - t0) * (1 if full else (num_per / (1 << k1)) * planes)
+        t0 = time.time()
+        for _ in range(reps):
+            o.from_ntt_fold_parallel(cts, v_fold[:ka * w], v_neg[:ka * w], nu=ka, classes=threads)
+        t_fold_all = (time.time() - t0) * (1 if full else (num_per / (1 << ka)) * planes)
+        if full:
+            how = ("every z-row of all %d planes and the whole fold tree of every plane executed (random residues as "
+                   "database words), nothing scaled; pack/encode omitted (<1%%)" % planes)
+        else:
+            how = ("sweep: %d of %d z-rows of one plane (AVX2, %d threads) / %d rows (scalar u128, 1 thread), x%d planes; "
+                   "fold: %d-leaf subtree over %d threads / %d-leaf subtree on 1 thread, scaled to %d leaves x %d planes; "
+                   "expand_query + get_v_folding_neg in full; pack/encode omitted (<1%%)" %
+                   (nz, N, threads, nz1, planes, 1 << ka, threads, 1 << k1, num_per, planes))
+        return {"config": name, "sampled": not full,
+                "faithful_qps": 1.0 / (t_expand + t_sweep_1 + t_fold_1),
+                "all_core_qps": 1.0 / (t_expand + t_sweep_all + t_fold_all),
+                "seconds": {"expand": t_expand, "sweep_1thread": t_sweep_1, "fold_1thread": t_fold_1,
+                            "sweep_all_core": t_sweep_all, "fold_all_core": t_fold_all},
+                "sample": how}
+
+    main = one(cfg_name, cfg, full=False)
+    extra = [one(k, CONFIGS[k], full=True) for k in ("c1", "p2")] if cfg_name not in ("c1", "p2", "fast") else []
     return {
-        "value": 1.0 / total, "unit": "queries/s", "cores": threads, "kind": "port",
-        "sample": ("C++ restatement of spiral-rs (oracle/), config %s: expand_query+get_v_folding_neg in full (%.2f s, "
-                   "%d OpenMP threads = the reference's rayon loops); multiply_reg_by_database timed on %d of %d z-rows "
-                   "of one plane and scaled x%d planes (%.1f s/query, single thread as server.rs:682-694); "
-                   "from_ntt+fold_ciphertexts timed on a %d-leaf subtree and scaled to %d leaves x %d planes (%.1f s/query, "
-                   "single thread); pack/encode omitted (<1%%)" %
-                   (cfg_name, t_expand, threads, nz, N, planes, t_sweep, leaves, num_per, planes, t_fold)),
+        "value": main["all_core_qps"], "unit": "queries/s", "cores": threads, "kind": "port",
+        "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "modes": {"all_core": main["all_core_qps"], "faithful": main["faithful_qps"]},
+        "seconds_per_query": main["seconds"],
+        "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = all_core mode (every core busy: AVX2 "
+                  "u64-lane sweep over z-rows as lib/server's dot_product.rs:59-95, fold subtrees in parallel); "
+                  "faithful mode = spiral-rs threading (sweep + fold on one thread per instance, server.rs:682-694). "
+                  "%s" % (cfg_name, main["sample"]),
+        "unsampled": extra,
     }
 
 
@@ -124,18 +197,23 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--config", default=os.environ.get("SPIRAL_BENCH_CONFIG", "c2"), choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default=os.environ.get("SPIRAL_BENCH_MODE", "auto"), choices=["auto", "shard", "replicas"],
+                    help="N > 1: shard (row shards + RCCL exchange, default) or replicas (whole database per GPU, "
+                         "queries split over the GPUs, no collective; BASELINE configs[4])")
     ap.add_argument("--sweep-iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--batch", type=int, default=1,
-                    help="queries per step (N = 1 only); > 1 uses sp_process_query_batch: groups of <= 8 queries "
-                         "share one database pass (BASELINE configs[4]).  Default 1 = the single-query metric.")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="queries per step per GPU (single-GPU and replicas modes): groups of <= 8 queries share one "
+                         "database pass (sp_process_query_batch).  Default 1 (single) / 8 (replicas).")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    os.environ.setdefault("OMP_NUM_THREADS", str(min(64, os.cpu_count() or 1)))   # cpu_baseline: every core
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
-    from sdk_amd.sharding import gather_local, local_cts_tensor, partial_tensor, reduce_partials, scatter_fold_query
+    from sdk_amd.sharding import (Comm, gather_local, local_cts_tensor, partial_tensor, reduce_partials,
+                                  scatter_fold_query)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -148,6 +226,7 @@ def main():
         raise SystemExit("sp_set_device failed")
     # SPIRAL_FORCE_DIST=1: run the N > 1 code path (process group, collectives) at world size 1 (1-GPU boxes)
     use_dist = world > 1 or os.environ.get("SPIRAL_FORCE_DIST") == "1"
+    replicas = args.mode == "replicas"
     real_stdout = None
     if use_dist:
         # RCCL prints a version banner through C stdio on stdout; keep stdout for the one JSON line
@@ -156,17 +235,24 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     cfg = CONFIGS[args.config]
     p = sp.Params(cfg)
+    planes = cfg["instances"] * cfg["n"] ** 2
     pp = sp.PublicParameters.deserialize(p, synthetic_wire_bytes(p.setup_bytes(), 1))
-    queries = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
-    mode = os.environ.get("SPIRAL_MULTIGPU", "scatter") if use_dist else "single"
-    if mode in ("scatter", "columns") and (1 << cfg["nu_2"]) < world:
-        mode = "reduce"
-    db = sp.Database(p, rank, world, by_columns=(mode == "columns")).fill_synthetic(0x123456789)  # util.rs:171-173 seed
+    batch = args.batch if args.batch > 0 else (8 if replicas else 1)
+    n_q = max(4, batch)
+    queries = [synthetic_wire_bytes(p.query_bytes(), 100 + 1000 * (rank if replicas else 0) + i) for i in range(n_q)]
+    if replicas or not use_dist:
+        mode = "replicas" if replicas else "single"
+    else:
+        mode = os.environ.get("SPIRAL_MULTIGPU", "lib")   # lib | torch | reduce | columns
+        if mode in ("lib", "torch", "columns") and (1 << cfg["nu_2"]) < world:
+            mode = "reduce"
+    sharded = mode in ("lib", "torch", "reduce", "columns")
+    db = sp.Database(p, rank if sharded else 0, world if sharded else 1,
+                     by_columns=(mode == "columns")).fill_synthetic(SEED)
     torch.cuda.synchronize()
 
     def barrier():
@@ -174,15 +260,34 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    distributed_fold = mode == "scatter"
-    # stream-ordered flow with the reduce-scatter of plane p overlapping the sweep of plane p+1; verified below
-    # against the host-synchronised flow of the same data path before it is timed
+    comm = None
+    selfcheck = "not_applicable"
     overlap = os.environ.get("SPIRAL_OVERLAP", "1") != "0"
+    if mode == "lib":
+        # the library's own communicator: rank 0 makes the RCCL id, torch.distributed (already up for the barrier /
+        # timing contract) carries the 128 bytes to the other ranks
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                idt.copy_(torch.frombuffer(bytearray(Comm.unique_id()), dtype=torch.uint8))
+            dist.broadcast(idt, src=0)
+            comm = Comm.rccl(rank, world, bytes(idt.cpu().numpy().tobytes()))
+        except Exception as e:  # loud, and every rank takes the same decision
+            print("bench[rank %d]: sp_comm_create failed: %r" % (rank, e), file=sys.stderr, flush=True)
+            comm = None
+        ok = torch.tensor([1 if comm is not None else 0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) != 1:
+            comm, mode, selfcheck = None, "torch", "lib_comm_unavailable"
 
     def step(i):
-        if args.batch > 1 and world == 1:
-            outs = sp.process_query_batch(p, pp, [queries[(i + k) % len(queries)] for k in range(args.batch)], db)
+        """-> (response bytes on rank 0 or None, stage timings or None)"""
+        if mode in ("single", "replicas") and batch > 1:
+            outs = sp.process_query_batch(p, pp, [queries[(i + k) % len(queries)] for k in range(batch)], db)
             return outs[0], None
+        if mode == "lib":
+            out = comm.process_query(p, pp, queries[i % len(queries)], db)
+            return (out if rank == 0 else None), None
         run = sp.QueryRun(p, pp, queries[i % len(queries)], db=db)  # row shards: expansion pruned to the shard's rows
         if mode == "columns":
             # column shards: complete outputs per shard, no partial sums; only the folded cts are gathered
@@ -192,11 +297,9 @@ def main():
             gathered = gather_local(local_cts_tensor(run), rank, world, dst=0)
             torch.cuda.synchronize()
             out = run.finish_gathered(gathered.data_ptr(), world) if rank == 0 else None
-        elif distributed_fold:
-            # row-sharded sweep -> RCCL reduce-scatter over columns -> every rank folds its columns ->
-            # gather of one ciphertext per plane per rank -> rank 0 folds the last log2(N) levels
+        elif mode == "torch":
             out = scatter_fold_query(run, db, rank, world, overlap=overlap)
-        elif use_dist:
+        elif mode == "reduce":
             run.sweep(db)
             run.sync()
             reduce_partials(partial_tensor(run), dst=0)  # RCCL ncclSum over xGMI onto rank 0
@@ -209,94 +312,139 @@ def main():
         run.free()
         return out, t
 
-    if distributed_fold and overlap:
-        # self-check: the overlapped flow must reproduce the synchronised flow's response byte for byte
-        overlap = False
+    if mode in ("lib", "torch") and (mode == "lib" or overlap):
+        # self-check before timing: the stream-ordered flow must reproduce, byte for byte, the host-synchronised
+        # reference flow of the same data path (one sweep launch, one reduce-scatter, torch.distributed collectives).
+        # A disagreement is reported in the JSON line ("overlap_selfcheck": "fell_back") and the synchronised flow is
+        # timed instead -- never silently.
+        fast_mode, fast_overlap = mode, overlap
+        mode, overlap = "torch", False
         ref, _ = step(0)
-        overlap = True
+        mode, overlap = fast_mode, fast_overlap
         try:
             got, _ = step(0)
             good = rank != 0 or got == ref
-        except Exception as e:  # an API error on any rank sends every rank back to the synchronised flow
-            print("bench: overlapped flow raised %r" % (e,), file=sys.stderr, flush=True)
+        except Exception as e:
+            print("bench[rank %d]: %s flow raised %r" % (rank, fast_mode, e), file=sys.stderr, flush=True)
             good = False
         ok = torch.tensor([1 if good else 0], device="cuda")
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) != 1:
-            overlap = False
+        if int(ok.item()) == 1:
+            selfcheck = "ok" if selfcheck == "not_applicable" else selfcheck + "; torch overlapped flow ok"
+        else:
+            mode, overlap, selfcheck = "torch", False, "fell_back"
             if rank == 0:
-                print("bench: overlapped multi-GPU flow disagreed with the synchronised flow; timing the latter",
+                print("bench: the stream-ordered multi-GPU flow DISAGREED with the synchronised flow; timing the latter",
                       file=sys.stderr, flush=True)
     for i in range(args.warmup):
         step(i)
     barrier()
     t0 = time.perf_counter()
     stage = np.zeros(4)
+    rank_ms = np.zeros(2)
     for i in range(args.steps):
         out, t = step(i)
         if t is not None:
             stage += np.array(t)
+        if mode == "lib":
+            rank_ms += np.array(comm.timings()[:2])
     barrier()
-    elapsed = time.perf_counter() - t0
+    my_elapsed = time.perf_counter() - t0
+    elapsed = my_elapsed
+    per_rank = None
     if use_dist:
-        tt = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        tt = torch.tensor([my_elapsed], device="cuda", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed * 1e3 / args.steps
 
     # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
     run = sp.QueryRun(p, pp, queries[0], db=db)
-    if distributed_fold and overlap:                          # one launch per plane, exchange overlapped
-        sweep_ms, launches = run.bench_sweep(db, args.sweep_iters, per_plane=1), cfg["instances"] * cfg["n"] ** 2
+    per_plane_flow = mode in ("lib",) or (mode == "torch" and overlap)
+    if per_plane_flow:                                        # one launch per plane, exchange overlapped
+        sweep_ms, launches = run.bench_sweep(db, args.sweep_iters, per_plane=1), planes
     else:                                                     # 1, or one per plane when the fold is overlapped
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters), run.sweep_launches(db)
     run.free()
-    alg_bytes = sweep_algorithmic_bytes(cfg, world) / launches
-    standalone = alg_bytes / (sweep_ms * 1e-3) / 1e9
+    shards = world if sharded else 1
+    alg_bytes = sweep_algorithmic_bytes(cfg, shards) / launches
+    moved_bytes = sweep_moved_bytes(cfg, shards, db.device_bytes()) / launches
     # In the timed region the sweep launches are the only work on the query's main stream between the "expanded" and
     # "swept" HIP events, so that span / launches is the kernel's average duration in the real run -- including what
     # it loses to the folds that share the CUs from the second stream.  (Batched steps have no per-query span.)
-    in_situ_ms = stage[1] / args.steps / launches if (stage[1] > 0 and args.batch == 1) else sweep_ms
-    achieved = alg_bytes / (in_situ_ms * 1e-3) / 1e9
+    if mode == "single" and batch == 1 and stage[1] > 0:
+        in_situ_ms, in_situ_src = stage[1] / args.steps / launches, "HIP events around the sweep launches inside the timed steps"
+    elif mode == "lib" and rank_ms[0] > 0:
+        in_situ_ms, in_situ_src = rank_ms[0] / args.steps / launches, "HIP events around the per-plane sweep launches inside the timed steps (rank 0)"
+    else:
+        in_situ_ms, in_situ_src = sweep_ms, "stand-alone launches (no per-query span in this mode)"
+    achieved = moved_bytes / (in_situ_ms * 1e-3) / 1e9
+    standalone = moved_bytes / (sweep_ms * 1e-3) / 1e9
+    if use_dist:
+        pr = torch.tensor([my_elapsed * 1e3 / args.steps, sweep_ms * launches, in_situ_ms * launches], device="cuda",
+                          dtype=torch.float64)
+        allr = [torch.zeros_like(pr) for _ in range(world)]
+        dist.all_gather(allr, pr)
+        per_rank = {"step_ms": [float(x[0]) for x in allr], "sweep_standalone_ms_per_query": [float(x[1]) for x in allr],
+                    "sweep_in_situ_ms_per_query": [float(x[2]) for x in allr]}
 
     if rank == 0:
+        q_per_step = batch * (world if replicas else 1) if mode in ("single", "replicas") else 1
+        traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches)
+        kernel = ("k_sweep_packed_batch" if batch > 1 else "k_sweep_packed_persist<4>") if cfg["nu_2"] >= 7 else "k_sweep_narrow2"
+        workload_how = {
+            "single": "unsharded, one query per step" if batch == 1 else "unsharded, %d queries per step (<= 8 per database pass)" % batch,
+            "replicas": "whole database on each of the %d GPUs, %d queries per GPU per step (one database pass), no collective in the timed region (BASELINE configs[4])" % (world, batch),
+            "lib": "row-sharded dim0/%d per GPU; RCCL reduce-scatter of the partial Regev cts per plane (overlapping the next plane's sweep), distributed fold, all-gather -- issued by libspiral_hip.so (sp_process_query_sharded)" % world,
+            "torch": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts%s, distributed fold, all-gather (torch.distributed)" % (world, " (per plane, overlapping the next plane's sweep)" if overlap else ", host-synchronised"),
+            "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world,
+            "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]
         line = {
-            "metric": "PIR queries/sec (single query, full answer path) on 2^%d items x %d B" %
-                      (cfg["nu_1"] + cfg["nu_2"], cfg["db_item_size"]),
-            "value": args.steps * (args.batch if world == 1 else 1) / elapsed,
+            "metric": "PIR queries/sec (full answer path) on 2^%d items x %d B" % (cfg["nu_1"] + cfg["nu_2"], cfg["db_item_size"]),
+            "value": args.steps * q_per_step / elapsed,
             "unit": "queries/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak" if replicas else "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
+            "mode": mode,
+            "rccl_ranks": dist.get_world_size() if use_dist else 1,
+            "overlap_selfcheck": selfcheck,
+            "per_rank": per_rank,
             "config": {"arithmetic": "exact integers: u32 x u32 -> u64 multiply-accumulate mod two 28-bit primes, u32 NTT "
                                      "butterflies (Shoup), no floating point",
-                       "workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB resident in HBM, "
-                                   "%s" % (args.config, json.dumps(cfg, sort_keys=True),
-                                           p.db_words * 8 / 2**30,
-                                           "unsharded" if world == 1 else {"scatter": "row-sharded dim0/%d per GPU + RCCL reduce-scatter of partial Regev cts%s, distributed fold, all-gather" % (world, " (per plane, overlapping the next plane's sweep)" if overlap else ""), "reduce": "row-sharded dim0/%d per GPU + RCCL reduce onto rank 0" % world, "columns": "column-sharded num_per/%d per GPU, distributed fold, all-gather (no partial sums)" % world}[mode]),
-                       "queries_per_step": args.batch if world == 1 else 1,
+                       "workload": "spiral-rs process_query, %s = %s, encoded DB %.1f GiB (%.1f GiB resident per GPU), %s" %
+                                   (args.config, json.dumps(cfg, sort_keys=True), p.db_words * 8 / 2**30,
+                                    db.device_bytes() / 2**30, workload_how),
+                       "queries_per_step": q_per_step,
                        "stage_ms": {"expand": stage[0] / args.steps, "sweep": stage[1] / args.steps,
-                                    "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps}},
-            "roofline": {"bound": "hbm", "kernel": "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2",
+                                    "fold": stage[2] / args.steps, "pack_encode": stage[3] / args.steps},
+                       "rank0_ms": {"sweep_with_overlapped_exchange": rank_ms[0] / args.steps,
+                                    "exchange_tail_fold_gather": rank_ms[1] / args.steps} if mode == "lib" else None},
+            "roofline": {"bound": "hbm", "kernel": kernel,
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": pmc_traffic(args.config, world, launches),
-                         "algorithmic_bytes_per_launch": alg_bytes, "ms_per_launch": in_situ_ms,
+                         "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "traffic_source": traffic_source,
+                         "bytes_per_launch": moved_bytes, "ms_per_launch": in_situ_ms, "ms_per_launch_source": in_situ_src,
                          "launches_per_query": launches,
                          "standalone": {"ms_per_launch": sweep_ms, "achieved": standalone, "frac": standalone / HBM_PEAK_GBPS,
                                         "note": "the same launches issued back to back with nothing else on the GPU "
                                                 "(sp_bench_sweep, HIP events on the launch stream)"},
-                         "note": "achieved = algorithmic bytes (reference 8-byte words) / average duration of a sweep "
-                                 "launch inside the timed steps (HIP events on its stream; the fold of the previous plane "
-                                 "runs beside it); the resident database is bit-packed to 7 bytes per word, so HBM traffic "
-                                 "(PMC, profiles/r01_pmc_sweep_c2_packed.json) is below the algorithmic bytes"},
+                         "reference_format_equivalent": {
+                             "bytes_per_launch": alg_bytes, "GBps": alg_bytes / (in_situ_ms * 1e-3) / 1e9,
+                             "note": "SURVEY.md 8(d) counts the reference's 8-byte words; the resident database is bit-"
+                                     "packed to 7 bytes per word, so this rate is 8/7 of the bytes really moved and is "
+                                     "NOT a fraction of the hardware peak"},
+                         "note": "achieved = bytes this implementation moves per launch (PACKED 7-byte database words + "
+                                 "query slice + u32 outputs; equals the PMC-measured traffic) / average duration of a "
+                                 "sweep launch; peak = HBM3E spec; a plain device copy reaches ~6300 GB/s on this part"},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         else:
             line["cpu_baseline"] = None
@@ -307,6 +455,8 @@ def main():
         print(json.dumps(line), flush=True)
         if real_stdout is not None:
             os.dup2(2, 1)
+    if comm is not None:
+        comm.free()
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()

