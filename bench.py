@@ -150,7 +150,7 @@ def cpu_baseline(cfg_name, cfg):
         t_sweep_all = (time.time() - t0) * (1 if full else (N / nz) * planes)
         # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
         k1 = o.db_dim_2 if full else min(o.db_dim_2, 5)
-        ka = o.db_dim_2 if full else min(o.db_dim_2, 8)
+        ka = o.db_dim_2 if full else min(o.db_dim_2, 11)   # all-core: the whole tree of a plane (its serial top included)
         w = 2 * 2 * o.t_gsw * 2 * N
         cts = np.concatenate([rng.integers(0, 249561089, (1 << ka) * 2 * 2 * N, dtype=np.uint64)])
         t0 = time.time()

@@ -688,7 +688,10 @@ static void fold_parallel(const Params& p, std::vector<PolyMatrixRaw>& cts, cons
     fold_ciphertexts(p, mine, vf_loc, vfn_loc);
     tops[g] = mine[0];
   }
-  fold_ciphertexts(p, tops, vf_top, vfn_top);
+  // the tree over the G class results: the same split again (about sqrt(G) classes) keeps the sequential chain short
+  size_t sub = 1;
+  while (sub * sub < G) sub *= 2;
+  fold_parallel(p, tops, vf_top, vfn_top, sub >= G ? 1 : sub);
   cts[0] = tops[0];
 }
 

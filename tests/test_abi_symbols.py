@@ -26,6 +26,22 @@ def test_every_declared_symbol_is_exported():
     assert not missing, missing
 
 
+def test_rust_shim_declares_every_symbol():
+    """rust/src/hip.rs (source only: no rustc in the image) keeps an extern declaration for every entry point of
+    include/spiral_hip.h, with the same number of arguments"""
+    hdr = open(os.path.join(ROOT, "include", "spiral_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    rs = open(os.path.join(ROOT, "rust", "src", "hip.rs")).read()
+    for name in _declared():
+        m = re.search(r"\b%s\s*\(([^;]*?)\)\s*;" % name, hdr, flags=re.S)
+        assert m, name
+        c_args = [a for a in m.group(1).split(",") if a.strip() and a.strip() != "void"]
+        r = re.search(r"pub fn %s\s*\(([^;]*?)\)\s*(->[^;]*)?;" % name, rs, flags=re.S)
+        assert r, "rust/src/hip.rs lacks %s" % name
+        r_args = [a for a in r.group(1).split(",") if a.strip()]
+        assert len(r_args) == len(c_args), (name, c_args, r_args)
+
+
 def test_host_only_entry_points(oracle_mod):
     import sdk_amd as sp
     from conftest import C2, FAST, P2
