@@ -55,6 +55,9 @@ const char* sp_last_error(void);
  * by a silently selected fallback kernel.  reset != 0 clears the mask after reading it. */
 uint64_t sp_paths_taken(int reset);
 const char* sp_path_name(int bit); /* NULL past the last defined bit */
+/* Run-time tunables for A/B measurements inside one process (the same switches as the SPIRAL_<NAME> environment
+ * variables of DESIGN.md section 8, e.g. "pipe_wgs", "pipe_unroll", "sweep_prio", "cu_split"): takes effect on the next launch / next workspace. */
+int sp_debug_set(const char* name, long value);
 /* Number of visible HIP devices (0 if none); selects `device` for this thread's subsequent calls. */
 int sp_device_count(void);
 int sp_set_device(int device);
@@ -242,6 +245,11 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
 /* per_plane_launches: 1 = one launch per plane (what sp_query_sweep_scatter_plane issues), 0 = one launch,
  * -1 = what sp_query_sweep would do for this db (sp_bench_sweep). */
 int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane_launches, float* ms_per_launch);
+
+/* Diagnostics: where workgroups land.  `blocks` 64-thread workgroups are launched on a stream whose CU mask has bits
+ * [bit_lo, bit_hi) set (no mask when bit_hi <= bit_lo); out2[2b] = HW_REG_XCC_ID, out2[2b+1] = HW_REG_HW_ID of
+ * workgroup b.  Used to verify the CU partition of the fold / sweep overlap (SPIRAL_CU_SPLIT). */
+int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2);
 
 /* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient
  * vectors per thread, `blocks` workgroups each chaining `reps` transforms, no memory traffic but twiddles). */

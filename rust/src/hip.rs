@@ -58,6 +58,7 @@ pub mod sys {
         pub fn sp_last_error() -> *const c_char;
         pub fn sp_paths_taken(reset: c_int) -> u64;
         pub fn sp_path_name(bit: c_int) -> *const c_char;
+        pub fn sp_debug_set(name: *const c_char, value: c_long) -> c_int;
         pub fn sp_device_count() -> c_int;
         pub fn sp_set_device(device: c_int) -> c_int;
         // ---- Params (util.rs:219-263, params.rs:49-200)
@@ -127,6 +128,7 @@ pub mod sys {
         pub fn sp_bench_sweep(q: *mut sp_query_t, db: *const sp_db_t, iters: c_int, ms_per_launch: *mut f32) -> c_int;
         pub fn sp_bench_sweep_ex(q: *mut sp_query_t, db: *const sp_db_t, iters: c_int, per_plane_launches: c_int,
                                  ms_per_launch: *mut f32) -> c_int;
+        pub fn sp_debug_cu_probe(bit_lo: c_int, bit_hi: c_int, blocks: c_int, out2: *mut u32) -> c_int;
         pub fn sp_bench_ntt(p: *const sp_params_t, m: c_int, blocks: c_int, reps: c_int, ns_per_ntt: *mut f32) -> c_int;
         // ---- stage level, 1:1 with the reference's pub functions (host arrays in the reference layouts)
         pub fn sp_ntt_forward(p: *const sp_params_t, data: *mut u64, count: usize) -> c_int;

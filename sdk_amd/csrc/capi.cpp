@@ -46,7 +46,10 @@ struct sp_query {
     if (ws && params) {
       (void)hipStreamSynchronize(ws->stream);
       (void)hipStreamSynchronize(ws->stream2);
+      if (ws->s_sweep) (void)hipStreamSynchronize(ws->s_sweep);
+      if (ws->s_fold) (void)hipStreamSynchronize(ws->s_fold);
       ws->pipelined = false;
+      ws->have_sweep_span = false;
       params->release_ws(std::move(ws));
     }
   }
@@ -105,6 +108,11 @@ extern "C" {
 const char* sp_last_error(void) { return g_last_error.c_str(); }
 
 uint64_t sp_paths_taken(int reset) { return paths_taken(reset != 0); }
+int sp_debug_set(const char* name, long value) {
+  if (!name) return SP_E_ARG;
+  set_tunable(name, value);
+  return SP_OK;
+}
 // internal hooks for comm.cpp (not declared in the public header)
 void sp_set_last_error_(const char* msg) { g_last_error = msg ? msg : ""; }
 void sp_note_path_(uint64_t bits) { note_path(bits); }
@@ -114,7 +122,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
-                                "rccl_in_library", "fold_fused_lowreg"};
+                                "rccl_in_library", "fold_fused_lowreg", "cu_split_overlap"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -656,6 +664,8 @@ int sp_query_sync(sp_query_t* q) {
     need(q && q->ws, "null query");
     HIP_CHECK(hipStreamSynchronize(q->ws->stream));
     HIP_CHECK(hipStreamSynchronize(q->ws->stream2));
+    if (q->ws->s_sweep) HIP_CHECK(hipStreamSynchronize(q->ws->s_sweep));
+    if (q->ws->s_fold) HIP_CHECK(hipStreamSynchronize(q->ws->s_fold));
   });
 }
 
@@ -678,6 +688,16 @@ static void finish_impl(sp_query_t* q, bool premod, uint8_t* out, size_t out_cap
   q->ms[2] = t;
   HIP_CHECK(hipEventElapsedTime(&t, W.ev[3], W.ev[4]));
   q->ms[3] = t;
+  if (W.have_sweep_span) {
+    // pipelined sweeps: [1] = first sweep launch begins -> last sweep launch done (on the stream that carries them),
+    // [2] = what is left of the span expanded -> folded (the exposed part of the last plane's fold)
+    float sw = 0, tot = 0;
+    HIP_CHECK(hipEventElapsedTime(&sw, W.ev_sw[0], W.ev_sw[1]));
+    HIP_CHECK(hipEventElapsedTime(&tot, W.ev[1], W.ev[3]));
+    q->ms[1] = sw;
+    q->ms[2] = tot > sw ? tot - sw : 0.f;
+    W.have_sweep_span = false;
+  }
   q->state = 3;
 }
 
@@ -821,6 +841,31 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
 int sp_sweep_launches(const sp_params_t* h, const sp_db_t* db) {
   if (!h || !db) return 0;
   return sweep_is_pipelined(h->p, *db) ? (int)h->p.planes() : 1;
+}
+
+// Placement probe: launches `blocks` small workgroups on a stream whose CU mask has bits [bit_lo, bit_hi) set (the
+// whole device when bit_hi <= bit_lo) and reports the XCC / HW_ID registers each one saw.
+int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2) {
+  return guarded([&] {
+    need(out2 && blocks > 0 && blocks <= 65536, "bad argument");
+    hipStream_t s = nullptr;
+    if (bit_hi > bit_lo) {
+      hipDeviceProp_t prop;
+      int dev = 0;
+      HIP_CHECK(hipGetDevice(&dev));
+      HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+      std::vector<uint32_t> m((prop.multiProcessorCount + 31) / 32, 0u);
+      for (int k = bit_lo; k < bit_hi && k < prop.multiProcessorCount; k++) m[k / 32] |= 1u << (k % 32);
+      HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)m.size(), m.data()));
+    } else {
+      HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    }
+    DevBuf<u32> d((size_t)blocks * 2);
+    launch_cu_probe(d.p, blocks, s);
+    HIP_CHECK(hipMemcpyAsync(out2, d.p, (size_t)blocks * 8, hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipStreamDestroy(s);
+  });
 }
 
 // transform-core micro-benchmark (profiling aid): ns per 2048-point forward NTT with M vectors per thread

@@ -345,4 +345,22 @@ void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipS
   launched(0, "k_reorient");
 }
 
+// ---- placement probe (diagnostics): every workgroup records which XCC / shader engine / CU it ran on -------------
+__global__ __launch_bounds__(64) void k_cu_probe(u32* out) {
+  u32 xcc, hw;
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+  asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+  // burn a little time so that the grid spreads over every CU the queue may use
+  u32 acc = threadIdx.x;
+  for (int i = 0; i < 20000; i++) acc = acc * 1664525u + 1013904223u;
+  if (threadIdx.x == 0) {
+    out[blockIdx.x * 2] = xcc;
+    out[blockIdx.x * 2 + 1] = hw | ((acc & 1u) << 31);
+  }
+}
+void launch_cu_probe(u32* out, int blocks, hipStream_t s) {
+  hipLaunchKernelGGL(k_cu_probe, dim3(blocks), dim3(64), 0, s, out);
+  launched(0, "k_cu_probe");
+}
+
 }  // namespace spiral

@@ -43,8 +43,12 @@ enum PathBit : u64 {
   PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_head (first expansion rounds in one launch)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
-  PATH_FOLD_FUSED_LOWREG = 1ull << 20 // k_fold_fused3 (4 waves per SIMD form)
+  PATH_FOLD_FUSED_LOWREG = 1ull << 20,// k_fold_fused3 (lower-VGPR form)
+  PATH_CU_SPLIT = 1ull << 21          // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
 };
+// Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
+// measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
+long tunable(const char* name, long dflt);  // server.cpp
 void launched(u64 path_bits, const char* kernel);  // server.cpp
 void note_path(u64 path_bits);
 
@@ -183,6 +187,9 @@ void launch_gadget_raw(u64* out, const u64* inp, int rows_in, int cols, int rows
 void launch_u64_to_u32(u32* out, const u64* in, long n, hipStream_t s);
 void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s);
 
+// diagnostics: out[2b] = HW_REG_XCC_ID, out[2b+1] = HW_REG_HW_ID of workgroup b
+void launch_cu_probe(u32* out, int blocks, hipStream_t s);
+
 // ---- encode (server.rs:470-503) on the device: rescale (arith.rs:429-444) + LSB-first bit packing -------------
 // packed: [instances][(n+1) x n raw polys]; out: zeroed buffer of response_bytes/8 u64 words (atomicOr packing)
 struct EncodeDesc {
@@ -231,7 +238,7 @@ inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {
 }
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
 // persistent PACKED sweep with a capped footprint (wgs_per_cu workgroups per CU, `unroll` row pairs in flight)
-void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus = 256);
 // B queries against ONE pass over the (PACKED) database: every database word is multiplied into B
 // accumulator sets.  B <= SWEEP_BATCH_MAX; qv[b] / out[b] as in SweepDesc.
 constexpr int SWEEP_BATCH_MAX = 8;

@@ -14,6 +14,15 @@ struct Workspace {
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
+  // CU-partitioned overlap (SPIRAL_CU_SPLIT = n > 0): the per-plane sweeps run on a stream masked to all but n CUs
+  // (n/8 in every XCD) and the overlapped folds on a stream masked to those n CUs, so the two never share a CU's
+  // issue slots, LDS or L1; created on first use (hipExtStreamCreateWithCUMask)
+  hipStream_t s_sweep = nullptr, s_fold = nullptr;
+  int split_fold_cus = -1, split_sweep_cus = 0;   // -1: not probed yet, 0: off
+  hipEvent_t ev_split_begin = nullptr;
+  hipEvent_t ev_sw[2] = {nullptr, nullptr};  // first sweep launch begins / last sweep launch done (timing)
+  bool have_sweep_span = false;
+  void ensure_split_streams();
   bool pipelined = false;                   // set by run_sweep_pipelined, consumed by run_finish
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
   // expansion

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 
 #include "pipeline.hpp"
 
@@ -18,6 +19,33 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
     (void)hipGetLastError();
     throw HipError(std::string(what) + " failed at " + file + ":" + std::to_string(line) + ": " + hipGetErrorString(e));
   }
+}
+
+// ---- tunables: sp_debug_set(name, v) overrides, else SPIRAL_<NAME> from the environment, else the default
+static std::mutex g_tun_mu;
+static std::vector<std::pair<std::string, long>> g_tun;
+void set_tunable(const char* name, long v) {
+  std::lock_guard<std::mutex> lk(g_tun_mu);
+  for (auto& kv : g_tun)
+    if (kv.first == name) {
+      kv.second = v;
+      return;
+    }
+  g_tun.emplace_back(name, v);
+}
+long tunable(const char* name, long dflt) {
+  {
+    std::lock_guard<std::mutex> lk(g_tun_mu);
+    for (auto& kv : g_tun)
+      if (kv.first == name) return kv.second;
+  }
+  std::string env = "SPIRAL_";
+  for (const char* c = name; *c; c++) env += (char)toupper((unsigned char)*c);
+  const char* e = getenv(env.c_str());
+  const long v = e ? atol(e) : dflt;
+  std::lock_guard<std::mutex> lk(g_tun_mu);
+  g_tun.emplace_back(name, v);  // cache the environment lookup
+  return v;
 }
 
 static thread_local u64 g_paths = 0;
@@ -307,6 +335,7 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   ev_plane.resize(P.planes());
   for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+  for (auto& e : ev_sw) HIP_CHECK(hipEventCreate(&e));
   HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
   h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
   HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
@@ -325,8 +354,40 @@ Workspace::~Workspace() {
   for (auto& e : ev_plane)
     if (e) (void)hipEventDestroy(e);
   if (ev_fold) (void)hipEventDestroy(ev_fold);
+  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1]})
+    if (e) (void)hipEventDestroy(e);
+  if (s_sweep) (void)hipStreamDestroy(s_sweep);
+  if (s_fold) (void)hipStreamDestroy(s_fold);
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
+}
+
+// SPIRAL_CU_SPLIT = n: CU bit k of a stream's mask is CU (k / 8) of XCD (k % 8) on this part (the driver deals the mask
+// bits round-robin over the 8 XCCs), so the low n bits give the fold n/8 CUs in every XCD and the sweep the rest: both
+// partitions keep all 8 L2s and every HBM channel.
+void Workspace::ensure_split_streams() {
+  if (split_fold_cus >= 0) return;
+  split_fold_cus = 0;
+  const int n = (int)tunable("cu_split", 0);
+  if (n <= 0) return;
+  hipDeviceProp_t prop;
+  HIP_CHECK(hipGetDeviceProperties(&prop, device));
+  const int total = prop.multiProcessorCount;
+  if (n >= total) return;
+  std::vector<uint32_t> mf((total + 31) / 32, 0u), ms((total + 31) / 32, 0u);
+  for (int k = 0; k < total; k++) (k < n ? mf : ms)[k / 32] |= 1u << (k % 32);
+  hipStream_t a = nullptr, b = nullptr;
+  if (hipExtStreamCreateWithCUMask(&a, (uint32_t)ms.size(), ms.data()) != hipSuccess ||
+      hipExtStreamCreateWithCUMask(&b, (uint32_t)mf.size(), mf.data()) != hipSuccess) {
+    (void)hipGetLastError();
+    if (a) (void)hipStreamDestroy(a);
+    return;  // no CU masking on this system: the shared-CU overlap stays in use
+  }
+  s_sweep = a;
+  s_fold = b;
+  HIP_CHECK(hipEventCreateWithFlags(&ev_split_begin, hipEventDisableTiming));
+  split_fold_cus = n;
+  split_sweep_cus = total - n;
 }
 
 void Workspace::ensure_expand() {
@@ -656,32 +717,67 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
   const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
               (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
-  static const int wgs = [] { const char* e = getenv("SPIRAL_PIPE_WGS"); return e ? atoi(e) : 4; }();
-  static const int unr = [] { const char* e = getenv("SPIRAL_PIPE_UNROLL"); return e ? atoi(e) : 4; }();
+  const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
   if (db.packed && wgs > 0)
-    launch_sweep_persist(W.D->T, d, wgs, unr, W.stream);
+    launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);
   else
     launch_sweep(W.D->T, d, W.stream);
+}
+
+static void on_stream(Workspace& W, hipStream_t s, const std::function<void()>& f) {
+  hipStream_t saved = W.stream;
+  W.stream = s;
+  try {
+    f();
+  } catch (...) {
+    W.stream = saved;
+    throw;
+  }
+  W.stream = saved;
 }
 
 void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
   W.ensure_finish();
-  for (size_t pl = 0; pl < p.planes(); pl++) {
+  W.ensure_split_streams();
+  const size_t planes = p.planes();
+  if (W.split_fold_cus > 0) {
+    // sweeps and folds on disjoint CU sets; the last plane's fold (nothing left to overlap with) on every CU
+    hipStream_t main = W.stream;
+    HIP_CHECK(hipEventRecord(W.ev_split_begin, main));
+    HIP_CHECK(hipStreamWaitEvent(W.s_sweep, W.ev_split_begin, 0));
+    HIP_CHECK(hipStreamWaitEvent(W.s_fold, W.ev_split_begin, 0));
+    HIP_CHECK(hipEventRecord(W.ev_sw[0], W.s_sweep));
+    for (size_t pl = 0; pl < planes; pl++) {
+      on_stream(W, W.s_sweep, [&] { launch_plane_sweep(W, db, pl); });
+      HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.s_sweep));
+      if (pl + 1 < planes) {
+        HIP_CHECK(hipStreamWaitEvent(W.s_fold, W.ev_plane[pl], 0));
+        on_stream(W, W.s_fold, [&] { fold_planes(W, pl, 1, false); });
+      }
+    }
+    HIP_CHECK(hipEventRecord(W.ev_sw[1], W.s_sweep));
+    HIP_CHECK(hipEventRecord(W.ev_fold, W.s_fold));
+    HIP_CHECK(hipStreamWaitEvent(main, W.ev_fold, 0));              // foldX / foldY are shared by all planes
+    HIP_CHECK(hipStreamWaitEvent(main, W.ev_plane[planes - 1], 0));
+    fold_planes(W, planes - 1, 1, false);
+    HIP_CHECK(hipEventRecord(W.ev_fold, main));
+    W.have_sweep_span = true;
+    W.pipelined = true;
+    note_path(PATH_PIPELINED | PATH_CU_SPLIT);
+    return;
+  }
+  HIP_CHECK(hipEventRecord(W.ev_sw[0], W.stream));
+  for (size_t pl = 0; pl < planes; pl++) {
     launch_plane_sweep(W, db, pl);
     HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
     HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
-    std::swap(W.stream, W.stream2);
-    try {
-      fold_planes(W, pl, 1, false);
-    } catch (...) {
-      std::swap(W.stream, W.stream2);
-      throw;
-    }
-    std::swap(W.stream, W.stream2);
+    on_stream(W, W.stream2, [&] { fold_planes(W, pl, 1, false); });
   }
+  HIP_CHECK(hipEventRecord(W.ev_sw[1], W.stream));
   HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
+  W.have_sweep_span = true;
   W.pipelined = true;
   note_path(PATH_PIPELINED);
 }

@@ -28,7 +28,8 @@ struct OomError : std::runtime_error {
 
 void hip_check(hipError_t e, const char* what, const char* file, int line);
 #define HIP_CHECK(x) ::spiral::hip_check((x), #x, __FILE__, __LINE__)
-u64 paths_taken(bool reset);  // thread-local PathBit mask accumulated by launched() / note_path()
+u64 paths_taken(bool reset);
+void set_tunable(const char* name, long v);  // thread-local PathBit mask accumulated by launched() / note_path()
 
 // RAII device buffer
 template <typename T>

@@ -238,10 +238,10 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
                      (u32)a03, (u32)a13);
   }
 }
-void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s) {
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus) {
   const int units = d.planes * N * (d.num_per >> 7);
-  const dim3 grid((unsigned)std::min(256 * wgs_per_cu, (units + 3) / 4));
-  static const int prio = [] { const char* e = getenv("SPIRAL_SWEEP_PRIO"); return e ? atoi(e) : 1; }();
+  const dim3 grid((unsigned)std::min(n_cus * wgs_per_cu, (units + 3) / 4));
+  const int prio = (int)tunable("sweep_prio", 1);
   switch (unroll) {
     case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio); break;
     case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio); break;
@@ -493,12 +493,10 @@ __global__ __launch_bounds__(256) void k_sweep_narrow2(DevTables T, SweepDesc d)
 
 const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
 
-void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s);
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
   // default: persistent grid of 4 workgroups per CU, 4 row pairs in flight per lane (profiles/r01_sweep_variants.md);
   // SPIRAL_SWEEP_PERSIST_WGS=0 selects the one-wave-per-unit grid
-  static const int persist_wgs = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_WGS"); return e ? atoi(e) : 4; }();
-  static const int persist_unr = [] { const char* e = getenv("SPIRAL_SWEEP_PERSIST_UNROLL"); return e ? atoi(e) : 4; }();
+  const int persist_wgs = (int)tunable("sweep_persist_wgs", 4), persist_unr = (int)tunable("sweep_persist_unroll", 4);
   if (d.packed && persist_wgs > 0) {
     launch_sweep_persist(T, d, persist_wgs, persist_unr, s);
     return;
