@@ -36,6 +36,7 @@ extern "C" {
 #define SP_E_HIP (-2)    /* HIP runtime error or no device */
 #define SP_E_OOM (-3)    /* device or host allocation failed */
 #define SP_E_STATE (-4)  /* call sequence error */
+#define SP_E_NOTFOUND (-5) /* unknown client uuid (lib/server Error::NotFound -> HTTP 404, lib/server/src/error.rs:7-34) */
 
 /* Row shards per database: each shard emits partial residues < q < 2^28 that the exchange step sums element-wise in
  * 32 bits (ncclSum on ncclUint32); 8 * (q - 1) < 2^31, so 8 is the largest shard count that can never overflow.
@@ -234,6 +235,34 @@ int sp_process_query_sharded(sp_comm_t*, const sp_params_t*, const sp_pp_t*, con
  * launches (the exchanges of the earlier planes run beside them), [1] exchange tail + local fold + all-gather,
  * [2] reserved */
 int sp_comm_timings(const sp_comm_t*, float* ms3);
+
+/* ------------------------------------------------------ request layer (lib/server's binary without the HTTP transport)
+ * ServerState of lib/server/src/bin/server.rs:21-28: the params, the resident database and the
+ * RwLock<HashMap<uuid, PublicParameters>> that POST /setup fills and POST /private-read consults.  `params` and `db` are
+ * borrowed and must outlive the handle.  All entry points may be called concurrently from several host threads. */
+typedef struct sp_server sp_server_t;
+sp_server_t* sp_server_create(const sp_params_t* params, const sp_db_t* db);
+void sp_server_free(sp_server_t*);
+size_t sp_server_clients(const sp_server_t*); /* registered public-parameter sets */
+/* POST /setup (bin/server.rs:71-94) after base64 decoding: deserialize (length must be setup_bytes), NTT, keep resident
+ * under a fresh UUIDv4; uuid_out37 receives the 36 characters + NUL. */
+int sp_server_setup(sp_server_t*, const uint8_t* pp_bytes, size_t len, char* uuid_out37);
+/* The same on the HTTP body: a JSON string holding base64(public parameters); out = {"uuid":"..."} (NUL-terminated). */
+int sp_server_setup_json(sp_server_t*, const char* body, size_t body_len, char* out, size_t out_cap, size_t* out_len);
+/* Drop a client's public parameters (not in the reference, which never evicts). SP_E_NOTFOUND for an unknown uuid. */
+int sp_server_forget(sp_server_t*, const char* uuid);
+/* POST /private-read (bin/server.rs:98-164) on decoded requests: request i is uuid (36 bytes) || serialized query when
+ * the params expand queries (bin/server.rs:107-121), serialized public parameters || query otherwise (:123-138).  The
+ * reference answers the list one query at a time (:152-158); here the whole list goes through the batch scheduler
+ * (sp_process_query_batch: groups of <= 8 queries share one pass over the database, each with its own client's public
+ * parameters).  Response i (response_bytes long) is written at out + i * out_stride.  A malformed length is SP_E_ARG
+ * (the reference asserts), an unknown uuid SP_E_NOTFOUND; nothing is answered in either case. */
+int sp_server_private_read(sp_server_t*, const uint8_t* const* requests, const size_t* request_lens, int n, uint8_t* out,
+                           size_t out_stride, size_t* out_lens);
+/* The same on the HTTP body: JSON list of base64 strings in, JSON list of base64 strings out (NUL-terminated; the text
+ * serde_json / the base64 crate produce: no spaces, standard alphabet, padding). */
+int sp_server_private_read_json(sp_server_t*, const char* body, size_t body_len, char* out, size_t out_cap, size_t* out_len);
+size_t sp_server_private_read_json_bound(const sp_server_t*, int n_queries); /* out_cap that always suffices */
 
 /* Stand-alone timed sweep for the roofline measurement: issues the db-sweep launches of one query over `db`
  * (the same kernel and launch shapes sp_process_query uses) `iters` times with the query slice of `q`, HIP events

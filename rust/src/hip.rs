@@ -19,6 +19,7 @@ pub mod sys {
     pub const SP_E_HIP: c_int = -2;
     pub const SP_E_OOM: c_int = -3;
     pub const SP_E_STATE: c_int = -4;
+    pub const SP_E_NOTFOUND: c_int = -5;
     pub const SP_MAX_ROW_SHARDS: c_int = 8;
     pub const SP_COMM_ID_BYTES: usize = 128;
 
@@ -40,6 +41,10 @@ pub mod sys {
     }
     #[repr(C)]
     pub struct sp_comm_t {
+        _p: [u8; 0],
+    }
+    #[repr(C)]
+    pub struct sp_server_t {
         _p: [u8; 0],
     }
     /// Host-supplied collectives for `sp_comm_create_custom` (enqueue on `hip_stream`, never block on it).
@@ -123,6 +128,19 @@ pub mod sys {
                                         query_len: usize, shard: *const sp_db_t, out: *mut u8, out_cap: usize,
                                         out_len: *mut usize) -> c_int;
         pub fn sp_comm_timings(c: *const sp_comm_t, ms3: *mut f32) -> c_int;
+        // ---- request layer: lib/server/src/bin/server.rs ServerState, /setup, /private-read (no HTTP)
+        pub fn sp_server_create(params: *const sp_params_t, db: *const sp_db_t) -> *mut sp_server_t;
+        pub fn sp_server_free(s: *mut sp_server_t);
+        pub fn sp_server_clients(s: *const sp_server_t) -> usize;
+        pub fn sp_server_setup(s: *mut sp_server_t, pp_bytes: *const u8, len: usize, uuid_out37: *mut c_char) -> c_int;
+        pub fn sp_server_setup_json(s: *mut sp_server_t, body: *const c_char, body_len: usize, out: *mut c_char, out_cap: usize,
+                                    out_len: *mut usize) -> c_int;
+        pub fn sp_server_forget(s: *mut sp_server_t, uuid: *const c_char) -> c_int;
+        pub fn sp_server_private_read(s: *mut sp_server_t, requests: *const *const u8, request_lens: *const usize, n: c_int,
+                                      out: *mut u8, out_stride: usize, out_lens: *mut usize) -> c_int;
+        pub fn sp_server_private_read_json(s: *mut sp_server_t, body: *const c_char, body_len: usize, out: *mut c_char,
+                                           out_cap: usize, out_len: *mut usize) -> c_int;
+        pub fn sp_server_private_read_json_bound(s: *const sp_server_t, n_queries: c_int) -> usize;
         // ---- measurement aids
         pub fn sp_sweep_launches(p: *const sp_params_t, db: *const sp_db_t) -> c_int;
         pub fn sp_bench_sweep(q: *mut sp_query_t, db: *const sp_db_t, iters: c_int, ms_per_launch: *mut f32) -> c_int;
@@ -472,6 +490,47 @@ pub fn encode(params: &Params, v_packed_ct: &[u64]) -> Vec<u8> {
     must(check(unsafe { sys::sp_encode(params.0, v_packed_ct.as_ptr(), out.as_mut_ptr(), out.len(), &mut n) }));
     out.truncate(n);
     out
+}
+
+/// `ServerState` of lib/server/src/bin/server.rs:21-28 minus the HTTP transport: `/setup` and `/private-read` bodies in,
+/// response bodies out; the per-uuid public parameters stay device resident.
+pub struct Server<'a> {
+    h: *mut sys::sp_server_t,
+    _params: &'a Params,
+    _db: &'a Database,
+}
+unsafe impl<'a> Send for Server<'a> {}
+unsafe impl<'a> Sync for Server<'a> {}
+impl<'a> Server<'a> {
+    pub fn new(params: &'a Params, db: &'a Database) -> Self {
+        let h = unsafe { sys::sp_server_create(params.0, db.0) };
+        assert!(!h.is_null(), "sp_server_create: {}", last_error());
+        Server { h, _params: params, _db: db }
+    }
+    /// POST /setup (bin/server.rs:71-94): body in, `{"uuid":"..."}` out.
+    pub fn setup(&self, body: &str) -> Result<String, HipError> {
+        let mut out = vec![0u8; 64];
+        let mut n = 0usize;
+        check(unsafe { sys::sp_server_setup_json(self.h, body.as_ptr() as *const c_char, body.len(), out.as_mut_ptr() as *mut c_char, out.len(), &mut n) })?;
+        out.truncate(n);
+        Ok(String::from_utf8(out).unwrap())
+    }
+    /// POST /private-read (bin/server.rs:143-164): JSON list of base64 requests in, JSON list of base64 responses out.
+    /// `Err` with `code == SP_E_NOTFOUND` maps to `Error::NotFound`.
+    pub fn private_read(&self, body: &[u8]) -> Result<String, HipError> {
+        let n_max = body.iter().filter(|&&c| c == b',').count() as c_int + 1;
+        let cap = unsafe { sys::sp_server_private_read_json_bound(self.h, n_max) };
+        let mut out = vec![0u8; cap];
+        let mut n = 0usize;
+        check(unsafe { sys::sp_server_private_read_json(self.h, body.as_ptr() as *const c_char, body.len(), out.as_mut_ptr() as *mut c_char, out.len(), &mut n) })?;
+        out.truncate(n);
+        Ok(String::from_utf8(out).unwrap())
+    }
+}
+impl<'a> Drop for Server<'a> {
+    fn drop(&mut self) {
+        unsafe { sys::sp_server_free(self.h) }
+    }
 }
 
 /// Names of the kernels / flows the calling thread went through since the last call (diagnostics).

@@ -13,6 +13,8 @@ from .spiral import (  # noqa: F401
     PublicParameters,
     Query,
     QueryRun,
+    Server,
+    NotFound,
     SpiralError,
     build_library,
     coefficient_expansion,

@@ -220,7 +220,7 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
       d->j0 = shard * d->nj;
       d->np_local = (int)p.num_per();
     }
-    d->packed = db_can_pack(d->np_local, d->nj) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
+    d->packed = db_can_pack(d->np_local, d->nj) && !tunable("db_unpacked", 0) ? 1 : 0;
     d->words.alloc((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8);
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
@@ -738,7 +738,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     return SP_E_ARG;
   }
   const Params& p = h->p;
-  const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !getenv("SPIRAL_NO_BATCH_SWEEP");
+  const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !tunable("no_batch_sweep", 0);
   if (!batched) {  // 8-byte / narrow databases: one pass per query
     for (int i = 0; i < batch; i++) {
       int rc = sp_process_query(h, pps[i], queries[i], query_lens[i], db, out + (size_t)i * out_stride, out_stride, out_len);
@@ -751,7 +751,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     return SP_E_ARG;
   }
   int group_max = SWEEP_BATCH_MAX;
-  if (const char* e = getenv("SPIRAL_BATCH_GROUP")) group_max = std::max(1, std::min(SWEEP_BATCH_MAX, atoi(e)));
+  group_max = std::max(1, std::min(SWEEP_BATCH_MAX, (int)tunable("batch_group", SWEEP_BATCH_MAX)));
   for (int g0 = 0; g0 < batch; g0 += group_max) {
     const int B = std::min(group_max, batch - g0);
     std::vector<sp_query_t*> qs;
@@ -779,9 +779,30 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         d.out[i] = qs[i]->ws->sweep_out.p;
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(W0.stream, qs[i]->ws->ev[1], 0));
       }
-      launch_sweep_batch(W0.D->T, d, W0.stream);
+      // SPIRAL_BATCH_PIPELINE=1 (off by default): the pass runs one (instance, trial) plane per launch and every query
+      // folds plane p on its second stream while plane p+1 is swept -- the single-query pipeline with B folds per
+      // plane.  Measured at C2, B = 8: 199 vs 198-227 queries/s for the one-launch pass -- the batched sweep's 188
+      // VGPRs + 64 KiB LDS leave no room for fold workgroups on a CU, so nothing overlaps
+      // (profiles/r02_fold_batch_experiments.md).
+      const bool per_plane = p.planes() > 1 && p.num_per() >= 1024 && tunable("batch_pipeline", 0) != 0;
+      if (per_plane) {
+        const size_t plane_db_words = db_bytes(1, db->np_local, db->nj, db->packed) / 8;
+        const size_t plane_out = (size_t)4 * POLY_LEN * db->np_local;
+        for (size_t pl = 0; pl < p.planes(); pl++) {
+          SweepBatchDesc dp = d;
+          dp.planes = 1;
+          dp.db = db->words.p + pl * plane_db_words;
+          for (int i = 0; i < B; i++) dp.out[i] = qs[i]->ws->sweep_out.p + pl * plane_out;
+          launch_sweep_batch(W0.D->T, dp, W0.stream);
+          HIP_CHECK(hipEventRecord(W0.ev_plane[pl], W0.stream));
+          for (int i = 0; i < B; i++) run_fold_plane_overlapped(*qs[i]->ws, pl, W0.ev_plane[pl]);
+        }
+        note_path(PATH_PIPELINED);
+      } else {
+        launch_sweep_batch(W0.D->T, d, W0.stream);
+      }
       HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
-      // 3. fold / pack per query, concurrently on the queries' own streams
+      // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
       for (int i = 0; i < B; i++) {
         Workspace& W = *qs[i]->ws;
         if (i > 0) {
@@ -1024,7 +1045,7 @@ int sp_multiply_reg_by_database(const sp_params_t* h, const uint64_t* db, const 
     DevBuf<u64> d_ref(words), d_dev(words), d_q, d_out(num_per * 4 * POLY_LEN);
     DevBuf<u32> d_res(4 * POLY_LEN * num_per);
     HIP_CHECK(hipMemcpyAsync(d_ref.p, db, words * 8, hipMemcpyHostToDevice, W->stream));
-    const int packed = db_can_pack((int)num_per, (int)dim0) && !getenv("SPIRAL_DB_UNPACKED") ? 1 : 0;
+    const int packed = db_can_pack((int)num_per, (int)dim0) && !tunable("db_unpacked", 0) ? 1 : 0;
     launch_db_relayout(d_dev.p, 0, d_ref.p, 0, N, (int)num_per, (int)dim0, 0, (int)dim0, packed, ColMap{}, W->stream);
     upload_raw(*W, v_firstdim, POLY_LEN * dim0 * 2, d_q);
     SweepDesc d{d_dev.p, d_q.p, d_res.p, 1, (int)num_per, (int)dim0, 0, (int)dim0, packed, 1};

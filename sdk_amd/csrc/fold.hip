@@ -235,10 +235,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
 }
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
-  static const int variant = [] {
-    const char* e = getenv("SPIRAL_FOLD_VARIANT");
-    return e ? atoi(e) : 3;
-  }();
+  const int variant = (int)tunable("fold_variant", 3);
   if (variant == 3 && (d.t % 2) == 0)
     hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 2 && (d.t % 2) == 0)

@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
   const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
-  static const int want = [] { const char* e = getenv("SPIRAL_FROM_SWEEP_XCD"); return e ? atoi(e) : 1; }();
+  const int want = (int)tunable("from_sweep_xcd", 1);
   const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");

@@ -70,6 +70,7 @@ void run_begin_direct(Workspace& W, const uint8_t* query);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0);
 void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
+void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);
 void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
 bool fused_fold_supported(const Params& p);

@@ -342,7 +342,7 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   HIP_CHECK(hipHostMalloc((void**)&h_response, P.response_bytes() + 16, hipHostMallocDefault));
   enc_out.alloc(P.response_bytes() / 8 + 2);
   q_raw.alloc(2 * POLY_LEN);
-  if (const char* e = getenv("SPIRAL_FUSED_MIN_PAIRS")) fused_min_pairs = atol(e);
+  fused_min_pairs = tunable("fused_min_pairs", 256);
 }
 
 Workspace::~Workspace() {
@@ -682,7 +682,7 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
-  if (p.num_per() % 4 == 0 && !getenv("SPIRAL_FROM_SWEEP1")) {
+  if (p.num_per() % 4 == 0 && !tunable("from_sweep1", 0)) {
     launch_from_sweep4(D.T, W.sweep_out.p + pg0 * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), np, premod ? 1 : 0,
                        W.foldX.p, s);
   } else {
@@ -704,10 +704,7 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
 // Only the last plane's fold is exposed.  Worth it when one plane's sweep outlasts one plane's fold, i.e. for
 // num_per >= 1024; narrow databases keep the single launch + all-planes fold (their fold is latency-bound).
 bool sweep_is_pipelined(const Params& p, const sp_db& db) {
-  static const bool enabled = [] {
-    const char* e = getenv("SPIRAL_PIPELINE");
-    return e ? atoi(e) != 0 : true;
-  }();
+  const bool enabled = tunable("pipeline", 1) != 0;
   return enabled && db.packed && db.num_shards == 1 && db.col_G == 1 && p.planes() > 1 && p.num_per() >= 1024;
 }
 
@@ -780,6 +777,18 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   W.have_sweep_span = true;
   W.pipelined = true;
   note_path(PATH_PIPELINED);
+}
+
+// from_ntt + fold of plane `pl` on the SECOND stream once `after` has fired (the batched per-plane pipeline: the plane
+// was swept by another query's stream); run_finish then waits for ev_fold
+void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after) {
+  W.ensure_finish();
+  HIP_CHECK(hipStreamWaitEvent(W.stream2, after, 0));
+  on_stream(W, W.stream2, [&] { fold_planes(W, pl, 1, false); });
+  if (pl + 1 == W.P->planes()) {
+    HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
+    W.pipelined = true;
+  }
 }
 
 // k_fold_fused* keep gadget digits in u32 and need digit < 2q, i.e. at most 28 bits per digit (t_gsw >= 2)

@@ -368,7 +368,7 @@ void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t
   const long units = (long)d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)((units + 3) / 4));
   const bool unroll = ((d.nj >> 1) % 4) == 0;
-  static const int lds_min_b = [] { const char* e = getenv("SPIRAL_BATCH_QLDS_MIN"); return e ? atoi(e) : 5; }();
+  const int lds_min_b = (int)tunable("batch_qlds_min", 5);
   const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && (size_t)d.batch * d.nj * 16 <= 65536;
   const size_t lds = qlds ? (size_t)d.batch * d.nj * 16 : 0;
 #define SP_BATCH_CASE(B)                                                                              \
@@ -507,10 +507,7 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
     launched(PATH_SWEEP_PACKED | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed");
   } else if (d.num_per >= 128) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
-    static const int variant = [] {
-      const char* e = getenv("SPIRAL_SWEEP_VARIANT");
-      return e ? atoi(e) : 0;
-    }();
+    const int variant = (int)tunable("sweep_variant", 0);
     const dim3 grid((unsigned)((units + 3) / 4));
     // measured on MI355X, C2 (profiles/r01_sweep_variants.md): non-temporal loads + no manual unroll is
     // the fastest form (6.8 TB/s); the others stay selectable for A/B runs
@@ -523,7 +520,7 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
     }
     launched(PATH_SWEEP_WIDE | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_wide");
   } else {
-    if (d.num_per >= 2 && !getenv("SPIRAL_NARROW1")) {
+    if (d.num_per >= 2 && !tunable("narrow1", 0)) {
       size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 8 * sizeof(u32);
       hipLaunchKernelGGL(k_sweep_narrow2, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
     } else {

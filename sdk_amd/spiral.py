@@ -85,7 +85,13 @@ def _err():
     return lib().sp_last_error().decode(errors="replace")
 
 
+class NotFound(SpiralError):
+    """SP_E_NOTFOUND: unknown client uuid (lib/server Error::NotFound)"""
+
+
 def _chk(rc):
+    if rc == -5:
+        raise NotFound(f"libspiral_hip rc={rc}: {_err()}")
     if rc != 0:
         raise SpiralError(f"libspiral_hip rc={rc}: {_err()}")
 
@@ -657,3 +663,70 @@ def encode(params, v_packed_ct):
     ln = C.c_size_t(0)
     _chk(lib().sp_encode(_vp(params.h), _p(v), _p(out, u8p), C.c_size_t(n), C.byref(ln)))
     return out[:ln.value].tobytes()
+
+
+# ------------------------------------------------------------------------------------------------
+class Server:
+    """ServerState of lib/server/src/bin/server.rs:21-28 without the HTTP transport (sp_server_*): POST /setup and POST
+    /private-read bodies in, response bodies out; public parameters stay device resident per client uuid and a list of
+    queries goes through the batch scheduler (<= 8 queries per pass over the database)."""
+
+    def __init__(self, params, db):
+        L = lib()
+        L.sp_server_create.restype = C.c_void_p
+        L.sp_server_clients.restype = C.c_size_t
+        L.sp_server_private_read_json_bound.restype = C.c_size_t
+        self.params, self.db = params, db
+        self.h = L.sp_server_create(_vp(params.h), _vp(db.h))
+        if not self.h:
+            raise SpiralError(_err())
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().sp_server_free(_vp(self.h))
+                self.h = None
+        except Exception:
+            pass
+
+    def clients(self):
+        return int(lib().sp_server_clients(_vp(self.h)))
+
+    def setup(self, pp_bytes):
+        """/setup on the decoded bytes -> uuid string"""
+        d = _bytes(pp_bytes)
+        out = C.create_string_buffer(37)
+        _chk(lib().sp_server_setup(_vp(self.h), _p(d, u8p), C.c_size_t(d.size), out))
+        return out.value.decode()
+
+    def setup_json(self, body):
+        """/setup on the HTTP body (JSON string of base64) -> '{"uuid":"..."}'"""
+        b = body.encode() if isinstance(body, str) else bytes(body)
+        out = C.create_string_buffer(128)
+        n = C.c_size_t(0)
+        _chk(lib().sp_server_setup_json(_vp(self.h), b, C.c_size_t(len(b)), out, C.c_size_t(128), C.byref(n)))
+        return out.raw[:n.value].decode()
+
+    def forget(self, uuid):
+        _chk(lib().sp_server_forget(_vp(self.h), uuid.encode()))
+
+    def private_read(self, requests):
+        """/private-read on decoded requests (uuid || query, or pp || query for direct-upload params) -> list of responses"""
+        n = len(requests)
+        bufs = [_bytes(r) for r in requests]
+        rb = self.params.get("response_bytes")
+        out = np.zeros(max(n, 1) * rb, dtype=np.uint8)
+        lens = (C.c_size_t * max(n, 1))()
+        r_arr = (u8p * max(n, 1))(*[_p(b, u8p) for b in bufs])
+        l_arr = (C.c_size_t * max(n, 1))(*[b.size for b in bufs])
+        _chk(lib().sp_server_private_read(_vp(self.h), r_arr, l_arr, C.c_int(n), _p(out, u8p), C.c_size_t(rb), lens))
+        return [out[i * rb:i * rb + lens[i]].tobytes() for i in range(n)]
+
+    def private_read_json(self, body):
+        """/private-read on the HTTP body (JSON list of base64 strings) -> JSON list of base64 strings"""
+        b = body.encode() if isinstance(body, str) else bytes(body)
+        cap = int(lib().sp_server_private_read_json_bound(_vp(self.h), C.c_int(b.count(b",") + 1)))
+        out = C.create_string_buffer(cap)
+        n = C.c_size_t(0)
+        _chk(lib().sp_server_private_read_json(_vp(self.h), b, C.c_size_t(len(b)), out, C.c_size_t(cap), C.byref(n)))
+        return out.raw[:n.value].decode()

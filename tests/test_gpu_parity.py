@@ -825,6 +825,38 @@ def test_process_query_batch_lds_staged(sp, oracle_mod):
         assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
 
 
+def test_process_query_batch_per_plane_pipeline(sp, oracle_mod):
+    """Batched queries on a wide database (num_per >= 1024), SPIRAL_BATCH_PIPELINE=1: the pass runs one plane per launch
+    and every query folds plane p on its second stream while plane p+1 is swept (the batch form of the single-query
+    pipeline; off by default -- it measures no faster); 11 queries =
+    a group of 8 + a group of 3, two instances (8 planes); byte-identical to the oracle and to the one-launch pass."""
+    import ctypes as C
+    cfg = {"n": 2, "nu_1": 4, "nu_2": 10, "p": 256, "q2_bits": 20, "t_gsw": 2, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 2, "db_item_size": 16384}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(31)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    item, db = o.generate_random_db_and_get_item(5)
+    gdb = sp.Database(p).load(db)
+    B = 11
+    qs = [cl.generate_query((997 * i + 5) % o.num_items, 400 + i) for i in range(B)]
+    sp.lib().sp_debug_set(b"batch_pipeline", C.c_long(1))
+    try:
+        sp.paths_taken()
+        resp = sp.process_query_batch(p, [gpp] * B, qs, gdb)
+        taken = sp.paths_taken()
+        assert {"sweep_batch", "pipelined_fold_overlap"} <= taken, taken
+    finally:
+        sp.lib().sp_debug_set(b"batch_pipeline", C.c_long(0))
+    for i in (0, 7, 8, 10):
+        assert resp[i] == o.process_query(pp, qs[i], db), i
+    sp.paths_taken()
+    assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp          # the default: one launch per pass
+    assert "pipelined_fold_overlap" not in sp.paths_taken()
+
+
 def _valid_cfg(c):
     dim0, right = 1 << c["nu_1"], c["t_gsw"] * c["nu_2"]
     g = max(1, int(np.ceil(np.log2(right + dim0))))
