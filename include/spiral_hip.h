@@ -91,6 +91,18 @@ sp_db_t* sp_db_create(const sp_params_t*, int shard, int num_shards);
  * for its columns, so the flow is sp_query_sweep -> sp_query_fold_local(q, sp_query_partial_ptr(q), S) ->
  * gather of the local results -> sp_query_finish_gathered; no partial sums cross GPUs. */
 sp_db_t* sp_db_create_columns(const sp_params_t*, int shard, int num_shards);
+/* A sparse bucket: lib/server's SparseDb (lib/server/src/db/sparse_db.rs:5-48).  Starts empty; items arrive through
+ * sp_db_update_item (= update_item_raw + upsert, db/loading.rs:317-359) and only they are stored (one packed NTT
+ * polynomial per (item, plane)) and multiplied, so the first-dimension step costs time in proportion to the occupancy.
+ * sp_process_query / sp_query_begin_for_db + sweep + finish on such a handle follow lib/server's process_query
+ * (lib/server/src/server.rs:17-99): expansion pruned to the rows that hold items (compute/query_expansion.rs:213-357),
+ * multiply_reg_by_sparse_database (compute/dot_product.rs:13-220; exact sums mod q, not the reference's wrapping u64),
+ * and fold_ciphertexts with the all-zero shortcuts of compute/fold.rs:38-44 -- so the response bytes are lib/server's,
+ * which differ from spiral-rs's dense process_query over the zero-filled database wherever a shortcut fires (both
+ * decode to the item).  Updates must not run concurrently with queries on the same handle (the reference holds a
+ * RwLock write guard, bin/server.rs:33,48).  Needs expand_queries and 3 <= t_gsw <= 32. */
+sp_db_t* sp_db_create_sparse(const sp_params_t*);
+size_t sp_db_sparse_items(const sp_db_t*); /* items present */
 void sp_db_free(sp_db_t*);
 /* Upload (a z-range of) one (instance,trial) plane given in the reference layout [z][ii][j] with
  * the FULL dim0 rows per (z,ii); the shard keeps only its rows.  `words` points at row z0.

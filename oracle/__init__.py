@@ -23,7 +23,7 @@ u8p = C.POINTER(C.c_uint8)
 def build(force=False):
     """Compile liboracle.so with g++ (seconds)."""
     so = os.path.join(_HERE, "liboracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("spiral_oracle.cpp", "oracle_capi.cpp", "spiral_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("spiral_oracle.cpp", "oracle_capi.cpp", "sparse_server.cpp", "spiral_oracle.h")]
     if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "-s"])
     return so
@@ -390,6 +390,53 @@ def sweep_rows_avx2(db_zslice, v_firstdim_zslice, nz, dim0, num_per, q0=26836992
     out = np.zeros(nz * num_per * 4, dtype=np.uint64)
     lib().orc_sweep_rows_avx2(_p(db_zslice), _p(v), _u64(nz), _u64(dim0), _u64(num_per), _u64(q0), _u64(q1), _p(out))
     return out.reshape(nz, num_per, 4)
+
+
+class SparseDb:
+    """lib/server's SparseDb (db/sparse_db.rs:5-48) filled through update_item_raw (db/loading.rs:317-359), and
+    lib/server's process_query over it (server.rs:17-99): the sparse caller the GPU library serves."""
+
+    def __init__(self, params):
+        L = lib()
+        L.orc_sparse_db_new.restype = C.c_void_p
+        L.orc_sparse_last_error.restype = C.c_char_p
+        L.orc_process_query_sparse.restype = C.c_int64
+        L.orc_sparse_db_polys.restype = C.c_uint64
+        self.params = params
+        self.h = L.orc_sparse_db_new()
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                lib().orc_sparse_db_free(_vp(self.h))
+                self.h = None
+        except Exception:
+            pass
+
+    def update_item_raw(self, db_idx, data):
+        d = np.frombuffer(bytes(data), dtype=np.uint8)
+        if lib().orc_sparse_update_item_raw(_vp(self.params.h), _vp(self.h), _u64(db_idx), _p(d, u8p), _u64(d.size)) != 0:
+            raise OracleError(lib().orc_sparse_last_error().decode())
+        return self
+
+    def polys(self):
+        return int(lib().orc_sparse_db_polys(_vp(self.h)))
+
+    def process_query(self, pp_bytes, q_bytes):
+        pp = np.frombuffer(pp_bytes, dtype=np.uint8)
+        q = np.frombuffer(q_bytes, dtype=np.uint8)
+        out = np.zeros(self.params.response_bytes() + 64, dtype=np.uint8)
+        n = lib().orc_process_query_sparse(_vp(self.params.h), _p(pp, u8p), _u64(pp.size), _p(q, u8p), _u64(q.size),
+                                           _vp(self.h), _p(out, u8p), _u64(out.size))
+        if n < 0:
+            raise OracleError(lib().orc_sparse_last_error().decode())
+        return out[:n].tobytes()
+
+    def to_dense(self):
+        """the dense database with zero polynomials for absent items (reference layout)"""
+        out = np.zeros(self.params.db_words(), dtype=np.uint64)
+        lib().orc_sparse_to_dense(_vp(self.params.h), _vp(self.h), _p(out))
+        return out
 
 
 def synth_word(seed, idx):

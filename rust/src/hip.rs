@@ -74,6 +74,8 @@ pub mod sys {
         // ---- database (`db: &[u64]` of server.rs:650-655, resident)
         pub fn sp_db_create(p: *const sp_params_t, shard: c_int, num_shards: c_int) -> *mut sp_db_t;
         pub fn sp_db_create_columns(p: *const sp_params_t, shard: c_int, num_shards: c_int) -> *mut sp_db_t;
+        pub fn sp_db_create_sparse(p: *const sp_params_t) -> *mut sp_db_t;
+        pub fn sp_db_sparse_items(db: *const sp_db_t) -> usize;
         pub fn sp_db_free(db: *mut sp_db_t);
         pub fn sp_db_load_plane(db: *mut sp_db_t, plane: c_int, z0: c_int, nz: c_int, words: *const u64) -> c_int;
         pub fn sp_db_load(db: *mut sp_db_t, words: *const u64, n_words: usize) -> c_int;
@@ -285,6 +287,13 @@ impl Database {
     /// An empty bucket (all-zero polynomials = what lib/server's SparseDb yields for absent rows), unsharded.
     pub fn new(params: &Params) -> Self {
         Self::shard(params, 0, 1)
+    }
+    /// lib/server's `SparseDb` (db/sparse_db.rs:5-48): only the items written through `update_item` are stored and
+    /// multiplied; `process_query` on it follows lib/server/src/server.rs:17-99.
+    pub fn sparse(params: &Params) -> Self {
+        let h = unsafe { sys::sp_db_create_sparse(params.0) };
+        assert!(!h.is_null(), "sp_db_create_sparse: {}", last_error());
+        Database(h)
     }
     /// Row shard `rank` of `world` (multi-GPU): first-dimension rows [rank*dim0/world, (rank+1)*dim0/world).
     pub fn shard(params: &Params, rank: usize, world: usize) -> Self {

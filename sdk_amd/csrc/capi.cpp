@@ -41,6 +41,7 @@ struct sp_query {
   int next_plane = 0;  // sp_query_sweep_scatter_plane progress
   int next_fold_plane = 0;  // sp_query_fold_local_plane progress
   int rows_j0 = 0, rows_nj = 0;  // sp_query_begin_for_db on a row shard: only these first-dimension rows were expanded
+  const sp_db* for_sparse = nullptr;  // begun for this sparse bucket: only the rows holding items were expanded
   float ms[4] = {0, 0, 0, 0};
   ~sp_query() {
     if (ws && params) {
@@ -50,6 +51,7 @@ struct sp_query {
       if (ws->s_fold) (void)hipStreamSynchronize(ws->s_fold);
       ws->pipelined = false;
       ws->have_sweep_span = false;
+      ws->zero_shortcuts = false;
       params->release_ws(std::move(ws));
     }
   }
@@ -102,6 +104,37 @@ void check_device(int dev) {
 }
 
 }  // namespace
+
+// present items by column + the expansion schedule pruned to the rows that hold items, rebuilt after updates
+void sp_db::ensure_sparse_index() {
+  std::lock_guard<std::mutex> lk(mu);
+  if (!index_dirty) return;
+  const Params& p = params->p;
+  const size_t num_per = p.num_per(), dim0 = p.dim0();
+  std::vector<int> ptr(num_per + 1, 0), rows(slot_of.size()), slots(slot_of.size());
+  std::vector<char> row_set(dim0, 0);
+  for (const auto& kv : slot_of) ptr[kv.first % num_per + 1]++;
+  for (size_t i = 0; i < num_per; i++) ptr[i + 1] += ptr[i];
+  std::vector<int> fill(ptr.begin(), ptr.end() - 1);
+  for (const auto& kv : slot_of) {
+    const size_t j = kv.first / num_per, ii = kv.first % num_per;  // full_idx = j * num_per + i (dot_product.rs:164)
+    rows[fill[ii]] = (int)j;
+    slots[fill[ii]] = (int)kv.second;
+    fill[ii]++;
+    row_set[j] = 1;
+  }
+  col_ptr.ensure(ptr.size());
+  col_rows.ensure(std::max<size_t>(rows.size(), 1));
+  col_slots.ensure(std::max<size_t>(slots.size(), 1));
+  HIP_CHECK(hipMemcpy(col_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!rows.empty()) {
+    HIP_CHECK(hipMemcpy(col_rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIP_CHECK(hipMemcpy(col_slots.p, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  if (slots_cap == 0) polys.ensure(1);
+  sparse_plan = build_pruned_plan_rows(p, row_set);  // query_expansion.rs:263-280: set_dim0 = rows of the present items
+  index_dirty = false;
+}
 
 extern "C" {
 
@@ -228,14 +261,36 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
   });
   return rc == SP_OK ? out : nullptr;
 }
+// lib/server's SparseDb (lib/server/src/db/sparse_db.rs:5-48): an empty bucket that stores only the items written to it
+sp_db_t* sp_db_create_sparse(const sp_params_t* h) {
+  sp_db_t* out = nullptr;
+  int rc = guarded([&] {
+    need(h != nullptr, "params is null");
+    const Params& p = h->p;
+    need(p.expand_queries, "sparse buckets serve expanded queries (lib/server's sparse path, server.rs:31-33)");
+    need(fused_fold_supported(p), "sparse buckets need gadget parameters the fused fold supports (3 <= t_gsw <= 32)");
+    auto d = std::make_unique<sp_db>();
+    d->params = h;
+    HIP_CHECK(hipGetDevice(&d->device));
+    d->sparse = true;
+    d->nj = (int)p.dim0();
+    d->np_local = (int)p.num_per();
+    const_cast<sp_params*>(h)->device_state();
+    out = d.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+size_t sp_db_sparse_items(const sp_db_t* d) { return d && d->sparse ? d->slot_of.size() : 0; }
+
 sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, false); }
 sp_db_t* sp_db_create_columns(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, true); }
 void sp_db_free(sp_db_t* d) { delete d; }
-size_t sp_db_device_bytes(const sp_db_t* d) { return d ? d->words.bytes() : 0; }
+size_t sp_db_device_bytes(const sp_db_t* d) { return d ? (d->sparse ? d->polys.bytes() : d->words.bytes()) : 0; }
 
 int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* words) {
   return guarded([&] {
     need(d && words, "null argument");
+    need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     const Params& p = d->params->p;
     need(plane >= 0 && (size_t)plane < p.planes() && z0 >= 0 && nz >= 0 && (size_t)(z0 + nz) <= POLY_LEN, "bad plane / z range");
     check_device(d->device);
@@ -275,6 +330,7 @@ int sp_db_load(sp_db_t* d, const uint64_t* words, size_t n_words) {
 int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
   return guarded([&] {
     need(d && (file || file_len == 0), "null argument");
+    need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
     sp_params* h = const_cast<sp_params*>(d->params);
     const Params& p = h->p;
@@ -333,6 +389,37 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     const Params& p = h->p;
     need(item_idx < p.num_items(), "item index out of range");
     need(len <= p.db_item_size, "item longer than db_item_size");
+    if (d->sparse) {
+      // lib/server/src/db/loading.rs:317-359 update_item_raw + sparse_db.rs:42-48 upsert
+      DeviceState& D = h->device_state();
+      std::lock_guard<std::mutex> lk(d->mu);
+      size_t logp = 0;
+      while (((u64)1 << logp) < p.pt_modulus) logp++;
+      const size_t planes = p.planes(), bpc = (p.db_item_size + planes - 1) / planes, poly_words = planes * POLY_LEN;
+      auto it = d->slot_of.find(item_idx);
+      size_t slot;
+      if (it != d->slot_of.end()) {
+        slot = it->second;
+      } else {
+        slot = d->slot_of.size();
+        if (slot >= d->slots_cap) {  // grow the polynomial store (amortised doubling, contents preserved)
+          const size_t cap = std::max<size_t>(64, d->slots_cap * 2);
+          DevBuf<u64> bigger(cap * poly_words);
+          if (d->slots_cap) HIP_CHECK(hipMemcpy(bigger.p, d->polys.p, d->slots_cap * poly_words * 8, hipMemcpyDeviceToDevice));
+          d->polys = std::move(bigger);
+          d->slots_cap = cap;
+        }
+        d->slot_of[item_idx] = slot;
+      }
+      DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
+      HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
+      if (len) HIP_CHECK(hipMemcpy(win.p, data, len, hipMemcpyHostToDevice));
+      launch_sparse_item_encode(D.T, win.p, (int)p.db_item_size, (int)bpc, (int)logp, (u32)p.pt_modulus,
+                                d->polys.p + slot * poly_words, (int)planes, 0);
+      HIP_CHECK(hipDeviceSynchronize());
+      d->index_dirty = true;
+      return;
+    }
     const size_t j = item_idx / p.num_per(), ii = item_idx % p.num_per();
     if ((int)j < d->j0 || (int)j >= d->j0 + d->nj) return;  // row lives on another shard
     if ((int)(ii % (size_t)d->col_G) != d->col_g) return;   // column lives on another shard
@@ -374,6 +461,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
 int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
   return guarded([&] {
     need(d != nullptr, "null db");
+    need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
     const Params& p = d->params->p;
     launch_db_synth(d->words.p, seed, (int)p.planes(), d->np_local, (int)p.dim0(), d->j0, d->nj, d->packed, d->colmap(), 0);
@@ -385,6 +473,7 @@ uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index) { return synth_word(se
 int sp_db_read_ref(const sp_db_t* d, int plane, int z, int ii, int j0, int count, uint64_t* out) {
   return guarded([&] {
     need(d && out, "null argument");
+    need(!d->sparse, "sp_db_read_ref reads dense databases");
     const Params& p = d->params->p;
     need(plane >= 0 && (size_t)plane < p.planes() && z >= 0 && z < N && ii >= 0 && (size_t)ii < p.num_per() && j0 >= 0 &&
              count >= 0 && j0 + count <= d->nj, "bad coordinates");
@@ -495,15 +584,21 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     need(!db || db->params == h, "db was created for different params");
     check_device(pp->device);
     const bool rows = db && db->num_shards > 1 && db->col_G == 1;
+    const DeviceState::PrunedPlan* plan = nullptr;
+    if (db && db->sparse) {
+      const_cast<sp_db*>(db)->ensure_sparse_index();
+      plan = db->sparse_plan.get();
+    }
     auto q = std::make_unique<sp_query>();
     q->params = const_cast<sp_params*>(h);
     q->pp = pp;
     q->ws = q->params->acquire_ws();
     Workspace& W = *q->ws;
     HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
-    run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0);
+    run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0, plan);
     HIP_CHECK(hipEventRecord(W.ev[1], W.stream));
     q->state = 1;
+    q->for_sparse = db && db->sparse ? db : nullptr;
     q->rows_j0 = rows ? db->j0 : 0;
     q->rows_nj = rows ? db->nj : 0;
     out = q.release();
@@ -520,7 +615,15 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
          "the query was expanded for another row shard (sp_query_begin_for_db)");
     check_device(db->device);
     Workspace& W = *q->ws;
-    if (sweep_is_pipelined(q->params->p, *db))
+    need(q->for_sparse == nullptr || q->for_sparse == db, "the query was expanded for another sparse bucket");
+    if (db->sparse) {
+      // lib/server's process_query over a SparseDb (lib/server/src/server.rs:17-99): present items only, and the
+      // fold takes fold.rs:38-44's all-zero shortcuts
+      need(q->for_sparse == db, "a sparse bucket needs sp_query_begin_for_db(…, db) (its expansion is pruned)");
+      const_cast<sp_db*>(db)->ensure_sparse_index();
+      run_sweep_sparse(W, *db);
+      W.zero_shortcuts = true;
+    } else if (sweep_is_pipelined(q->params->p, *db))
       run_sweep_pipelined(W, *db);
     else
       run_sweep(W, *db);
@@ -539,7 +642,7 @@ int sp_query_sweep_scatter(sp_query_t* q, const sp_db_t* db, int G) {
     const Params& p = q->params->p;
     need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G && G <= SP_MAX_ROW_SHARDS,
          "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS) and equal to the db's num_shards");
-    need(db->col_G == 1, "sweep_scatter works on row shards");
+    need(db->col_G == 1 && !db->sparse, "sweep_scatter works on row shards");
     check_device(db->device);
     Workspace& W = *q->ws;
     W.out_G = G;
@@ -559,7 +662,7 @@ int sp_query_sweep_scatter_plane(sp_query_t* q, const sp_db_t* db, int G, int pl
     const Params& p = q->params->p;
     need(G >= 1 && (G & (G - 1)) == 0 && (size_t)G <= p.num_per() && db->num_shards == G && G <= SP_MAX_ROW_SHARDS,
          "G must be a power of two <= min(num_per, SP_MAX_ROW_SHARDS) and equal to the db's num_shards");
-    need(db->col_G == 1, "sweep_scatter works on row shards");
+    need(db->col_G == 1 && !db->sparse, "sweep_scatter works on row shards");
     need(plane >= 0 && (size_t)plane < p.planes(), "plane out of range");
     need(q->state == 1 && q->next_plane == plane, "sp_query_sweep_scatter_plane: planes must be swept in order after begin");
     check_device(db->device);
@@ -722,7 +825,7 @@ int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* que
     g_last_error = "sp_process_query needs an unsharded db; use sp_query_begin/sweep/finish for shards";
     return SP_E_ARG;
   }
-  sp_query_t* q = sp_query_begin(h, pp, query, query_len);
+  sp_query_t* q = sp_query_begin_for_db(h, pp, query, query_len, db && db->sparse ? db : nullptr);
   if (!q) return g_last_error.find("hip") != std::string::npos ? SP_E_HIP : SP_E_ARG;
   int rc = sp_query_sweep(q, db);
   if (rc == SP_OK) rc = guarded([&] { finish_impl(q, false, out, out_cap, out_len); });

@@ -15,6 +15,23 @@ namespace spiral {
 // Requires v_folding_neg == G - v_folding, which holds inside process_query by construction.
 // The two LDS buffers alternate roles between consecutive transforms: three barriers per transform.
 // ------------------------------------------------------------------------------------------------
+// lib/server/src/compute/fold.rs:38-44 ("crucial for correctness" there): ct_i all zero -> the step yields ct_{i+half};
+// ct_{i+half} all zero -> ct_i stays.  Returns true when the workgroup is done.
+__device__ __forceinline__ bool fold_zero_shortcut(const u64* ct0, const u64* ct1, u64* out, int tau) {
+  int nz0 = 0, nz1 = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) {
+    nz0 |= ct0[tau + 256 * k] != 0;
+    nz1 |= ct1[tau + 256 * k] != 0;
+  }
+  const int any0 = __syncthreads_or(nz0), any1 = __syncthreads_or(nz1);
+  if (any0 && any1) return false;
+  const u64* src = any0 ? ct0 : ct1;  // ct_i unless it is the all-zero one
+#pragma unroll
+  for (int k = 0; k < 16; k++) out[tau + 256 * k] = src[tau + 256 * k];
+  return true;
+}
+
 template <bool HOIST_TW>
 __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) {
   __shared__ u32 lds0[LDS_WORDS];
@@ -28,6 +45,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
   u32* la = lds0;
   u32* lb = lds1;
   u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+  if (d.zero_shortcuts && fold_zero_shortcut(ct0, ct1, out, tau)) return;
 #pragma unroll 1
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
@@ -134,6 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
   u32* la = lds0;
   u32* lb = lds1;
   u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+  if (d.zero_shortcuts && fold_zero_shortcut(ct0, ct1, out, tau)) return;
 #pragma unroll 1
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];

@@ -154,6 +154,9 @@ struct FoldDesc {
   const u32* mats;
   int cur, half, planes;
   int t, bits;
+  // lib/server semantics (lib/server/src/compute/fold.rs:38-44): an all-zero ct_i is replaced by ct_{i+half}, an
+  // all-zero ct_{i+half} leaves ct_i as it is -- no external product in either case
+  int zero_shortcuts;
 };
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
 
@@ -281,6 +284,15 @@ struct DbEncodeDesc {
   ColMap cm;              // num_per above is the LOCAL column count
 };
 void launch_db_encode(const DevTables& T, const DbEncodeDesc& d, hipStream_t s);
+
+// ---- sparse buckets (lib/server SparseDb caller; sparse.hip) ----------------------------------------------------------
+// one item's bytes (device) -> `planes` packed NTT polynomials at slot_polys[plane][z]
+void launch_sparse_item_encode(const DevTables& T, const uint8_t* bytes, int item_bytes, int bytes_per_chunk, int logp,
+                               u32 pt_modulus, u64* slot_polys, int planes, hipStream_t s);
+// first-dimension multiply over the present items only (CSR by column); v = expanded NTT ciphertexts, row j at
+// ct index first + step * j; out = sweep-native [plane][r][crt][z][ii]
+void launch_sweep_sparse(const DevTables& T, const int* col_ptr, const int* col_rows, const int* col_slots, const u64* polys,
+                         int planes, const u32* v, int first, int step, u32* out, int num_per, hipStream_t s);
 
 // sweep-native out [plane][r][crt][z][ii] -> reference out[ii].data[r*2N + crt*N + z] (u64) for one plane
 void launch_sweep_out_to_ref(u64* out, const u32* in, int num_per, hipStream_t s);

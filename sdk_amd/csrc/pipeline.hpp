@@ -50,6 +50,7 @@ struct Workspace {
   uint8_t* h_response = nullptr;
   bool delta_tail = true;  // unfused fold levels use the delta form too (false: literal two-matrix form)
   int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
+  bool zero_shortcuts = false;  // lib/server fold semantics (sparse buckets): set per query, every level fused
   long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused
 
   Workspace(const Params& P, DeviceState& D);
@@ -67,7 +68,11 @@ void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int
 void run_folding_neg(Workspace& W);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
-void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0);
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0,
+               const DeviceState::PrunedPlan* plan = nullptr);
+void run_sweep_sparse(Workspace& W, const sp_db& db);
+// expansion schedule pruned to an arbitrary set of first-dimension rows (rows[j] != 0), lists uploaded
+std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P, const std::vector<char>& rows);
 void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
 void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after);

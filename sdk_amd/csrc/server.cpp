@@ -98,7 +98,8 @@ void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
 // Expansion schedule (server.rs:19-121) restricted to the first-dimension rows [j0, j0 + nj): output ct c of round
 // r (index < 2^(r+1)) is an ancestor of leaf L iff L = c (mod 2^(r+1)); leaf 2j is row j (server.rs:566-568), the odd
 // leaves are the GSW selector bits and are always kept.  j0 = 0, nj = dim0 gives the reference's own schedule.
-static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj, std::vector<int>& L) {
+static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj, std::vector<int>& L,
+                                                const std::vector<char>* row_set = nullptr) {
   auto put = [&](const std::vector<int>& v) {
     size_t off = L.size();
     L.insert(L.end(), v.begin(), v.end());
@@ -109,7 +110,9 @@ static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj,
   const size_t nu2 = P.db_dim_2;
   const size_t stop_round = nu2 > 0 ? P.stop_round() : 0;
   const size_t max_bits_right = nu2 > 0 ? P.t_gsw * nu2 : 0;
-  const bool prune = nu2 > 0 && (j0 != 0 || nj != (int)P.dim0());
+  // row_set: an arbitrary set of rows (sparse buckets; lib/server/src/compute/query_expansion.rs:213-248
+  // to_per_round_set keeps exactly the ancestors of the even leaves 2j, j in the set, and of every odd leaf)
+  const bool prune = nu2 > 0 && (row_set != nullptr || j0 != 0 || nj != (int)P.dim0());
   for (size_t r = 0; r < g; r++) {
     RoundPlan rp;
     rp.num_in = 1 << r;
@@ -119,7 +122,10 @@ static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj,
     if (prune) {
       std::fill(need_even.begin(), need_even.end(), 0);
       const size_t mod = (size_t)2 << r;
-      if ((size_t)nj * 2 >= mod) {
+      if (row_set) {
+        for (size_t j = 0; j < row_set->size(); j++)
+          if ((*row_set)[j]) need_even[((size_t)2 * j) % mod] = 1;
+      } else if ((size_t)nj * 2 >= mod) {
         std::fill(need_even.begin(), need_even.end(), 1);
       } else {
         for (int j = j0; j < j0 + nj; j++) need_even[((size_t)2 * j) % mod] = 1;
@@ -176,6 +182,17 @@ const DeviceState::PrunedPlan& DeviceState::pruned_plan(const Params& P, int j0,
   if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
   pruned.push_back(std::move(pl));
   return *pruned.back();
+}
+
+std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P, const std::vector<char>& rows) {
+  auto pl = std::make_unique<DeviceState::PrunedPlan>();
+  pl->j0 = -1;
+  pl->nj = -1;
+  std::vector<int> L;
+  pl->rounds = build_round_plans(P, 0, 0, L, &rows);
+  pl->lists.alloc(std::max<size_t>(L.size(), 1));
+  if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  return pl;
 }
 
 static std::unique_ptr<DeviceState> build_device_state(const Params& P, int device) {
@@ -637,7 +654,8 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
 }
 
 // Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
-void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0, int nj) {
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0, int nj,
+               const DeviceState::PrunedPlan* plan) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
@@ -658,8 +676,8 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   const size_t g = p.g();
   // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
   const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
-  if (prune) note_path(PATH_EXPAND_PRUNED);
-  run_coefficient_expansion(W, pp, g, prune ? &D.pruned_plan(p, j0, nj) : nullptr);
+  if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
+  run_coefficient_expansion(W, pp, g, plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr));
   const int* L = D.lists.p;
   if (p.db_dim_2 > 0) {
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
@@ -675,6 +693,15 @@ void run_sweep(Workspace& W, const sp_db& db) {
   W.ensure_sweep();
   SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), db.np_local, (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
   launch_sweep(W.D->T, d, W.stream);
+}
+
+// multiply_reg_by_sparse_database (lib/server/src/compute/dot_product.rs:13-220): only the present items, read from the
+// expanded ciphertexts directly (row j = ct 2j, or ct j when nu_2 = 0)
+void run_sweep_sparse(Workspace& W, const sp_db& db) {
+  const Params& p = *W.P;
+  W.ensure_sweep();
+  launch_sweep_sparse(W.D->T, db.col_ptr.p, db.col_rows.p, db.col_slots.p, db.polys.p, (int)p.planes(), W.v.p, 0,
+                      p.db_dim_2 > 0 ? 2 : 1, W.sweep_out.p, (int)p.num_per(), W.stream);
 }
 
 // from_ntt + fold of `np` planes starting at plane pg0 (sweep_out -> final_cts), on W.stream
@@ -810,8 +837,11 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
     const int half = cur / 2;
     // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
     // the three-kernel form, which parallelises over digits
-    if ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p)) {
+    if (W.zero_shortcuts && !fused_fold_supported(p))
+      throw ArgError("sparse buckets need gadget parameters the fused fold supports (3 <= t_gsw <= 32)");
+    if (W.zero_shortcuts || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
       FoldDesc fd{};
+      fd.zero_shortcuts = W.zero_shortcuts ? 1 : 0;
       fd.X = X;
       fd.Y = Y;
       fd.mats = W.fold_mats.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN;

@@ -9,6 +9,7 @@
 #include <mutex>
 #include <stdexcept>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.hpp"
@@ -155,4 +156,13 @@ struct sp_db {
   spiral::ColMap colmap() const { return spiral::ColMap{col_g, col_G, np_local * col_G}; }
   spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii] (or the PACKED unit stream)
   std::mutex mu;
+  // ---- sparse bucket (sp_db_create_sparse; lib/server/src/db/sparse_db.rs:5-48): only present items are stored
+  bool sparse = false;
+  std::unordered_map<size_t, size_t> slot_of;  // item index -> slot (db_idx_to_vec_idx)
+  spiral::DevBuf<spiral::u64> polys;           // [slot][plane][N] packed NTT words
+  size_t slots_cap = 0;
+  bool index_dirty = true;                     // the structures below are rebuilt before the next query
+  spiral::DevBuf<int> col_ptr, col_rows, col_slots;  // present items by column (CSR): row j and slot
+  std::unique_ptr<spiral::DeviceState::PrunedPlan> sparse_plan;  // expansion pruned to the rows that hold items
+  void ensure_sparse_index();                  // capi.cpp
 };

@@ -365,6 +365,22 @@ class Database:
         except Exception:
             pass
 
+    @classmethod
+    def sparse(cls, params):
+        """lib/server's SparseDb (db/sparse_db.rs:5-48): an empty bucket that stores (and multiplies) only the items
+        written through update_item; process_query on it follows lib/server/src/server.rs:17-99."""
+        self = cls.__new__(cls)
+        self.params, self.shard, self.num_shards, self.by_columns = params, 0, 1, False
+        lib().sp_db_create_sparse.restype = C.c_void_p
+        lib().sp_db_sparse_items.restype = C.c_size_t
+        self.h = lib().sp_db_create_sparse(_vp(params.h))
+        if not self.h:
+            raise SpiralError(_err())
+        return self
+
+    def sparse_items(self):
+        return int(lib().sp_db_sparse_items(_vp(self.h)))
+
     def load(self, words):
         """words: the reference-layout array produced by generate_random_db_and_get_item /
         load_db_from_seek / load_preprocessed_db_from_file (server.rs:223-386)."""
