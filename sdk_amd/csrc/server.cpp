@@ -41,11 +41,8 @@ long tunable(const char* name, long dflt) {
   }
   std::string env = "SPIRAL_";
   for (const char* c = name; *c; c++) env += (char)toupper((unsigned char)*c);
-  const char* e = getenv(env.c_str());
-  const long v = e ? atol(e) : dflt;
-  std::lock_guard<std::mutex> lk(g_tun_mu);
-  g_tun.emplace_back(name, v);  // cache the environment lookup
-  return v;
+  const char* e = getenv(env.c_str());  // looked up every time: tests change the environment between handles
+  return e ? atol(e) : dflt;
 }
 
 static thread_local u64 g_paths = 0;
