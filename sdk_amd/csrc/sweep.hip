@@ -261,8 +261,12 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
 // read back as broadcast ds_reads.  The scalar-load form keeps them in the 16 KiB scalar cache, which B > 4
 // overflows: every query word then costs an L2 round trip and the pass takes 25 ms instead of ~10 at B = 8.
 // Needs all four waves of the workgroup on the same z (chunks % 4 == 0).
+// LDS staging uses a FIXED row stride per query (QLDS_ROWS rows of 16 B): with a compile-time stride every (query, row
+// pair in flight) read is one base VGPR + an immediate offset; a run-time stride (nj) costs one live address register
+// per (query, row pair) -- 64 VGPRs at B = 8, U = 4 -- and pushes the kernel over 256 registers.
+constexpr int QLDS_ROWS = 512;
 template <int B, int U, bool QLDS>
-__global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBatchDesc d) {
+__global__ __launch_bounds__(256, 2) void k_sweep_packed_batch(DevTables T, SweepBatchDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_q[];
   const int lane = threadIdx.x & 63;
   const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -279,7 +283,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
 #pragma unroll
     for (int b = 0; b < B; b++) {
       const uint4* src = reinterpret_cast<const uint4*>(d.qv[b]) + ((size_t)z0 * d.dim0 + d.j0);
-      for (int j = threadIdx.x; j < d.nj; j += 256) qw[b * d.nj + j] = src[j];
+      for (int j = threadIdx.x; j < d.nj; j += 256) qw[b * QLDS_ROWS + j] = src[j];
     }
     __syncthreads();
   }
@@ -295,64 +299,98 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
   for (int b = 0; b < B; b++)
 #pragma unroll
     for (int k = 0; k < 8; k++) acc[b][k] = 0;
-  // software pipeline: the loads of the next U row pairs are issued before the current U are consumed
+  // Software pipeline in PING-PONG form: two buffers of U row pairs each; while buffer A is multiplied, buffer B's loads
+  // are in flight and vice versa.  The buffers are never copied into each other -- a `va = na` rotation at the loop end
+  // forces a full s_waitcnt vmcnt(0) on the just-issued prefetch (a register copy needs the loaded data), which is what
+  // made the first version of this kernel latency-bound (16 ms per pass at B = 8 for 7.5 ms of HBM time).  With no
+  // copies the compiler waits with vmcnt(2 U) for the older buffer only.  npairs % (2 U) == 0 is required (U = 1: any).
   u32x4_t va[U], na[U];
   u32x3_t vb[U], nb[U];
-#pragma unroll
-  for (int uu = 0; uu < U; uu++) {
-    const u32* u = base + (size_t)uu * ustride;
-    va[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
-    vb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
+#define SP_BATCH_LOAD(VA, VB, JP0)                                                                        \
+  _Pragma("unroll") for (int uu = 0; uu < U; uu++) {                                                      \
+    const u32* u = base + (size_t)((JP0) + uu) * ustride;                                                 \
+    VA[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));                  \
+    VB[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));            \
   }
-  for (int jp0 = 0; jp0 < npairs; jp0 += U) {
-    const bool more = jp0 + U < npairs;
-    if (more) {
-#pragma unroll
-      for (int uu = 0; uu < U; uu++) {
-        const u32* u = base + (size_t)(jp0 + U + uu) * ustride;
-        na[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));
-        nb[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));
-      }
+#define SP_BATCH_MAC16(QA, QB, b)                                                                                        \
+  acc[b][0] += (u64)QA.x * f0; acc[b][1] += (u64)QA.z * f0; acc[b][2] += (u64)QA.y * f1; acc[b][3] += (u64)QA.w * f1;     \
+  acc[b][4] += (u64)QA.x * f2; acc[b][5] += (u64)QA.z * f2; acc[b][6] += (u64)QA.y * f3; acc[b][7] += (u64)QA.w * f3;     \
+  acc[b][0] += (u64)QB.x * f4; acc[b][1] += (u64)QB.z * f4; acc[b][2] += (u64)QB.y * f5; acc[b][3] += (u64)QB.w * f5;     \
+  acc[b][4] += (u64)QB.x * f6; acc[b][5] += (u64)QB.z * f6; acc[b][6] += (u64)QB.y * f7; acc[b][7] += (u64)QB.w * f7;
+// one row pair at a time (sched_barrier between them: otherwise the scheduler hoists the query reads of every row pair
+// of the buffer and the kernel needs > 256 registers).  LDS form: the two query rows of query b+1 are read while query
+// b's 16 multiply-accumulates issue.
+#define SP_BATCH_MAC(VA, VB, JP0)                                                                                         \
+  _Pragma("unroll") for (int uu = 0; uu < U; uu++) {                                                                      \
+    const int jp = (JP0) + uu;                                                                                            \
+    const u32 d0 = VA[uu].x, d1 = VA[uu].y, d2 = VA[uu].z, d3 = VA[uu].w, d4 = VB[uu].x, d5 = VB[uu].y, d6 = VB[uu].z;    \
+    const u32 f0 = d0 & M;                                                                                                \
+    const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;                                                             \
+    const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;                                                             \
+    const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;                                                             \
+    const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;                                                             \
+    const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;                                                             \
+    const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;                                                              \
+    const u32 f7 = d6 >> 4;                                                                                               \
+    if (QLDS) {                                                                                                           \
+      uint4 qa_n = qs[2 * jp], qb_n = qs[2 * jp + 1];                                                                     \
+      _Pragma("unroll") for (int b = 0; b < B; b++) {                                                                     \
+        const uint4 qa = qa_n, qb = qb_n;                                                                                 \
+        if (b + 1 < B) {                                                                                                  \
+          qa_n = qs[(b + 1) * QLDS_ROWS + 2 * jp];                                                                        \
+          qb_n = qs[(b + 1) * QLDS_ROWS + 2 * jp + 1];                                                                    \
+        }                                                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                                \
+        SP_BATCH_MAC16(qa, qb, b)                                                                                         \
+      }                                                                                                                   \
+    } else {                                                                                                              \
+      _Pragma("unroll") for (int b = 0; b < B; b++) {                                                                     \
+        const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv[b]) + qoff;                                  \
+        const uint4 qa = qrow[2 * jp];                                                                                    \
+        const uint4 qb = qrow[2 * jp + 1];                                                                                \
+        SP_BATCH_MAC16(qa, qb, b)                                                                                         \
+      }                                                                                                                   \
+    }                                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                    \
+  }
+#define SP_BATCH_FOLD                                                                                     \
+  _Pragma("unroll") for (int b = 0; b < B; b++) {                                                         \
+    acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);                             \
+    acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);                             \
+    acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);                             \
+    acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);                             \
+  }
+  if (U > 1 || (npairs & 1) == 0) {
+    // steady state without conditionals (a branch around the reload lets the optimiser sink the multiply-accumulates
+    // of buffer A below the reload of A, which then needs a third set of registers); the last 2 U row pairs are peeled
+    SP_BATCH_LOAD(va, vb, 0)
+    int jp0 = 0;
+    for (; jp0 + 2 * U < npairs; jp0 += 2 * U) {
+      SP_BATCH_LOAD(na, nb, jp0 + U)
+      __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the multiply-accumulates
+      SP_BATCH_MAC(va, vb, jp0)
+      SP_BATCH_LOAD(va, vb, jp0 + 2 * U)
+      __builtin_amdgcn_sched_barrier(0);
+      SP_BATCH_MAC(na, nb, jp0 + U)
+      // at most 256 rows (128 row pairs) of < 2^56 products between Barrett folds
+      if (((jp0 + 2 * U) & 127) == 0) SP_BATCH_FOLD
     }
-    __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the multiply-accumulates
-#pragma unroll
-    for (int uu = 0; uu < U; uu++) {
-      const int jp = jp0 + uu;
-      const u32 d0 = va[uu].x, d1 = va[uu].y, d2 = va[uu].z, d3 = va[uu].w, d4 = vb[uu].x, d5 = vb[uu].y, d6 = vb[uu].z;
-      const u32 f0 = d0 & M;
-      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
-      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
-      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
-      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
-      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
-      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
-      const u32 f7 = d6 >> 4;
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        const uint4* __restrict__ qrow = QLDS ? qs + b * d.nj : reinterpret_cast<const uint4*>(d.qv[b]) + qoff;
-        const uint4 qa = qrow[2 * jp];
-        const uint4 qb = qrow[2 * jp + 1];
-        acc[b][0] += (u64)qa.x * f0; acc[b][1] += (u64)qa.z * f0; acc[b][2] += (u64)qa.y * f1; acc[b][3] += (u64)qa.w * f1;
-        acc[b][4] += (u64)qa.x * f2; acc[b][5] += (u64)qa.z * f2; acc[b][6] += (u64)qa.y * f3; acc[b][7] += (u64)qa.w * f3;
-        acc[b][0] += (u64)qb.x * f4; acc[b][1] += (u64)qb.z * f4; acc[b][2] += (u64)qb.y * f5; acc[b][3] += (u64)qb.w * f5;
-        acc[b][4] += (u64)qb.x * f6; acc[b][5] += (u64)qb.z * f6; acc[b][6] += (u64)qb.y * f7; acc[b][7] += (u64)qb.w * f7;
-      }
-    }
-    if (!more || ((jp0 + U) & 127) == 0) {  // at most 256 rows of < 2^56 products between Barrett folds
-#pragma unroll
-      for (int b = 0; b < B; b++) {
-        acc[b][0] = reduce64(acc[b][0], m0); acc[b][1] = reduce64(acc[b][1], m0);
-        acc[b][2] = reduce64(acc[b][2], m1); acc[b][3] = reduce64(acc[b][3], m1);
-        acc[b][4] = reduce64(acc[b][4], m0); acc[b][5] = reduce64(acc[b][5], m0);
-        acc[b][6] = reduce64(acc[b][6], m1); acc[b][7] = reduce64(acc[b][7], m1);
-      }
-    }
-#pragma unroll
-    for (int uu = 0; uu < U; uu++) {
-      va[uu] = na[uu];
-      vb[uu] = nb[uu];
+    SP_BATCH_LOAD(na, nb, jp0 + U)
+    __builtin_amdgcn_sched_barrier(0);
+    SP_BATCH_MAC(va, vb, jp0)
+    SP_BATCH_MAC(na, nb, jp0 + U)
+    SP_BATCH_FOLD
+  } else {  // odd number of row pairs (U == 1 only): no pipelining
+    for (int jp0 = 0; jp0 < npairs; jp0++) {
+      SP_BATCH_LOAD(va, vb, jp0)
+      SP_BATCH_MAC(va, vb, jp0)
+      if (((jp0 + 1) & 127) == 0 || jp0 + 1 >= npairs) SP_BATCH_FOLD
     }
   }
+#undef SP_BATCH_LOAD
+#undef SP_BATCH_MAC
+#undef SP_BATCH_MAC16
+#undef SP_BATCH_FOLD
   const size_t rc = (size_t)N * d.num_per;
   const size_t zi = (size_t)plane * 4 * rc + (size_t)z * d.num_per + (size_t)chunk * 128 + 2 * lane;
 #pragma unroll
@@ -367,14 +405,17 @@ __global__ __launch_bounds__(256) void k_sweep_packed_batch(DevTables T, SweepBa
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
   const long units = (long)d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)((units + 3) / 4));
-  const bool unroll = ((d.nj >> 1) % 4) == 0;
-  const int lds_min_b = (int)tunable("batch_qlds_min", 5);
-  const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && (size_t)d.batch * d.nj * 16 <= 65536;
-  const size_t lds = qlds ? (size_t)d.batch * d.nj * 16 : 0;
+  const bool unroll = ((d.nj >> 1) % 8) == 0;  // U = 4 (and the U = 2 LDS form) run ping-pong: npairs % (2 U) == 0
+  const int lds_min_b = (int)tunable("batch_qlds_min", 4);
+  const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && d.nj <= QLDS_ROWS;
+  const size_t lds = qlds ? (size_t)d.batch * QLDS_ROWS * 16 : 0;
+  const int u_lds = (int)tunable("batch_lds_unroll", 2);  // row pairs per ping-pong buffer in the LDS-staged form
 #define SP_BATCH_CASE(B)                                                                              \
   case B:                                                                                             \
-    if (qlds)                                                                                         \
-      hipLaunchKernelGGL((k_sweep_packed_batch<B, (B >= 7 ? 2 : 4), true>), grid, dim3(256), lds, s, T, d); \
+    if (qlds && u_lds == 2)                                                                           \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 2, true>), grid, dim3(256), lds, s, T, d);          \
+    else if (qlds)                                                                                    \
+      hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, true>), grid, dim3(256), lds, s, T, d);          \
     else if (unroll)                                                                                  \
       hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, false>), grid, dim3(256), 0, s, T, d);           \
     else                                                                                              \
