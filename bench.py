@@ -391,7 +391,9 @@ def main():
     if rank == 0:
         q_per_step = batch * (world if replicas else 1) if mode in ("single", "replicas") else 1
         traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches)
-        kernel = ("k_sweep_packed_batch" if batch > 1 else "k_sweep_packed_persist<4>") if cfg["nu_2"] >= 7 else "k_sweep_narrow2"
+        # the roofline block always describes the kernel sp_bench_sweep / the stage events time: the single-query sweep
+        # (batched steps run k_sweep_packed_batch<B>, whose pass time is in profiles/r02_batch8_kernel_stats.md)
+        kernel = "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2"
         workload_how = {
             "single": "unsharded, one query per step" if batch == 1 else "unsharded, %d queries per step (<= 8 per database pass)" % batch,
             "replicas": "whole database on each of the %d GPUs, %d queries per GPU per step (one database pass), no collective in the timed region (BASELINE configs[4])" % (world, batch),
