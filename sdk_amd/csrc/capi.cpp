@@ -155,7 +155,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
-                                "rccl_in_library", "fold_fused_lowreg", "cu_split_overlap"};
+                                "rccl_in_library", "fold_wave", "cu_split_overlap"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -1329,6 +1329,7 @@ int sp_fold_ciphertexts_fused(const sp_params_t* h, uint64_t* cts, size_t num_pe
         HIP_CHECK(hipMemcpyAsync(row + two_t * 2 * POLY_LEN, dF.p + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, W->stream));
       }
     launch_folding_neg(W->D->T, W->fold_mats.p, W->D->gadget_gsw.p, (int)further, (int)two_t, W->stream);
+    run_mats_to_wave(*W, further);
     HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
     const long saved = W->fused_min_pairs;
     if (fused_min_pairs > 0) W->fused_min_pairs = fused_min_pairs;

@@ -1,6 +1,7 @@
 // Fused fold step of fold_ciphertexts (server.rs:388-427) for gfx950: digits -> NTT -> multiply-accumulate -> iNTT -> CRT
 // in registers / LDS.  See DESIGN.md section 3 for the algebra and the roofline.
 #include "device_common.hpp"
+#include "wave_ntt.hpp"
 
 namespace spiral {
 
@@ -63,7 +64,8 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
       }
 #pragma unroll 1
       for (int kd = 0; kd < d.t; kd++) {
-        const int sh = kd * d.bits;
+        const int sh = (kd * d.bits) & 63;
+      const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
         u32 v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -252,9 +254,170 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
     }
   }
 }
+// ------------------------------------------------------------------------------------------------
+// Fused fold step on the wave-per-transform NTT (wave_ntt.hpp).  grid (half, planes), 4 waves per step.
+// Same algebra as k_fold_fused*: out = ct_i + from_ntt( C * NTT(G^-1(ct_{i+half}) - G^-1(ct_i)) ).
+// Per modulus: the 2t digit polynomials are dealt to the four waves (digit dg -> wave dg % 4); each wave transforms
+// its digits one after the other without any workgroup barrier and multiply-accumulates them into private 64-bit
+// sums for both output rows (32 coefficients per lane); the four partial sums are combined through LDS (two rounds),
+// wave 0 ends up with row 0 and wave 1 with row 1 and each runs one inverse transform; Garner and + ct_i as before.
+// mats_w: the level's [G-C | C] operands in wave layout (wave_layout_word), same polynomial order as FoldDesc::mats.
+// Needs an even digit count t (2t digits over 4 waves).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, const u32* __restrict__ mats_w) {
+  __shared__ u32 wbuf[4 * WBUF_WORDS];  // transposes (one region per wave) / cross-wave reduction scratch
+  __shared__ u32 ltw[2 * N];            // forward tables of the current modulus (swizzled, wtw_stage)
+  const int tau = threadIdx.x, lane = tau & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index, shifts and row pointers stay scalar
+  const int i = blockIdx.x, plane = blockIdx.y;
+  const int two_t = 2 * d.t, four_t = 4 * d.t;
+  const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
+  const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
+  u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
+  if (d.zero_shortcuts && fold_zero_shortcut(ct0, ct1, out, tau)) return;
+  const u64 mask = (1ULL << d.bits) - 1ULL;
+  u32* mybuf = wbuf + wv * WBUF_WORDS;
+#pragma unroll 1
+  for (int c = 0; c < 2; c++) {
+    const ModConst m = T.c.mod[c];
+    const u32* fw = T.tw + (size_t)c * 4 * N;
+    if (c == 1) __syncthreads();
+    wtw_stage(ltw, fw, tau);
+    __syncthreads();
+    u64 acc0[32], acc1[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) acc0[k] = acc1[k] = 0;
+#pragma unroll 1
+    for (int dg = wv; dg < two_t; dg += 4) {
+      const int j = dg / d.t, kd = dg - j * d.t;
+      const int sh = (kd * d.bits) & 63;
+      const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
+      // everything derived from the lane id or the table pointer is loop invariant; left alone the compiler hoists some
+      // sixty addresses and as many scalar twiddles out of this loop and spills the accumulators to make room for them
+      int ln = lane;
+      const u32* fwi = fw;
+      asm volatile("" : "+v"(ln));
+      asm volatile("" : "+s"(fwi));
+      u32 v[32];
+#pragma unroll
+      for (int kc = 0; kc < 4; kc++) {  // eight coefficients at a time: 16 loads in flight, not 64
+#pragma unroll
+        for (int k = 8 * kc; k < 8 * kc + 8; k++) {
+          const u64 x0 = ct0[(size_t)j * N + 64 * k + ln], x1 = ct1[(size_t)j * N + 64 * k + ln];
+          u32 d0 = (u32)((x0 >> sh) & dmask);
+          u32 d1 = (u32)((x1 >> sh) & dmask);
+          if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
+            d0 = d0 >= m.q ? d0 - m.q : d0;
+            d1 = d1 >= m.q ? d1 - m.q : d1;
+          }
+          v[k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      wntt_fwd(v, ln, mybuf, fwi, ltw, m.q, m.two_q);
+      const int kk = two_t + j + 2 * kd;  // column of C inside the [G-C | C] row
+      const u32x4w_t* a0 = reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)kk * 2 + c) * N) + ln;
+      const u32x4w_t* a1 = reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)(four_t + kk) * 2 + c) * N) + ln;
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        const u32x4w_t p = a0[64 * g], r = a1[64 * g];
+        acc0[4 * g] += (u64)p.x * v[4 * g]; acc0[4 * g + 1] += (u64)p.y * v[4 * g + 1];
+        acc0[4 * g + 2] += (u64)p.z * v[4 * g + 2]; acc0[4 * g + 3] += (u64)p.w * v[4 * g + 3];
+        acc1[4 * g] += (u64)r.x * v[4 * g]; acc1[4 * g + 1] += (u64)r.y * v[4 * g + 1];
+        acc1[4 * g + 2] += (u64)r.z * v[4 * g + 2]; acc1[4 * g + 3] += (u64)r.w * v[4 * g + 3];
+        if (g & 1) __builtin_amdgcn_sched_barrier(0);  // two operand vectors per row in flight, not sixteen
+      }
+    }
+    // partial sums of the four waves -> wave 0 (row 0) and wave 1 (row 1).  u32 residues travel through LDS as b128
+    // vectors at [(g * 64 + lane)] (conflict-free); region s holds one row of one wave (2048 words)
+    u32 r0[32], r1[32];
+    int lt = lane;  // as above: keeps the tail's sixty-odd row addresses from being hoisted over the digit loop
+    asm volatile("" : "+v"(lt));
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      r0[k] = reduce64(acc0[k], m);
+      r1[k] = reduce64(acc1[k], m);
+    }
+    u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(wbuf);
+#define SP_PUT(R, REGION)                                                                              \
+  _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
+    u32x4w_t t4;                                                                                       \
+    t4.x = R[4 * g]; t4.y = R[4 * g + 1]; t4.z = R[4 * g + 2]; t4.w = R[4 * g + 3];                    \
+    sc[(REGION) * 512 + g * 64 + lt] = t4;                                                           \
+  }
+#define SP_ADD(R, REGION)                                                                              \
+  _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
+    const u32x4w_t t4 = sc[(REGION) * 512 + g * 64 + lt];                                            \
+    R[4 * g] = add_mod(R[4 * g], t4.x, m.q); R[4 * g + 1] = add_mod(R[4 * g + 1], t4.y, m.q);          \
+    R[4 * g + 2] = add_mod(R[4 * g + 2], t4.z, m.q); R[4 * g + 3] = add_mod(R[4 * g + 3], t4.w, m.q);  \
+  }
+    __syncthreads();  // every wave is done with its transpose buffer
+    if (wv == 2) { SP_PUT(r0, 0) SP_PUT(r1, 1) }
+    if (wv == 3) { SP_PUT(r0, 2) SP_PUT(r1, 3) }
+    __syncthreads();
+    if (wv == 0) { SP_ADD(r0, 0) SP_ADD(r0, 2) }
+    if (wv == 1) { SP_ADD(r1, 1) SP_ADD(r1, 3) }
+    __syncthreads();
+    if (wv == 0) { SP_PUT(r1, 0) }
+    if (wv == 1) { SP_PUT(r0, 1) }
+    __syncthreads();
+    if (wv == 0) { SP_ADD(r0, 1) }
+    if (wv == 1) { SP_ADD(r1, 0) }
+    __syncthreads();  // the scratch is free again: waves 0 and 1 use their own regions for the inverse transform
+#undef SP_PUT
+#undef SP_ADD
+    if (wv < 2) {
+      const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+      u64* orow = out + (size_t)wv * N;
+      const u64* crow = ct0 + (size_t)wv * N;
+      u32 rr[32];
+#pragma unroll
+      for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
+      wntt_inv(rr, lt, mybuf, iw, m.q, m.two_q);
+      if (c == 0) {  // park the modulus-0 residues in the output slot (the same lane re-reads them below)
+#pragma unroll
+        for (int k = 0; k < 32; k++) orow[64 * k + lt] = rr[k];
+      } else {
+        const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+#pragma unroll
+        for (int k = 0; k < 32; k++) {
+          const size_t zi = 64 * k + lt;
+          u32 x = (u32)orow[zi], y = rr[k];
+          u32 xm = x >= q1 ? x - q1 : x;
+          u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+          e = e >= q1 ? e - q1 : e;
+          u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
+          orow[zi] = val >= T.c.Q ? val - T.c.Q : val;
+        }
+      }
+    }
+  }
+}
+
+// fold_mats (NTT polynomials [crt][z]) -> wave layout, same polynomial order: one thread per word
+__global__ __launch_bounds__(256) void k_mats_to_wave(u32* dst, const u32* __restrict__ src, size_t n_words) {
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= n_words) return;
+  const size_t poly = idx >> POLY_LEN_LOG2;  // (polynomial, crt) pairs are N words each
+  const int n = (int)(idx & (N - 1));
+  dst[poly * N + wave_layout_word(n)] = src[idx];
+}
+void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
+  if (n_words == 0) return;
+  hipLaunchKernelGGL(k_mats_to_wave, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, dst, src, n_words);
+  launched(0, "k_mats_to_wave");
+}
+
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   const int variant = (int)tunable("fold_variant", 3);
+  if (variant == 5 && d.mats_w && (d.t % 2) == 0) {
+    hipLaunchKernelGGL(k_fold_wave, dim3(d.half, d.planes), dim3(256), 0, s, T, d, d.mats_w);
+    launched(PATH_FOLD_FUSED | PATH_FOLD_WAVE, "k_fold_wave");
+    return;
+  }
   if (variant == 3 && (d.t % 2) == 0)
     hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 2 && (d.t % 2) == 0)

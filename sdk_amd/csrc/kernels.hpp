@@ -43,7 +43,7 @@ enum PathBit : u64 {
   PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_head (first expansion rounds in one launch)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
-  PATH_FOLD_FUSED_LOWREG = 1ull << 20,// k_fold_fused3 (lower-VGPR form)
+  PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
   PATH_CU_SPLIT = 1ull << 21          // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
@@ -157,7 +157,11 @@ struct FoldDesc {
   // lib/server semantics (lib/server/src/compute/fold.rs:38-44): an all-zero ct_i is replaced by ct_{i+half}, an
   // all-zero ct_{i+half} leaves ct_i as it is -- no external product in either case
   int zero_shortcuts;
+  // the level's operands in wave layout (k_fold_wave); nullptr: not available
+  const u32* mats_w;
 };
+// fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
+void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
 
 // dst poly idx[b] += src poly b   (NTT polys, mod q)

@@ -33,6 +33,8 @@ struct Workspace {
   DevBuf<u32> exp_ct1;    // NTT of row 1 of the automorphed cts
   DevBuf<u64> qv;         // reoriented first-dimension query [N][dim0][2]
   DevBuf<u32> fold_mats;  // [nu_2][2 rows][ G - C | C ] (2 x 4 t_gsw NTT polys per GSW ct)
+  DevBuf<u32> fold_mats_w;  // the same polynomials in wave layout (k_fold_wave), filled by run_folding_neg
+  bool mats_w_ready = false;
   DevBuf<u64> gsw_raw;
   DevBuf<u32> gsw_dig;
   // sweep
@@ -66,6 +68,7 @@ struct Workspace {
 void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan = nullptr);
 void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
 void run_folding_neg(Workspace& W);
+void run_mats_to_wave(Workspace& W, size_t levels);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0,

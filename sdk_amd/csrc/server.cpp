@@ -603,6 +603,18 @@ void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int
 void run_folding_neg(Workspace& W) {
   const Params& p = *W.P;
   launch_folding_neg(W.D->T, W.fold_mats.p, W.D->gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), W.stream);
+  run_mats_to_wave(W, p.db_dim_2);
+}
+
+// the fold operands once more in wave layout when the wave-per-transform fold kernel is selected (fold_variant 5)
+void run_mats_to_wave(Workspace& W, size_t levels) {
+  const Params& p = *W.P;
+  W.mats_w_ready = false;
+  if (tunable("fold_variant", 3) != 5 || (p.t_gsw % 2) != 0 || !fused_fold_supported(p) || levels == 0) return;
+  const size_t words = levels * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
+  W.fold_mats_w.ensure(words);
+  launch_mats_to_wave(W.fold_mats_w.p, W.fold_mats.p, words, W.stream);
+  W.mats_w_ready = true;
 }
 
 // Non-expanded ("direct_upload") queries: Query::deserialize (client.rs:315-327) regenerates the public
@@ -839,6 +851,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
     if (W.zero_shortcuts || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
       FoldDesc fd{};
       fd.zero_shortcuts = W.zero_shortcuts ? 1 : 0;
+      fd.mats_w = W.mats_w_ready ? W.fold_mats_w.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN : nullptr;
       fd.X = X;
       fd.Y = Y;
       fd.mats = W.fold_mats.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN;

@@ -305,7 +305,7 @@ def test_process_query_c1(sp, oracle_mod):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3"])
+@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "5"])
 def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
     """The fused fold kernels (k_fold_fused / k_fold_fused2: the form used when a level has >= 256 (pair, plane)
     units, i.e. at C2 scale) forced on for a small tree, every kernel variant, through the STAGE export that runs
@@ -331,6 +331,7 @@ def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
     assert (sp.fold_ciphertexts_fused(p, raw, v_fold, fused_min_pairs=1)[:2 * N] == expect).all()
     taken = sp.paths_taken()
     assert "fold_fused" in taken and not ({"fold_tail_delta", "fold_tail_literal", "fold_tail_persistent"} & taken), taken
+    assert ("fold_wave" in taken) == (variant == "5"), taken     # the wave-per-transform kernel (wave_ntt.hpp)
     # mixed: the first levels fused, the tail of the tree through the non-fused form
     assert (sp.fold_ciphertexts_fused(p, raw, v_fold, fused_min_pairs=4)[:2 * N] == expect).all()
     taken = sp.paths_taken()
