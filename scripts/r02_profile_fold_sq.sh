@@ -2,7 +2,7 @@
 cd /tmp; export TMPDIR=/tmp
 R=/root/repo
 export SPIRAL_PIPELINE=0
-for v in 3 5; do
+for v in ${FOLD_VARIANTS:-3 5}; do
   export SPIRAL_FOLD_VARIANT=$v
   i=0
   for set in "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CU_CYCLES" \

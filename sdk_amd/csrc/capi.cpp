@@ -155,7 +155,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
-                                "rccl_in_library", "fold_wave", "cu_split_overlap"};
+                                "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -542,6 +542,10 @@ sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len
     pp->all.alloc(off * 2 * POLY_LEN);
     FwdDesc f{d_raw.p, nullptr, pp->all.p, (int)off, 1, 1, 1, 64, 1, 0, 1};  // to_ntt_alloc (client.rs:244-247)
     launch_ntt_fwd(D.T, f, 0);
+    if (p.expand_queries) {
+      pp->all_w.alloc(off * 2 * POLY_LEN);
+      launch_mats_to_wave(pp->all_w.p, pp->all.p, off * 2 * POLY_LEN, 0);
+    }
     // [W_0 | W_1 | ...] for pack (server.rs:450-463)
     const size_t n = p.n, tc = p.t_conv;
     pp->pack_cat.alloc((n + 1) * n * tc * 2 * POLY_LEN);
@@ -1247,6 +1251,7 @@ int sp_expand_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* quer
     check_device(pp->device);
     Scoped W(h);
     run_begin(*W, *pp, query, query_len);
+    join_right(*W);  // the GSW side is produced on the second stream
     download_raw(*W, W->qv.p, POLY_LEN * p.dim0() * 2, v_reg_reoriented);
     const size_t nu2 = p.db_dim_2, two_t = 2 * p.t_gsw;
     if (nu2 > 0) {

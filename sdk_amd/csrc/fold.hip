@@ -64,8 +64,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
       }
 #pragma unroll 1
       for (int kd = 0; kd < d.t; kd++) {
-        const int sh = (kd * d.bits) & 63;
-      const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
+        const int sh = kd * d.bits;
         u32 v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -257,76 +256,166 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
 // ------------------------------------------------------------------------------------------------
 // Fused fold step on the wave-per-transform NTT (wave_ntt.hpp).  grid (half, planes), 4 waves per step.
 // Same algebra as k_fold_fused*: out = ct_i + from_ntt( C * NTT(G^-1(ct_{i+half}) - G^-1(ct_i)) ).
-// Per modulus: the 2t digit polynomials are dealt to the four waves (digit dg -> wave dg % 4); each wave transforms
-// its digits one after the other without any workgroup barrier and multiply-accumulates them into private 64-bit
-// sums for both output rows (32 coefficients per lane); the four partial sums are combined through LDS (two rounds),
-// wave 0 ends up with row 0 and wave 1 with row 1 and each runs one inverse transform; Garner and + ct_i as before.
+//   prologue   the 2t digit differences d = G^-1(ct_{i+half})_dg - G^-1(ct_i)_dg are small SIGNED integers that do
+//              not depend on the modulus: all 256 threads fetch the two ciphertexts once (32 loads in flight per
+//              thread) and park the differences in LDS: the low 8 ES bits in a byte/short/word plane per digit, the
+//              sign in a bit plane (ES = 1 for the 8-bit digits of t_gsw = 8: 9-bit differences in 36 KiB)
+//   per modulus  the digit polynomials are dealt to the four waves (digit dg -> wave dg % 4); a wave reads a digit from
+//              LDS (two b128 per lane at ES = 1), transforms it without any workgroup barrier and multiply-accumulates
+//              it into private 64-bit sums for both output rows (32 coefficients per lane) -- the operands are fetched
+//              during the transform's last stages and consumed quarter by quarter as it finishes (FoldMac);
+//              the four partial sums are combined through LDS (two rounds), wave 0 ends up with row 0 and wave 1 with
+//              row 1 and each runs one inverse transform; Garner and + ct_i as before.
 // mats_w: the level's [G-C | C] operands in wave layout (wave_layout_word), same polynomial order as FoldDesc::mats.
-// Needs an even digit count t (2t digits over 4 waves).
+// LDS: [4 transpose buffers 18 KiB | forward tables of the current modulus 16 KiB | digit planes 2t * 2048 * ES | sign planes 2t * 256];
+// the first 32 KiB double as the cross-wave reduction scratch.
 // ------------------------------------------------------------------------------------------------
+constexpr int FOLD_WAVE_FIXED_LDS = (4 * WBUF_WORDS + 2 * N) * 4;
+
+struct FoldMac {  // hooks into wntt_fwd: operand vectors of coefficient group g (4 coefficients per lane) for both rows
+  u64 (&acc0)[32];
+  u64 (&acc1)[32];
+  const u32x4w_t* a0;
+  const u32x4w_t* a1;
+  u32x4w_t m0[8], m1[8];
+  __device__ __forceinline__ void fetch(int g) {
+    m0[g] = a0[64 * g];
+    m1[g] = a1[64 * g];
+  }
+  __device__ __forceinline__ void mac(int g, const u32 (&v)[32]) {
+    acc0[4 * g] += (u64)m0[g].x * v[4 * g]; acc0[4 * g + 1] += (u64)m0[g].y * v[4 * g + 1];
+    acc0[4 * g + 2] += (u64)m0[g].z * v[4 * g + 2]; acc0[4 * g + 3] += (u64)m0[g].w * v[4 * g + 3];
+    acc1[4 * g] += (u64)m1[g].x * v[4 * g]; acc1[4 * g + 1] += (u64)m1[g].y * v[4 * g + 1];
+    acc1[4 * g + 2] += (u64)m1[g].z * v[4 * g + 2]; acc1[4 * g + 3] += (u64)m1[g].w * v[4 * g + 3];
+  }
+  __device__ __forceinline__ void before_t4() {
+    fetch(0); fetch(1); fetch(2); fetch(3);
+  }
+  __device__ __forceinline__ void before_t1() {
+    fetch(4); fetch(5);
+  }
+  __device__ __forceinline__ void after_quarter(int qq, u32 (&v)[32]) {  // quarter qq = coefficients 8qq .. 8qq+7, final
+    if (qq == 0) {
+      fetch(6); fetch(7);
+      SP_SB();
+    }
+    mac(2 * qq, v);
+    mac(2 * qq + 1, v);
+  }
+};
+
+template <int ES>
 __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, const u32* __restrict__ mats_w) {
-  __shared__ u32 wbuf[4 * WBUF_WORDS];  // transposes (one region per wave) / cross-wave reduction scratch
-  __shared__ u32 ltw[2 * N];            // forward tables of the current modulus (swizzled, wtw_stage)
+  extern __shared__ __attribute__((aligned(16))) u32 smem_fw[];
+  u32* wbuf = smem_fw;                      // transposes (one region per wave) ...
+  u32* ltw = smem_fw + 4 * WBUF_WORDS;      // forward tables of the current modulus (swizzled, wtw_stage)
+  unsigned char* dig = reinterpret_cast<unsigned char*>(ltw + 2 * N);
+  unsigned char* sgn = dig + (size_t)2 * d.t * (N * ES);  // sign bits: digit dg, lane l -> one dword, bit k = coefficient 64k + l
+  constexpr int E = 16 / ES;                // digit differences per 16-byte vector
   const int tau = threadIdx.x, lane = tau & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index, shifts and row pointers stay scalar
+  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index and row pointers stay scalar
   const int i = blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
   u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
   if (d.zero_shortcuts && fold_zero_shortcut(ct0, ct1, out, tau)) return;
-  const u64 mask = (1ULL << d.bits) - 1ULL;
   u32* mybuf = wbuf + wv * WBUF_WORDS;
+  {  // digit differences of coefficients 64k + lane, k = 8 wv .. 8 wv + 7, both rows.  Element (digit, n = 64k + lane) lives
+     // at byte (digit * 2048 * ES) + (k / E) * 1024 + lane * 16 + (k % E) * ES: a lane's 32 values are 2 ES vectors of
+     // 16 bytes, vector h of all lanes one contiguous KiB (conflict-free b128 reads)
+    const u64 mask = (1ULL << d.bits) - 1ULL;
+    u64 x0[2][8], x1[2][8];
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int e = 0; e < 8; e++) {
+        const size_t n = (size_t)j * N + 64 * (8 * wv + e) + lane;
+        x0[j][e] = ct0[n];
+        x1[j][e] = ct1[n];
+      }
+#pragma unroll 1
+    for (int kd = 0; kd < d.t; kd++) {
+      const int sh = (kd * d.bits) & 63;
+      const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        u32 df[8];
+#pragma unroll
+        for (int e = 0; e < 8; e++) df[e] = (u32)((x1[j][e] >> sh) & dmask) - (u32)((x0[j][e] >> sh) & dmask);
+        unsigned char* base = dig + (size_t)(j * d.t + kd) * (N * ES);
+        u32 sb = 0;
+#pragma unroll
+        for (int e = 0; e < 8; e++) sb |= (df[e] >> 31) << e;
+        sgn[(j * d.t + kd) * 256 + lane * 4 + wv] = (unsigned char)sb;
+        if (ES == 1) {
+          u32x2w_t o;
+          o.x = (df[0] & 0xff) | ((df[1] & 0xff) << 8) | ((df[2] & 0xff) << 16) | (df[3] << 24);
+          o.y = (df[4] & 0xff) | ((df[5] & 0xff) << 8) | ((df[6] & 0xff) << 16) | (df[7] << 24);
+          *reinterpret_cast<u32x2w_t*>(base + (wv >> 1) * 1024 + lane * 16 + 8 * (wv & 1)) = o;
+        } else if (ES == 2) {
+          u32x4w_t o;
+          o.x = (df[0] & 0xffff) | (df[1] << 16); o.y = (df[2] & 0xffff) | (df[3] << 16);
+          o.z = (df[4] & 0xffff) | (df[5] << 16); o.w = (df[6] & 0xffff) | (df[7] << 16);
+          *reinterpret_cast<u32x4w_t*>(base + wv * 1024 + lane * 16) = o;
+        } else {
+          u32x4w_t o;
+          o.x = df[0]; o.y = df[1]; o.z = df[2]; o.w = df[3];
+          *reinterpret_cast<u32x4w_t*>(base + (2 * wv) * 1024 + lane * 16) = o;
+          o.x = df[4]; o.y = df[5]; o.z = df[6]; o.w = df[7];
+          *reinterpret_cast<u32x4w_t*>(base + (2 * wv + 1) * 1024 + lane * 16) = o;
+        }
+      }
+    }
+  }
 #pragma unroll 1
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
     const u32* fw = T.tw + (size_t)c * 4 * N;
-    if (c == 1) __syncthreads();
+    if (c == 1) __syncthreads();  // the reduction scratch of modulus 0 overlapped the table area
     wtw_stage(ltw, fw, tau);
-    __syncthreads();
+    __syncthreads();              // tables (and, the first time, the digit differences) are in place
     u64 acc0[32], acc1[32];
 #pragma unroll
     for (int k = 0; k < 32; k++) acc0[k] = acc1[k] = 0;
 #pragma unroll 1
     for (int dg = wv; dg < two_t; dg += 4) {
       const int j = dg / d.t, kd = dg - j * d.t;
-      const int sh = (kd * d.bits) & 63;
-      const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
       // everything derived from the lane id or the table pointer is loop invariant; left alone the compiler hoists some
       // sixty addresses and as many scalar twiddles out of this loop and spills the accumulators to make room for them
       int ln = lane;
       const u32* fwi = fw;
       asm volatile("" : "+v"(ln));
       asm volatile("" : "+s"(fwi));
+      const unsigned char* src = dig + (size_t)dg * (N * ES) + ln * 16;
+      u32x4w_t dv[2 * ES];
+#pragma unroll
+      for (int h = 0; h < 2 * ES; h++) dv[h] = *reinterpret_cast<const u32x4w_t*>(src + h * 1024);
+      const int sg = *reinterpret_cast<const int*>(sgn + dg * 256 + ln * 4);
+      WaveScalarTw stw;
+      wntt_scalar_tw(stw, fwi);
+      SP_SB();
       u32 v[32];
 #pragma unroll
-      for (int kc = 0; kc < 4; kc++) {  // eight coefficients at a time: 16 loads in flight, not 64
+      for (int h = 0; h < 2 * ES; h++) {
+        const u32 wd[4] = {dv[h].x, dv[h].y, dv[h].z, dv[h].w};
 #pragma unroll
-        for (int k = 8 * kc; k < 8 * kc + 8; k++) {
-          const u64 x0 = ct0[(size_t)j * N + 64 * k + ln], x1 = ct1[(size_t)j * N + 64 * k + ln];
-          u32 d0 = (u32)((x0 >> sh) & dmask);
-          u32 d1 = (u32)((x1 >> sh) & dmask);
-          if (d.bits >= 28) {  // 28-bit digits can exceed q (q < 2^28 < 2q): canonical residues first
-            d0 = d0 >= m.q ? d0 - m.q : d0;
-            d1 = d1 >= m.q ? d1 - m.q : d1;
+        for (int e = 0; e < E; e++) {
+          // low 8 ES bits from the digit plane, everything above from the sign plane (two's complement)
+          const int sm = __builtin_amdgcn_sbfe(sg, h * E + e, 1);
+          const int sd = ES == 4 ? (int)wd[e] : (int)(__builtin_amdgcn_ubfe(wd[(e * ES) >> 2], ((e * ES) & 3) * 8, 8 * ES) | ((u32)sm << (8 * ES)));
+          u32 x = (u32)(sd + (sm & (int)m.q));  // |difference| < q unless the digits have 28+ bits
+          if (ES == 4) {
+            x += (u32)(((int)x >> 31) & (int)m.q);
+            x -= (x >= m.q ? m.q : 0u);
           }
-          v[k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
+          v[h * E + e] = x;
         }
-        __builtin_amdgcn_sched_barrier(0);
       }
-      wntt_fwd(v, ln, mybuf, fwi, ltw, m.q, m.two_q);
       const int kk = two_t + j + 2 * kd;  // column of C inside the [G-C | C] row
-      const u32x4w_t* a0 = reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)kk * 2 + c) * N) + ln;
-      const u32x4w_t* a1 = reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)(four_t + kk) * 2 + c) * N) + ln;
-#pragma unroll
-      for (int g = 0; g < 8; g++) {
-        const u32x4w_t p = a0[64 * g], r = a1[64 * g];
-        acc0[4 * g] += (u64)p.x * v[4 * g]; acc0[4 * g + 1] += (u64)p.y * v[4 * g + 1];
-        acc0[4 * g + 2] += (u64)p.z * v[4 * g + 2]; acc0[4 * g + 3] += (u64)p.w * v[4 * g + 3];
-        acc1[4 * g] += (u64)r.x * v[4 * g]; acc1[4 * g + 1] += (u64)r.y * v[4 * g + 1];
-        acc1[4 * g + 2] += (u64)r.z * v[4 * g + 2]; acc1[4 * g + 3] += (u64)r.w * v[4 * g + 3];
-        if (g & 1) __builtin_amdgcn_sched_barrier(0);  // two operand vectors per row in flight, not sixteen
-      }
+      FoldMac hk{acc0, acc1, reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)kk * 2 + c) * N) + ln,
+                 reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)(four_t + kk) * 2 + c) * N) + ln};
+      wntt_fwd<false>(v, ln, mybuf, fwi, stw, ltw, m.q, m.two_q, hk);
     }
     // partial sums of the four waves -> wave 0 (row 0) and wave 1 (row 1).  u32 residues travel through LDS as b128
     // vectors at [(g * 64 + lane)] (conflict-free); region s holds one row of one wave (2048 words)
@@ -338,20 +427,20 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
       r0[k] = reduce64(acc0[k], m);
       r1[k] = reduce64(acc1[k], m);
     }
-    u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(wbuf);
+    u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(smem_fw);
 #define SP_PUT(R, REGION)                                                                              \
   _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
     u32x4w_t t4;                                                                                       \
     t4.x = R[4 * g]; t4.y = R[4 * g + 1]; t4.z = R[4 * g + 2]; t4.w = R[4 * g + 3];                    \
-    sc[(REGION) * 512 + g * 64 + lt] = t4;                                                           \
+    sc[(REGION) * 512 + g * 64 + lt] = t4;                                                             \
   }
 #define SP_ADD(R, REGION)                                                                              \
   _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
-    const u32x4w_t t4 = sc[(REGION) * 512 + g * 64 + lt];                                            \
+    const u32x4w_t t4 = sc[(REGION) * 512 + g * 64 + lt];                                              \
     R[4 * g] = add_mod(R[4 * g], t4.x, m.q); R[4 * g + 1] = add_mod(R[4 * g + 1], t4.y, m.q);          \
     R[4 * g + 2] = add_mod(R[4 * g + 2], t4.z, m.q); R[4 * g + 3] = add_mod(R[4 * g + 3], t4.w, m.q);  \
   }
-    __syncthreads();  // every wave is done with its transpose buffer
+    __syncthreads();  // every wave is done with its transpose buffer and the tables
     if (wv == 2) { SP_PUT(r0, 0) SP_PUT(r1, 1) }
     if (wv == 3) { SP_PUT(r0, 2) SP_PUT(r1, 3) }
     __syncthreads();
@@ -413,10 +502,20 @@ void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   const int variant = (int)tunable("fold_variant", 3);
-  if (variant == 5 && d.mats_w && (d.t % 2) == 0) {
-    hipLaunchKernelGGL(k_fold_wave, dim3(d.half, d.planes), dim3(256), 0, s, T, d, d.mats_w);
-    launched(PATH_FOLD_FUSED | PATH_FOLD_WAVE, "k_fold_wave");
-    return;
+  if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)
+    const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
+    const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
+    if (lds <= 80 * 1024) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
+      const dim3 grid(d.half, d.planes), block(256);  // > 64 KiB of dynamic LDS needs no opt-in on gfx950 (scripts/ubench/dyn_lds.hip)
+      if (es == 1)
+        hipLaunchKernelGGL(k_fold_wave<1>, grid, block, lds, s, T, d, d.mats_w);
+      else if (es == 2)
+        hipLaunchKernelGGL(k_fold_wave<2>, grid, block, lds, s, T, d, d.mats_w);
+      else
+        hipLaunchKernelGGL(k_fold_wave<4>, grid, block, lds, s, T, d, d.mats_w);
+      launched(PATH_FOLD_FUSED | PATH_FOLD_WAVE, "k_fold_wave");
+      return;
+    }
   }
   if (variant == 3 && (d.t % 2) == 0)
     hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);

@@ -44,7 +44,8 @@ enum PathBit : u64 {
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
-  PATH_CU_SPLIT = 1ull << 21          // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
+  PATH_CU_SPLIT = 1ull << 21,         // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
+  PATH_EXPAND_SPLIT = 1ull << 22      // odd expansion subtree + GSW side on the second stream, beside the even subtree
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -163,6 +164,21 @@ struct FoldDesc {
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
+
+// One round of coefficient_expansion, one workgroup per ciphertext (expand.hip).  Group 0 / 1 = the "left" / "right"
+// ciphertexts of the round (different gadget widths and key-switching matrices).
+struct ExpandDesc {
+  const u32* src;        // v as the round finds it: [ct][row][crt][N]
+  u32* dst;              // v as the round leaves it (a different buffer: see expand.hip)
+  const int* ct_idx[2];  // ciphertext indices of the group
+  int n[2];
+  int t[2], bits[2];
+  const u32* W[2];       // 2 x t key-switching matrix of this round in wave layout (sp_pp::all_w)
+  int num_in;            // ciphertexts >= num_in are first formed as neg1 * v[ct - num_in]
+  const u32* neg1;       // [crt][N] of this round
+  int t_auto;
+};
+void launch_expand_round(const DevTables& T, const ExpandDesc& d, hipStream_t s);
 
 // dst poly idx[b] += src poly b   (NTT polys, mod q)
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s);

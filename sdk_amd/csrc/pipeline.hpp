@@ -14,6 +14,8 @@ struct Workspace {
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
+  hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
+  bool right_pending = false;               // this query's fold operands are produced on stream2: join_right before use
   // CU-partitioned overlap (SPIRAL_CU_SPLIT = n > 0): the per-plane sweeps run on a stream masked to all but n CUs
   // (n/8 in every XCD) and the overlapped folds on a stream masked to those n CUs, so the two never share a CU's
   // issue slots, LDS or L1; created on first use (hipExtStreamCreateWithCUMask)
@@ -28,9 +30,12 @@ struct Workspace {
   // expansion
   DevBuf<u64> q_raw;      // query ct, raw 2x1
   DevBuf<u32> v;          // [2^g] 2x1 NTT cts
+  DevBuf<u32> v2;         // second copy: the fused expansion rounds read one and write the other
   DevBuf<u64> exp_raw;    // [active] automorphed raw cts
   DevBuf<u32> exp_dig;    // digit NTTs of one group
   DevBuf<u32> exp_ct1;    // NTT of row 1 of the automorphed cts
+  DevBuf<u64> exp_raw_r;  // the same three for the odd subtree (runs concurrently on stream2)
+  DevBuf<u32> exp_dig_r, exp_ct1_r;
   DevBuf<u64> qv;         // reoriented first-dimension query [N][dim0][2]
   DevBuf<u32> fold_mats;  // [nu_2][2 rows][ G - C | C ] (2 x 4 t_gsw NTT polys per GSW ct)
   DevBuf<u32> fold_mats_w;  // the same polynomials in wave layout (k_fold_wave), filled by run_folding_neg
@@ -65,7 +70,10 @@ struct Workspace {
   size_t plane_group() const;
 };
 
-void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan = nullptr);
+// tree: 0 = whole schedule, 1 = even subtree, 2 = round 0 + odd subtree; rounds [r_begin, g_rounds)
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan = nullptr,
+                               int tree = 0, size_t r_begin = 0);
+void join_right(Workspace& W);
 void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
 void run_folding_neg(Workspace& W);
 void run_mats_to_wave(Workspace& W, size_t levels);

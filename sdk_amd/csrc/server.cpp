@@ -95,8 +95,9 @@ void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
 // Expansion schedule (server.rs:19-121) restricted to the first-dimension rows [j0, j0 + nj): output ct c of round
 // r (index < 2^(r+1)) is an ancestor of leaf L iff L = c (mod 2^(r+1)); leaf 2j is row j (server.rs:566-568), the odd
 // leaves are the GSW selector bits and are always kept.  j0 = 0, nj = dim0 gives the reference's own schedule.
+// side: 0 = the whole schedule, 1 = only the even subtree (rounds >= 1, even i), 2 = round 0 and the odd subtree
 static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj, std::vector<int>& L,
-                                                const std::vector<char>* row_set = nullptr) {
+                                                const std::vector<char>* row_set = nullptr, int side = 0) {
   auto put = [&](const std::vector<int>& v) {
     size_t off = L.size();
     L.insert(L.end(), v.begin(), v.end());
@@ -128,12 +129,14 @@ static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj,
         for (int j = j0; j < j0 + nj; j++) need_even[((size_t)2 * j) % mod] = 1;
       }
     }
-    std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout, skip2;
+    std::vector<int> all_ct, all_row1, lpos, lout, rpos, rout, skip2, lct, rct;
     for (int half = 0; half < 2; half++)
       for (int i = 0; i < rp.num_in; i++) {  // both halves enumerate from 0 (server.rs:112-119)
         bool skip = (stop_round > 0 && r > stop_round && (i % 2) == 1) ||
                     (stop_round > 0 && r == stop_round && (i % 2) == 1 && (size_t)(i / 2) >= max_bits_right);
         const int ct = half * rp.num_in + i;
+        const bool even_tree = r != 0 && (i % 2) == 0;
+        if ((side == 1 && !even_tree) || (side == 2 && even_tree)) continue;
         if (skip) {
           if (half == 1 && !prune) skip2.push_back(rp.num_in + i);
           continue;
@@ -145,9 +148,11 @@ static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj,
         if (r != 0 && (i % 2) == 0) {
           lpos.push_back(pos);
           lout.push_back(ct * 2);
+          lct.push_back(ct);
         } else {
           rpos.push_back(pos);
           rout.push_back(ct * 2);
+          rct.push_back(ct);
         }
       }
     rp.n_all = (int)all_ct.size();
@@ -159,6 +164,8 @@ static std::vector<RoundPlan> build_round_plans(const Params& P, int j0, int nj,
     rp.left_out = put(lout);
     rp.right_pos = put(rpos);
     rp.right_out = put(rout);
+    rp.left_ct = put(lct);
+    rp.right_ct = put(rct);
     rp.skip2 = put(skip2);
     rp.n_skip2 = (int)skip2.size();
     rounds.push_back(rp);
@@ -175,6 +182,8 @@ const DeviceState::PrunedPlan& DeviceState::pruned_plan(const Params& P, int j0,
   pl->nj = nj;
   std::vector<int> L;
   pl->rounds = build_round_plans(P, j0, nj, L);
+  pl->rounds_even = build_round_plans(P, j0, nj, L, nullptr, 1);
+  pl->rounds_odd = build_round_plans(P, j0, nj, L, nullptr, 2);
   pl->lists.alloc(std::max<size_t>(L.size(), 1));
   if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
   pruned.push_back(std::move(pl));
@@ -187,6 +196,8 @@ std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P,
   pl->nj = -1;
   std::vector<int> L;
   pl->rounds = build_round_plans(P, 0, 0, L, &rows);
+  pl->rounds_even = build_round_plans(P, 0, 0, L, &rows, 1);
+  pl->rounds_odd = build_round_plans(P, 0, 0, L, &rows, 2);
   pl->lists.alloc(std::max<size_t>(L.size(), 1));
   if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
   return pl;
@@ -240,6 +251,8 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
   };
   if (P.expand_queries) {
     D->rounds = build_round_plans(P, 0, (int)P.dim0(), L);
+    D->rounds_even = build_round_plans(P, 0, (int)P.dim0(), L, nullptr, 1);
+    D->rounds_odd = build_round_plans(P, 0, (int)P.dim0(), L, nullptr, 2);
     for (const RoundPlan& rp : D->rounds) {
       D->max_all = std::max(D->max_all, (size_t)rp.n_all);
       D->max_left = std::max(D->max_left, (size_t)rp.n_left);
@@ -346,6 +359,8 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
   HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_round0, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_right, hipEventDisableTiming));
   ev_plane.resize(P.planes());
   for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -368,7 +383,7 @@ Workspace::~Workspace() {
   for (auto& e : ev_plane)
     if (e) (void)hipEventDestroy(e);
   if (ev_fold) (void)hipEventDestroy(ev_fold);
-  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1]})
+  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right})
     if (e) (void)hipEventDestroy(e);
   if (s_sweep) (void)hipStreamDestroy(s_sweep);
   if (s_fold) (void)hipStreamDestroy(s_fold);
@@ -408,10 +423,16 @@ void Workspace::ensure_expand() {
   const Params& p = *P;
   const size_t g = p.g();
   v.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);
+  if (p.db_dim_2 > 0) v2.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);  // k_expand_round ping-pongs v and v2
   exp_raw.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
   size_t dig = D->max_left * p.t_exp_left + D->max_right * p.t_exp_right;  // both groups of a round coexist
   exp_dig.ensure(std::max<size_t>(dig, 1) * 2 * POLY_LEN);
   exp_ct1.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
+  if (p.db_dim_2 > 0) {  // scratch of the odd subtree (its rounds run on stream2 beside the even subtree's)
+    exp_raw_r.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
+    exp_dig_r.ensure(std::max<size_t>(D->max_right * p.t_exp_right, 1) * 2 * POLY_LEN);
+    exp_ct1_r.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
+  }
   qv.ensure(POLY_LEN * p.dim0() * 2);
   const size_t nb = p.db_dim_2 * p.t_gsw;
   fold_mats.ensure(std::max<size_t>(p.db_dim_2, 1) * 2 * 4 * p.t_gsw * 2 * POLY_LEN);
@@ -456,15 +477,37 @@ void Workspace::ensure_finish() {
 
 // ---------------------------------------------------------------------------------- pipeline stages
 // server.rs:19-121; v[0] holds the NTT'd query ct.
-void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan) {
+static void on_stream(Workspace& W, hipStream_t s, const std::function<void()>& f) {
+  hipStream_t saved = W.stream;
+  W.stream = s;
+  try {
+    f();
+  } catch (...) {
+    W.stream = saved;
+    throw;
+  }
+  W.stream = saved;
+}
+
+void join_right(Workspace& W);
+
+void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan,
+                               int tree, size_t r_begin) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
   const int* L = plan ? plan->lists.p : D.lists.p;
-  const std::vector<RoundPlan>& rounds = plan ? plan->rounds : D.rounds;
+  const std::vector<RoundPlan>& rounds = tree == 1   ? (plan ? plan->rounds_even : D.rounds_even)
+                                         : tree == 2 ? (plan ? plan->rounds_odd : D.rounds_odd)
+                                                     : (plan ? plan->rounds : D.rounds);
+  // the odd subtree has its own scratch: it runs concurrently with the even subtree (run_begin)
+  u64* const exp_raw = tree == 2 ? W.exp_raw_r.p : W.exp_raw.p;
+  u32* const exp_dig = tree == 2 ? W.exp_dig_r.p : W.exp_dig.p;
+  u32* const exp_ct1 = tree == 2 ? W.exp_ct1_r.p : W.exp_ct1.p;
   const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
-  for (size_t r = 0; r < g_rounds; r++) {
+  for (size_t r = r_begin; r < g_rounds; r++) {
     const RoundPlan& rp = rounds[r];
+    if (rp.n_all == 0 && (tree != 0 || rp.n_skip2 == 0)) continue;  // (a subtree's skipped cts are never read again)
     // three launches per round:
     // (1) v[num_in + i] = neg1[r] * v[i] (server.rs:105-110) fused into ct = from_ntt(v_i); ct_auto = automorph(ct, t)
     InvDesc inv{};
@@ -475,7 +518,7 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
     inv.poly_stride = 2 * POLY_LEN;
     inv.crt_stride = POLY_LEN;
     inv.z_stride = 1;
-    inv.dst = W.exp_raw.p;
+    inv.dst = exp_raw;
     inv.n_polys = rp.n_all * 2;
     inv.automorph_t = rp.t_auto;
     inv.scal = D.neg1.p + r * 2 * POLY_LEN;
@@ -490,9 +533,9 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
       const int cnt = side == 0 ? rp.n_left : rp.n_right;
       const int t = side == 0 ? tl : tr;
       FwdDesc f{};
-      f.src = W.exp_raw.p;
+      f.src = exp_raw;
       f.src_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
-      f.dst = W.exp_dig.p + (side == 0 ? 0 : (size_t)rp.n_left * tl * 2 * POLY_LEN);
+      f.dst = exp_dig + (side == 0 ? 0 : (size_t)rp.n_left * tl * 2 * POLY_LEN);
       f.n_out = cnt * t;
       f.rdim = 1;
       f.cols = 1;
@@ -505,8 +548,8 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
     }
     {
       FwdDesc f1{};
-      f1.src = W.exp_raw.p;
-      f1.dst = W.exp_ct1.p;
+      f1.src = exp_raw;
+      f1.dst = exp_ct1;
       f1.n_out = rp.n_all;
       f1.rdim = 1;
       f1.cols = 1;
@@ -542,13 +585,52 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
       m.split_off = 0;
       m.out_batch_stride = 0;
       m.out_row_stride = 1;
-      m.extra = W.exp_ct1.p;
+      m.extra = exp_ct1;
       m.extra_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
       m.extra_row = 1;
       md[side] = m;
     }
     launch_mac2(D.T, md[0], md[1], s);
   }
+}
+
+// Rounds [r_begin, r_end) of one subtree (or of the whole schedule) with k_expand_round: round r reads buf[r & 1] and
+// writes buf[(r & 1) ^ 1].  Returns the buffer the last launched round wrote (buf[r_begin & 1] if none ran).
+static u32* run_expansion_fused(Workspace& W, const sp_pp& pp, size_t r_begin, size_t r_end, const DeviceState::PrunedPlan* plan,
+                                int tree, u32* const buf[2]) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  const int* L = plan ? plan->lists.p : D.lists.p;
+  const std::vector<RoundPlan>& rounds = tree == 1   ? (plan ? plan->rounds_even : D.rounds_even)
+                                         : tree == 2 ? (plan ? plan->rounds_odd : D.rounds_odd)
+                                                     : (plan ? plan->rounds : D.rounds);
+  const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
+  u32* last = buf[r_begin & 1];
+  for (size_t r = r_begin; r < r_end; r++) {
+    const RoundPlan& rp = rounds[r];
+    if (rp.n_all == 0) continue;
+    const bool use_right = pp.has_right && p.db_dim_2 > 0;
+    ExpandDesc d{};
+    d.src = buf[r & 1];
+    d.dst = buf[(r & 1) ^ 1];
+    // the group lists hold positions inside all_ct; the kernel wants the ciphertext itself = out poly index / 2
+    d.ct_idx[0] = L + rp.left_ct;
+    d.ct_idx[1] = L + rp.right_ct;
+    d.n[0] = rp.n_left;
+    d.n[1] = rp.n_right;
+    d.t[0] = tl;
+    d.t[1] = tr;
+    d.bits[0] = (int)p.bits_per(tl);
+    d.bits[1] = (int)p.bits_per(tr);
+    d.W[0] = pp.all_w.p + (pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
+    d.W[1] = pp.all_w.p + (use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
+    d.num_in = rp.num_in;
+    d.neg1 = D.neg1.p + r * 2 * POLY_LEN;
+    d.t_auto = rp.t_auto;
+    launch_expand_round(D.T, d, W.stream);
+    last = d.dst;
+  }
+  return last;
 }
 
 // server.rs:123-151 with idx_factor 1, idx_offset 0, reading the inputs v[2b+1] in place and writing
@@ -610,7 +692,7 @@ void run_folding_neg(Workspace& W) {
 void run_mats_to_wave(Workspace& W, size_t levels) {
   const Params& p = *W.P;
   W.mats_w_ready = false;
-  if (tunable("fold_variant", 3) != 5 || (p.t_gsw % 2) != 0 || !fused_fold_supported(p) || levels == 0) return;
+  if (tunable("fold_variant", 3) != 5 || !fused_fold_supported(p) || levels == 0) return;
   const size_t words = levels * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
   W.fold_mats_w.ensure(words);
   launch_mats_to_wave(W.fold_mats_w.p, W.fold_mats.p, words, W.stream);
@@ -675,6 +757,8 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   if (p.db_dim_2 == 0 && p.t_exp_left != p.t_exp_right) throw ArgError("nu_2 == 0 requires t_exp_left == t_exp_right (server.rs:573)");
   W.ensure_expand();
   hipStream_t s = W.stream;
+  join_right(W);  // a previous query of this workspace whose odd subtree nobody waited for
+  W.right_pending = false;
   // row 0 = Q - (rng.gen::<u64>() % Q) (client.rs:47-49), row 1 from the wire
   chacha20_keystream_u64(query, W.h_query, POLY_LEN);
   for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - (W.h_query[i] % p.modulus);
@@ -686,8 +770,51 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
   const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
   if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
-  run_coefficient_expansion(W, pp, g, plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr));
+  const DeviceState::PrunedPlan* pl = plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
+  if (p.db_dim_2 > 0 && g >= 2 && tunable("expand_split", 0)) {
+    // SPIRAL_EXPAND_SPLIT=1 (off): after round 0 the tree falls into the even subtree (-> v_reg, what the sweep waits
+    // for) and the odd subtree (-> the GSW bits, regev_to_gsw and G - C, what the FOLD waits for; 56 digits per
+    // ciphertext against 8: more than half of the transforms).  The odd side then runs on stream2, beside the even side
+    // and the first plane's sweep; consumers of fold_mats order themselves after ev_right (join_right).
+    // Measured (profiles/r02_expand_experiments.md): the even subtree is a chain of 27 launches whose length does not
+    // depend on how much work rides along, so taking the odd subtree out shortens it by 6 % at C2 and not at all at
+    // C1/P2, where the odd subtree then competes with the short sweep.  SPIRAL_EXPAND_FUSED=1 replaces the three
+    // launches of a round by k_expand_round (one workgroup per ciphertext): byte-identical, but a wave-per-transform
+    // NTT takes ~5.5 us, so a round costs 50 us instead of 30.
+    note_path(PATH_EXPAND_SPLIT);
+    if (tunable("expand_fused", 0) && pp.all_w.p) {
+      // one launch per round and subtree (expand.hip): v and v2 alternate as source and destination
+      u32* const buf[2] = {W.v.p, W.v2.p};
+      run_expansion_fused(W, pp, 0, 1, pl, 0, buf);
+      HIP_CHECK(hipEventRecord(W.ev_round0, s));
+      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_round0, 0));
+      on_stream(W, W.stream2, [&] {
+        const u32* v_odd = run_expansion_fused(W, pp, 1, g, pl, 2, buf);
+        run_regev_to_gsw(W, pp, v_odd, L + D.gsw_src_ct, L + D.gsw_src_poly);
+        run_folding_neg(W);
+      });
+      HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
+      W.right_pending = true;
+      const u32* v_even = run_expansion_fused(W, pp, 1, g, pl, 1, buf);
+      launch_reorient(W.qv.p, v_even, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+      return;
+    }
+    run_coefficient_expansion(W, pp, 1, pl, 0, 0);
+    HIP_CHECK(hipEventRecord(W.ev_round0, s));
+    HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_round0, 0));
+    on_stream(W, W.stream2, [&] {
+      run_coefficient_expansion(W, pp, g, pl, 2, 1);
+      run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+      run_folding_neg(W);
+    });
+    HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
+    W.right_pending = true;
+    run_coefficient_expansion(W, pp, g, pl, 1, 1);
+    launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+    return;
+  }
+  run_coefficient_expansion(W, pp, g, pl);
   if (p.db_dim_2 > 0) {
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
     run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
@@ -695,6 +822,11 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   } else {
     launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), s);  // server.rs:574-576
   }
+}
+
+// orders the current stream after the odd expansion subtree of this workspace's query (no-op when it was not split off)
+void join_right(Workspace& W) {
+  if (W.right_pending) HIP_CHECK(hipStreamWaitEvent(W.stream, W.ev_right, 0));
 }
 
 void run_sweep(Workspace& W, const sp_db& db) {
@@ -755,18 +887,6 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
     launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);
   else
     launch_sweep(W.D->T, d, W.stream);
-}
-
-static void on_stream(Workspace& W, hipStream_t s, const std::function<void()>& f) {
-  hipStream_t saved = W.stream;
-  W.stream = s;
-  try {
-    f();
-  } catch (...) {
-    W.stream = saved;
-    throw;
-  }
-  W.stream = saved;
 }
 
 void run_sweep_pipelined(Workspace& W, const sp_db& db) {
@@ -837,6 +957,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
   const int two_t = (int)(2 * p.t_gsw);
+  join_right(W);
   int cur = num_cts;
   int further = 0;
   while (((int)1 << further) < num_cts) further++;

@@ -79,6 +79,7 @@ struct RoundPlan {
   size_t left_pos = 0;    // position within the active list of each left-group ct
   size_t left_out = 0;    // poly index (ct*2) of each left-group ct
   size_t right_pos = 0, right_out = 0;
+  size_t left_ct = 0, right_ct = 0;  // ciphertext index of each left / right group member (k_expand_round)
   size_t skip2 = 0;       // second-half cts that are pruned (only scalar-multiplied), server.rs:40-47
   int n_skip2 = 0;
 };
@@ -91,12 +92,17 @@ struct DeviceState {
   DevBuf<u32> gadget_gsw;  // [2][2 t_gsw] polys
   DevBuf<int> lists;
   std::vector<RoundPlan> rounds;
+  // the same schedule split along the expansion tree: after round 0 the even-indexed ciphertexts (first-dimension
+  // query, server.rs:566-568) and the odd-indexed ones (GSW bits, server.rs:569-571) never meet again, so the two
+  // subtrees can run on different streams.  rounds_even[0] / rounds_odd[0] are empty / round 0 itself.
+  std::vector<RoundPlan> rounds_even, rounds_odd;
   size_t max_all = 0, max_left = 0, max_right = 0;
   // Expansion schedules pruned to the first-dimension rows [j0, j0 + nj) a row shard needs (the even "left" subtree
   // only computes the ancestors of those leaves; the GSW side is always complete).  Built on first use.
   struct PrunedPlan {
     int j0 = 0, nj = 0;
     std::vector<RoundPlan> rounds;  // offsets into `lists` below
+    std::vector<RoundPlan> rounds_even, rounds_odd;  // as in DeviceState
     DevBuf<int> lists;
   };
   std::vector<std::unique_ptr<PrunedPlan>> pruned;
@@ -139,6 +145,7 @@ struct sp_pp {
   int device = -1;
   // NTT-form matrices, device resident
   spiral::DevBuf<spiral::u32> all;  // wire order: v_packing[n], v_expansion_left[g], [v_expansion_right], v_conversion
+  spiral::DevBuf<spiral::u32> all_w;  // the same polynomials in wave layout (wave_ntt.hpp; k_expand_round's operands)
   size_t n_polys = 0;
   size_t off_packing = 0, off_left = 0, off_right = 0, off_conv = 0;  // poly offsets
   bool has_right = false;

@@ -904,3 +904,65 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     gpp = sp.PublicParameters.deserialize(p, pp)
     gdb = sp.Database(p).load(db)
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
+
+
+@pytest.mark.parametrize("mode", ["split", "split+fused"])
+@pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
+def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
+    """The optional expansion schedules (off by default, profiles/r02_expand_experiments.md): odd subtree + GSW side on
+    the second stream (SPIRAL_EXPAND_SPLIT) and one k_expand_round launch per round (SPIRAL_EXPAND_FUSED), over gadget
+    widths from 2 to 56 digits, 28-bit digits included; expand_query and the response must not change."""
+    cfg = _FUZZ[ci]
+    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1")
+    monkeypatch.setenv("SPIRAL_EXPAND_FUSED", "1" if mode == "split+fused" else "0")
+    o = oracle_mod.Params(cfg)
+    idx = (613 * (ci + 1)) % o.num_items
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(70 + ci)
+    q = cl.generate_query(idx, 170 + ci)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    sp.paths_taken()
+    v_reg, v_fold = sp.expand_query(p, gpp, q)
+    taken = sp.paths_taken()
+    assert "expand_split" in taken and ("expand_head_fused" in taken) == (mode == "split+fused"), taken
+    e_reg, e_fold = o.expand_query(pp, q)
+    assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
+    assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
+    # row shard: pruned even subtree through the same schedules
+    shard = sp.Database(p, shard=1, num_shards=2).load(db)
+    run = sp.QueryRun(p, gpp, q, db=shard)
+    run.sweep(shard)
+    full = sp.QueryRun(p, gpp, q, db=gdb)
+    full.sweep(gdb)
+    assert "expand_pruned" in sp.paths_taken()
+    run.free()
+    full.free()
+
+
+@pytest.mark.parametrize("ci", [0, 1, 2, 4, 5, 8, 9, 11, 13])
+def test_wave_fold_kernel_gadget_widths(sp, oracle_mod, monkeypatch, ci):
+    """k_fold_wave (SPIRAL_FOLD_VARIANT=5) on every tree level over odd and even t_gsw from 2 to 28 (byte, short and
+    word digit planes: 2..28-bit digits), against the oracle's response."""
+    cfg = _FUZZ[ci]
+    monkeypatch.setenv("SPIRAL_FOLD_VARIANT", "5")
+    monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", "1")
+    o = oracle_mod.Params(cfg)
+    idx = (331 * (ci + 1)) % o.num_items
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(90 + ci)
+    q = cl.generate_query(idx, 190 + ci)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    sp.paths_taken()
+    resp = sp.process_query(p, gpp, q, gdb)
+    # the kernel is used while two workgroups fit a CU: 34 KiB + 2 t (2048 ES + 256) bytes of LDS <= 80 KiB
+    es = 1 if o.get_bits_per(cfg["t_gsw"]) <= 8 else 2 if o.get_bits_per(cfg["t_gsw"]) <= 16 else 4
+    fits = 34816 + 2 * cfg["t_gsw"] * (2048 * es + 256) <= 80 * 1024
+    taken = sp.paths_taken()
+    assert ("fold_wave" in taken) == fits, (taken, es, fits)
+    assert resp == o.process_query(pp, q, db)
