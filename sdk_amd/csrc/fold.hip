@@ -501,7 +501,7 @@ void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s
 
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
-  const int variant = (int)tunable("fold_variant", 3);
+  const int variant = (int)tunable("fold_variant", FOLD_VARIANT_DEFAULT);
   if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)
     const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
     const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
@@ -517,7 +517,7 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
       return;
     }
   }
-  if (variant == 3 && (d.t % 2) == 0)
+  if ((variant == 3 || variant == 5) && (d.t % 2) == 0)
     hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 2 && (d.t % 2) == 0)
     hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);

@@ -163,6 +163,10 @@ struct FoldDesc {
 };
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
+// SPIRAL_FOLD_VARIANT: 5 = k_fold_wave (wave-per-transform NTT; used while two workgroups fit a CU's LDS, else falls
+// through), 3 / 2 = k_fold_fused2 (two transforms per pass, even t_gsw) with / without hoisted twiddles, 1 / 0 =
+// k_fold_fused.  profiles/r02_fold_batch_experiments.md has the measurements behind the default.
+constexpr long FOLD_VARIANT_DEFAULT = 5;
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
 
 // One round of coefficient_expansion, one workgroup per ciphertext (expand.hip).  Group 0 / 1 = the "left" / "right"

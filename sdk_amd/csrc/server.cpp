@@ -692,7 +692,7 @@ void run_folding_neg(Workspace& W) {
 void run_mats_to_wave(Workspace& W, size_t levels) {
   const Params& p = *W.P;
   W.mats_w_ready = false;
-  if (tunable("fold_variant", 3) != 5 || !fused_fold_supported(p) || levels == 0) return;
+  if (tunable("fold_variant", FOLD_VARIANT_DEFAULT) != 5 || !fused_fold_supported(p) || levels == 0) return;
   const size_t words = levels * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
   W.fold_mats_w.ensure(words);
   launch_mats_to_wave(W.fold_mats_w.p, W.fold_mats.p, words, W.stream);

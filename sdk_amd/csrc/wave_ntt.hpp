@@ -63,6 +63,55 @@ __device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, 
 // ------------------------------------------------------------------------------------------------------------------
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 
+// B independent Cooley-Tukey butterflies (ct_bfly) issued phase by phase: left to itself the compiler emits one
+// butterfly after the other, each a chain of dependent multiplies (v_mul_hi -> v_mul_lo -> v_sub -> v_add) that a wave
+// can only issue at the dependent-operation latency; phase-wise every instruction's operands are B issue slots old
+template <int B>
+__device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&w)[B], const u32 (&wp)[B], u32 q, u32 q2) {
+  u32 qt[B], lo[B], t[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) qt[b] = __umulhi(y[b], wp[b]);
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) lo[b] = w[b] * y[b];
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) t[b] = x[b] - q2;
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) qt[b] = qt[b] * q;
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) x[b] = x[b] < t[b] ? x[b] : t[b];  // x - (x >= 2q ? 2q : 0)
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) lo[b] = lo[b] - qt[b];
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) y[b] = x[b] + q2;
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) {
+    y[b] = y[b] - lo[b];
+    x[b] = x[b] + lo[b];
+  }
+  SP_SB();
+}
+// butterflies (v[ia], v[ib]) with twiddles (w, wp), ia / ib / twiddle index given by the functors, in batches of 8
+#define SP_BFLY_STAGE(COUNT, IA, IB, W, WP)                                                      \
+  _Pragma("unroll") for (int b0_ = 0; b0_ < (COUNT); b0_ += 8) {                                 \
+    u32 xa_[8], ya_[8], wa_[8], pa_[8];                                                          \
+    _Pragma("unroll") for (int b_ = 0; b_ < 8; b_++) {                                           \
+      const int j_ = b0_ + b_;                                                                   \
+      xa_[b_] = v[IA(j_)]; ya_[b_] = v[IB(j_)]; wa_[b_] = W(j_); pa_[b_] = WP(j_);               \
+    }                                                                                            \
+    ct_bfly_batch<8>(xa_, ya_, wa_, pa_, q, q2);                                                 \
+    _Pragma("unroll") for (int b_ = 0; b_ < 8; b_++) {                                           \
+      const int j_ = b0_ + b_;                                                                   \
+      v[IA(j_)] = xa_[b_]; v[IB(j_)] = ya_[b_];                                                  \
+    }                                                                                            \
+  }
+
 struct WaveScalarTw {  // table entries 0..15 of [w | w'] (stages t = 1024 .. 128): wave-uniform, live in SGPRs
   u32 w[16], wp[16];
 };
@@ -98,15 +147,17 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
   }
   SP_SB();
 #pragma unroll
-  for (int mm = 0; mm < 4; mm++) {
+  for (int mm = 0; mm < 4; mm++) {  // butterfly j of the stage: registers k, k + Tk with k = (j / Tk) * 2 Tk + j % Tk
     const int Tk = 16 >> mm;
-#pragma unroll
-    for (int k = 0; k < 32; k++) {
-      if (((k / Tk) & 1) == 0) {
-        const int ti = (1 << mm) + k / (2 * Tk);
-        ct_bfly(v[k], v[k + Tk], s.w[ti], s.wp[ti], q, q2);
-      }
-    }
+#define SP_IA(j) (((j) / Tk) * 2 * Tk + (j) % Tk)
+#define SP_IB(j) (SP_IA(j) + Tk)
+#define SP_W(j) s.w[(1 << mm) + (j) / Tk]
+#define SP_WP(j) s.wp[(1 << mm) + (j) / Tk]
+    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   }
   // stage t = 32: lanes 0-31 use entry 32 + 2p, lanes 32-63 entry 33 + 2p -- read per lane from the LDS copy, four
   // register pairs ahead
@@ -118,8 +169,15 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
     gp[0][i] = lw[N + 2 * i];
   }
   SP_SB();
-#pragma unroll
-  for (int k = 0; k < 32; k += 2) ct_bfly(v[k], v[k + 1], w5[k / 2], p5[k / 2], q, q2);
+#define SP_IA(j) (2 * (j))
+#define SP_IB(j) (2 * (j) + 1)
+#define SP_W(j) w5[j]
+#define SP_WP(j) p5[j]
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   const int hl = wave_h(lane);
   const bool lo = lane < 32;
   const u32* rd = buf + 36 * (lane & 31);
@@ -138,14 +196,22 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
       p16 = ltw[N + 64 + lane];
     }
     SP_SB();
+    {
+      u32 a[4], b[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-      const int p = 4 * grp + i, pp = p & 7;
-      const auto r = __builtin_amdgcn_permlane32_swap(v[2 * p], v[2 * p + 1], false, false);
-      u32 a = r[0], b = r[1];  // lanes 0-31: (x, y) of register 2p; lanes 32-63: (x, y) of register 2p+1
-      ct_bfly(a, b, gw[grp][i], gp[grp][i], q, q2);
-      buf[144 * pp + hl] = a;       // element 128pp + (lane < 32 ? lane : lane + 32) of this half, at n + 4 (n >> 5)
-      buf[144 * pp + 36 + hl] = b;  // the element 32 above it
+      for (int i = 0; i < 4; i++) {
+        const int p = 4 * grp + i;
+        const auto r = __builtin_amdgcn_permlane32_swap(v[2 * p], v[2 * p + 1], false, false);
+        a[i] = r[0];  // lanes 0-31: (x, y) of register 2p; lanes 32-63: (x, y) of register 2p+1
+        b[i] = r[1];
+      }
+      ct_bfly_batch<4>(a, b, gw[grp], gp[grp], q, q2);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int pp = (4 * grp + i) & 7;
+        buf[144 * pp + hl] = a[i];       // element 128pp + (lane < 32 ? lane : lane + 32) of this half, at n + 4 (n >> 5)
+        buf[144 * pp + 36 + hl] = b[i];  // the element 32 above it
+      }
     }
     if (grp & 1) {
       // half (grp >> 1) is complete: lanes 0-31 (first half) / 32-63 (second) pick up their 32 values.  The reads of
@@ -171,17 +237,28 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
   const u32x2w_t w8 = *reinterpret_cast<const u32x2w_t*>(ltw + 128 + 2 * lane);
   const u32x2w_t p8 = *reinterpret_cast<const u32x2w_t*>(ltw + N + 128 + 2 * lane);
   SP_SB();
-#pragma unroll
-  for (int k = 0; k < 16; k++) ct_bfly(v[k], v[k + 16], w16, p16, q, q2);
+#define SP_IA(j) (j)
+#define SP_IB(j) ((j) + 16)
+#define SP_W(j) w16
+#define SP_WP(j) p16
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   const u32x4w_t w4 = *reinterpret_cast<const u32x4w_t*>(ltw + 256 + 4 * lane);
   const u32x4w_t p4 = *reinterpret_cast<const u32x4w_t*>(ltw + N + 256 + 4 * lane);
   hk.before_t4();
   SP_SB();
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    ct_bfly(v[k], v[k + 8], w8.x, p8.x, q, q2);
-    ct_bfly(v[16 + k], v[24 + k], w8.y, p8.y, q, q2);
-  }
+#define SP_IA(j) (((j) >> 3) * 16 + ((j) & 7))
+#define SP_IB(j) (SP_IA(j) + 8)
+#define SP_W(j) ((j) < 8 ? w8.x : w8.y)
+#define SP_WP(j) ((j) < 8 ? p8.x : p8.y)
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   u32x4w_t w2[2], p2[2];
   {
     const int ph = 512 + 8 * lane + 4 * ((lane >> 3) & 1);
@@ -191,10 +268,15 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
   SP_SB();
   {
     const u32 ww[4] = {w4.x, w4.y, w4.z, w4.w}, pp[4] = {p4.x, p4.y, p4.z, p4.w};
-#pragma unroll
-    for (int g = 0; g < 4; g++)
-#pragma unroll
-      for (int k = 0; k < 4; k++) ct_bfly(v[8 * g + k], v[8 * g + 4 + k], ww[g], pp[g], q, q2);
+#define SP_IA(j) (((j) >> 2) * 8 + ((j) & 3))
+#define SP_IB(j) (SP_IA(j) + 4)
+#define SP_W(j) ww[(j) >> 2]
+#define SP_WP(j) pp[(j) >> 2]
+    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   }
   u32x4w_t w1[4], p1[4];
 #pragma unroll
@@ -211,12 +293,15 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
     }
     SP_SB();
     const u32 ww[4] = {w2[hh].x, w2[hh].y, w2[hh].z, w2[hh].w}, pp[4] = {p2[hh].x, p2[hh].y, p2[hh].z, p2[hh].w};
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-      const int k0 = 16 * hh + 4 * g;
-      ct_bfly(v[k0], v[k0 + 2], ww[g], pp[g], q, q2);
-      ct_bfly(v[k0 + 1], v[k0 + 3], ww[g], pp[g], q, q2);
-    }
+#define SP_IA(j) (16 * hh + ((j) >> 1) * 4 + ((j) & 1))
+#define SP_IB(j) (SP_IA(j) + 2)
+#define SP_W(j) ww[(j) >> 1]
+#define SP_WP(j) pp[(j) >> 1]
+    SP_BFLY_STAGE(8, SP_IA, SP_IB, SP_W, SP_WP)
+#undef SP_IA
+#undef SP_IB
+#undef SP_W
+#undef SP_WP
   }
 #pragma unroll
   for (int qq = 0; qq < 4; qq++) {  // t = 1: sixteen twiddles, four (rotated) b128
@@ -227,8 +312,20 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
     }
     SP_SB();
     const u32 ww[4] = {w1[qq].x, w1[qq].y, w1[qq].z, w1[qq].w}, pp[4] = {p1[qq].x, p1[qq].y, p1[qq].z, p1[qq].w};
+    {
+      u32 a[4], b[4];
 #pragma unroll
-    for (int g = 0; g < 4; g++) ct_bfly(v[8 * qq + 2 * g], v[8 * qq + 2 * g + 1], ww[g], pp[g], q, q2);
+      for (int g = 0; g < 4; g++) {
+        a[g] = v[8 * qq + 2 * g];
+        b[g] = v[8 * qq + 2 * g + 1];
+      }
+      ct_bfly_batch<4>(a, b, ww, pp, q, q2);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        v[8 * qq + 2 * g] = a[g];
+        v[8 * qq + 2 * g + 1] = b[g];
+      }
+    }
     if (CANON) {
 #pragma unroll
       for (int k = 8 * qq; k < 8 * qq + 8; k++) {  // ntt.rs:107-111
