@@ -857,21 +857,44 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     g_last_error = "out_stride smaller than response_bytes";
     return SP_E_ARG;
   }
-  int group_max = SWEEP_BATCH_MAX;
-  group_max = std::max(1, std::min(SWEEP_BATCH_MAX, (int)tunable("batch_group", SWEEP_BATCH_MAX)));
-  for (int g0 = 0; g0 < batch; g0 += group_max) {
-    const int B = std::min(group_max, batch - g0);
-    std::vector<sp_query_t*> qs;
-    int rc = guarded([&] {
-      check_device(db->device);
+  // Groups of up to SWEEP_BATCH_MAX queries share one database pass.  Nothing waits for a group's folds before the next
+  // group's expansions and pass are queued (the passes themselves run one after the other: both are HBM-bound), and at
+  // most two groups hold workspaces at a time.  Measured at C2 (profiles/r02_fold_batch_experiments.md): the overlap
+  // buys nothing yet -- 16 queries take 2 x the time of 8, and 8 as 2 x 4 are slower (195 vs 236 queries/s) -- because
+  // the batched sweep's workgroups fill every CU's register file, so a fold wave only starts when the pass drains.
+  int group_max = (int)tunable("batch_group", SWEEP_BATCH_MAX);
+  if (group_max <= 0) group_max = SWEEP_BATCH_MAX;
+  group_max = std::max(1, std::min(SWEEP_BATCH_MAX, group_max));
+  std::vector<sp_query_t*> all_qs;   // queries in flight (at most two groups: bounds the workspaces held)
+  size_t drained = 0;                // responses copied out so far
+  hipEvent_t prev_pass = nullptr;
+  auto drain = [&](size_t count) {   // oldest `count` queries: wait, copy the response out, give the workspace back
+    for (size_t i = 0; i < count; i++) {
+      Workspace& W = *all_qs[i]->ws;
+      HIP_CHECK(hipStreamSynchronize(W.stream));
+      memcpy(out + (drained + i) * out_stride, W.h_response, p.response_bytes());
+      *out_len = p.response_bytes();
+    }
+    for (size_t i = 0; i < count; i++) sp_query_free(all_qs[i]);
+    all_qs.erase(all_qs.begin(), all_qs.begin() + count);
+    drained += count;
+  };
+  size_t prev_group = 0;
+  int rc = guarded([&] {
+    check_device(db->device);
+    for (int g0 = 0; g0 < batch; g0 += group_max) {
+      const int B = std::min(group_max, batch - g0);
+      if (all_qs.size() > prev_group) drain(all_qs.size() - prev_group);  // keep only the previous group in flight
       // 1. expand every query of the group on its own stream
+      const size_t first = all_qs.size();
       for (int i = 0; i < B; i++) {
         sp_query_t* q = sp_query_begin(h, pps[g0 + i], queries[g0 + i], query_lens[g0 + i]);
         if (!q) throw ArgError(g_last_error);
-        qs.push_back(q);
+        all_qs.push_back(q);
         q->ws->ensure_sweep();
       }
-      // 2. one database pass for the whole group, on the first query's stream
+      sp_query_t* const* qs = all_qs.data() + first;
+      // 2. one database pass for the whole group, on the first query's stream, after the previous group's pass
       Workspace& W0 = *qs[0]->ws;
       SweepBatchDesc d{};
       d.db = db->words.p;
@@ -886,6 +909,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         d.out[i] = qs[i]->ws->sweep_out.p;
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(W0.stream, qs[i]->ws->ev[1], 0));
       }
+      if (prev_pass) HIP_CHECK(hipStreamWaitEvent(W0.stream, prev_pass, 0));
       // SPIRAL_BATCH_PIPELINE=1 (off by default): the pass runs one (instance, trial) plane per launch and every query
       // folds plane p on its second stream while plane p+1 is swept -- the single-query pipeline with B folds per
       // plane.  Measured at C2, B = 8: 199 vs 198-227 queries/s for the one-launch pass -- the batched sweep's 188
@@ -909,6 +933,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         launch_sweep_batch(W0.D->T, d, W0.stream);
       }
       HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
+      prev_pass = W0.ev[2];
       // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
       for (int i = 0; i < B; i++) {
         Workspace& W = *qs[i]->ws;
@@ -918,17 +943,15 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         }
         run_finish(W, *qs[i]->pp, false);
       }
-      for (int i = 0; i < B; i++) {
-        Workspace& W = *qs[i]->ws;
-        HIP_CHECK(hipStreamSynchronize(W.stream));
-        memcpy(out + (size_t)(g0 + i) * out_stride, W.h_response, p.response_bytes());
-        *out_len = p.response_bytes();
-      }
-    });
-    for (auto* q : qs) sp_query_free(q);
-    if (rc != SP_OK) return rc;
+      prev_group = (size_t)B;
+    }
+    drain(all_qs.size());
+  });
+  if (rc != SP_OK) {  // let whatever was queued drain before the workspaces go back to the pool
+    for (auto* q : all_qs) (void)hipStreamSynchronize(q->ws->stream);
   }
-  return SP_OK;
+  for (auto* q : all_qs) sp_query_free(q);
+  return rc;
 }
 
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch) {
