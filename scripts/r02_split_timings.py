@@ -18,7 +18,7 @@ for name in os.environ.get("CFGS", "c1,p2,c2").split(","):
     qs = [bench.synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
     db = sp.Database(p).fill_synthetic(bench.SEED)
     for split in [int(x) for x in os.environ.get("SPLITS", "0,1,0,1").split(",")]:
-        setv(expand_split=split)
+        setv(expand_split=1 if split else 0, expand_fused=1 if split >= 2 else 0)   # 2: + k_expand_round_teams
         stage = np.zeros(4)
         n = 12
         for i in range(3 + n):

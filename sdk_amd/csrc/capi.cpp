@@ -542,10 +542,6 @@ sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len
     pp->all.alloc(off * 2 * POLY_LEN);
     FwdDesc f{d_raw.p, nullptr, pp->all.p, (int)off, 1, 1, 1, 64, 1, 0, 1};  // to_ntt_alloc (client.rs:244-247)
     launch_ntt_fwd(D.T, f, 0);
-    if (p.expand_queries) {
-      pp->all_w.alloc(off * 2 * POLY_LEN);
-      launch_mats_to_wave(pp->all_w.p, pp->all.p, off * 2 * POLY_LEN, 0);
-    }
     // [W_0 | W_1 | ...] for pack (server.rs:450-463)
     const size_t n = p.n, tc = p.t_conv;
     pp->pack_cat.alloc((n + 1) * n * tc * 2 * POLY_LEN);

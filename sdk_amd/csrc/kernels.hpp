@@ -177,7 +177,7 @@ struct ExpandDesc {
   const int* ct_idx[2];  // ciphertext indices of the group
   int n[2];
   int t[2], bits[2];
-  const u32* W[2];       // 2 x t key-switching matrix of this round in wave layout (sp_pp::all_w)
+  const u32* W[2];       // 2 x t key-switching matrix of this round (polynomial row * t + k of sp_pp::all)
   int num_in;            // ciphertexts >= num_in are first formed as neg1 * v[ct - num_in]
   const u32* neg1;       // [crt][N] of this round
   int t_auto;

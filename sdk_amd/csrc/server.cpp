@@ -622,8 +622,9 @@ static u32* run_expansion_fused(Workspace& W, const sp_pp& pp, size_t r_begin, s
     d.t[1] = tr;
     d.bits[0] = (int)p.bits_per(tl);
     d.bits[1] = (int)p.bits_per(tr);
-    d.W[0] = pp.all_w.p + (pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
-    d.W[1] = pp.all_w.p + (use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
+    const u32* wbase = pp.all.p;
+    d.W[0] = wbase + (pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
+    d.W[1] = wbase + (use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
     d.num_in = rp.num_in;
     d.neg1 = D.neg1.p + r * 2 * POLY_LEN;
     d.t_auto = rp.t_auto;
@@ -780,10 +781,10 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
     // Measured (profiles/r02_expand_experiments.md): the even subtree is a chain of 27 launches whose length does not
     // depend on how much work rides along, so taking the odd subtree out shortens it by 6 % at C2 and not at all at
     // C1/P2, where the odd subtree then competes with the short sweep.  SPIRAL_EXPAND_FUSED=1 replaces the three
-    // launches of a round by k_expand_round (one workgroup per ciphertext): byte-identical, but a wave-per-transform
-    // NTT takes ~5.5 us, so a round costs 50 us instead of 30.
+    // launches of a round by k_expand_round_teams (one workgroup per ciphertext): byte-identical, but one CU cannot
+    // issue a ciphertext's 22 transforms faster than three launches spread over 22 CUs (32 us against 28 per round).
     note_path(PATH_EXPAND_SPLIT);
-    if (tunable("expand_fused", 0) && pp.all_w.p) {
+    if (tunable("expand_fused", 0)) {
       // one launch per round and subtree (expand.hip): v and v2 alternate as source and destination
       u32* const buf[2] = {W.v.p, W.v2.p};
       run_expansion_fused(W, pp, 0, 1, pl, 0, buf);

@@ -145,7 +145,6 @@ struct sp_pp {
   int device = -1;
   // NTT-form matrices, device resident
   spiral::DevBuf<spiral::u32> all;  // wire order: v_packing[n], v_expansion_left[g], [v_expansion_right], v_conversion
-  spiral::DevBuf<spiral::u32> all_w;  // the same polynomials in wave layout (wave_ntt.hpp; k_expand_round's operands)
   size_t n_polys = 0;
   size_t off_packing = 0, off_left = 0, off_right = 0, off_conv = 0;  // poly offsets
   bool has_right = false;

@@ -910,7 +910,7 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
 @pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
 def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
     """The optional expansion schedules (off by default, profiles/r02_expand_experiments.md): odd subtree + GSW side on
-    the second stream (SPIRAL_EXPAND_SPLIT) and one k_expand_round launch per round (SPIRAL_EXPAND_FUSED), over gadget
+    the second stream (SPIRAL_EXPAND_SPLIT) and one k_expand_round_teams launch per round (SPIRAL_EXPAND_FUSED), over gadget
     widths from 2 to 56 digits, 28-bit digits included; expand_query and the response must not change."""
     cfg = _FUZZ[ci]
     monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1")
@@ -927,7 +927,7 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     sp.paths_taken()
     v_reg, v_fold = sp.expand_query(p, gpp, q)
     taken = sp.paths_taken()
-    assert "expand_split" in taken and ("expand_head_fused" in taken) == (mode == "split+fused"), taken
+    assert "expand_split" in taken and ("expand_head_fused" in taken) == (mode != "split"), taken
     e_reg, e_fold = o.expand_query(pp, q)
     assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
