@@ -345,14 +345,17 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
     // windows of whole row pairs: the rows' items are contiguous in the file
     const size_t row_bytes = p.num_per() * p.db_item_size;
     const int npairs_total = (d->nj + 1) / 2;
-    const size_t max_win = (size_t)512 << 20;
+    const size_t max_win = (size_t)std::max<long>(1, tunable("db_load_window", (long)512 << 20));  // bytes of raw items per upload
     const int pairs_per_win = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs_total, max_win / (2 * row_bytes)));
-    DevBuf<uint8_t> win((size_t)pairs_per_win * 2 * row_bytes);
+    // + one chunk: when db_item_size is not a multiple of the chunk count the last chunk of an item reads
+    // bytes_per_chunk bytes all the same, i.e. into the next item (load_item_from_seek, server.rs:300-309) -- also
+    // for the last item of a window
+    DevBuf<uint8_t> win((size_t)pairs_per_win * 2 * row_bytes + bpc);
     for (int jp = 0; jp < npairs_total; jp += pairs_per_win) {
       const int cnt = std::min(pairs_per_win, npairs_total - jp);
       const size_t item0 = (size_t)(d->j0 + 2 * jp) * p.num_per();
       const size_t off = item0 * p.db_item_size;
-      size_t want = (size_t)cnt * 2 * row_bytes;
+      size_t want = (size_t)cnt * 2 * row_bytes + bpc;
       size_t have = off < file_len ? std::min(want, file_len - off) : 0;
       if (have) HIP_CHECK(hipMemcpy(win.p, file + off, have, hipMemcpyHostToDevice));
       DbEncodeDesc e{};

@@ -401,6 +401,24 @@ def test_db_preprocessing_on_gpu(sp, oracle_mod, cfg, short):
     assert (db2.read_ref(3, 5, o.num_per - 1, 0, o.dim0 // 2) == exp[3, 5, o.num_per - 1, o.dim0 // 2:]).all()
 
 
+def test_db_preprocessing_item_spill_across_windows(sp, oracle_mod, monkeypatch):
+    """db_item_size not a multiple of the chunk count: the last chunk of an item still reads bytes_per_chunk bytes, i.e.
+    the first bytes of the NEXT item (load_item_from_seek, server.rs:300-309).  The upload windows carry one chunk of
+    tail so that this also holds for the last item of a window (here: every second row pair starts a new window)."""
+    cfg = dict(FAST, nu_1=4, nu_2=1, db_item_size=1001)
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    monkeypatch.setenv("SPIRAL_DB_LOAD_WINDOW", str(2 * o.num_per * o.db_item_size))
+    rng = np.random.default_rng(5)
+    blob = rng.integers(1, 256, o.num_items * o.db_item_size, dtype=np.uint8).tobytes()
+    exp = o.load_db_from_bytes(blob).reshape(4, 2048, o.num_per, o.dim0)
+    db = sp.Database(p).load_items(blob)
+    for pl in range(4):
+        for z in (0, 500, 501, 2047):
+            for ii in range(o.num_per):
+                assert (db.read_ref(pl, z, ii, 0, o.dim0) == exp[pl, z, ii]).all(), (pl, z, ii)
+
+
 @pytest.mark.parametrize("cfg", [dict(FAST, db_item_size=256), dict(FAST, nu_1=2, nu_2=7, t_gsw=2, db_item_size=600)],
                          ids=["narrow", "packed"])
 def test_db_update_item_sparse_bucket(sp, oracle_mod, cfg):
