@@ -63,10 +63,15 @@ __device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, 
 // ------------------------------------------------------------------------------------------------------------------
 #define SP_SB() __builtin_amdgcn_sched_barrier(0)
 
-// B independent Cooley-Tukey butterflies (ct_bfly) issued phase by phase: left to itself the compiler emits one
-// butterfly after the other, each a chain of dependent multiplies (v_mul_hi -> v_mul_lo -> v_sub -> v_add) that a wave
-// can only issue at the dependent-operation latency; phase-wise every instruction's operands are B issue slots old
-template <int B>
+// B independent Cooley-Tukey butterflies issued phase by phase: left to itself the compiler emits one butterfly after
+// the other, each a chain of dependent multiplies (v_mul_hi -> v_mul_lo -> v_sub -> v_add) that a wave can only issue at
+// the dependent-operation latency; phase-wise every instruction's operands are B issue slots old.
+// LAZY range reduction: the Shoup product w y - floor(w' y / 2^32) q lies in [0, 2q) for ANY y < 2^32, so only the
+// operand that is added (x) has to be kept small enough for x + 2q not to wrap -- and with q < 2^28 a 32-bit word holds
+// 16q.  Both outputs are < x + 2q: values grow by 2q per stage.  Instead of the reference's conditional subtraction of
+// 2q in every butterfly (ntt.rs:92-103; two of nine instructions) x is reduced by 8q in two of the eleven stages only
+// (CORR; see wntt_fwd for the bounds).  The residues mod q are the same, so every canonical result is too.
+template <int B, bool CORR>
 __device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&w)[B], const u32 (&wp)[B], u32 q, u32 q2) {
   u32 qt[B], lo[B], t[B];
 #pragma unroll
@@ -75,15 +80,19 @@ __device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u3
 #pragma unroll
   for (int b = 0; b < B; b++) lo[b] = w[b] * y[b];
   SP_SB();
+  if (CORR) {
 #pragma unroll
-  for (int b = 0; b < B; b++) t[b] = x[b] - q2;
-  SP_SB();
+    for (int b = 0; b < B; b++) t[b] = x[b] - 4 * q2;
+    SP_SB();
+  }
 #pragma unroll
   for (int b = 0; b < B; b++) qt[b] = qt[b] * q;
   SP_SB();
+  if (CORR) {
 #pragma unroll
-  for (int b = 0; b < B; b++) x[b] = x[b] < t[b] ? x[b] : t[b];  // x - (x >= 2q ? 2q : 0)
-  SP_SB();
+    for (int b = 0; b < B; b++) x[b] = x[b] < t[b] ? x[b] : t[b];  // x - (x >= 8q ? 8q : 0)
+    SP_SB();
+  }
 #pragma unroll
   for (int b = 0; b < B; b++) lo[b] = lo[b] - qt[b];
   SP_SB();
@@ -98,14 +107,14 @@ __device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u3
   SP_SB();
 }
 // butterflies (v[ia], v[ib]) with twiddles (w, wp), ia / ib / twiddle index given by the functors, in batches of 8
-#define SP_BFLY_STAGE(COUNT, IA, IB, W, WP)                                                      \
+#define SP_BFLY_STAGE(COUNT, IA, IB, W, WP, CORR)                                                \
   _Pragma("unroll") for (int b0_ = 0; b0_ < (COUNT); b0_ += 8) {                                 \
     u32 xa_[8], ya_[8], wa_[8], pa_[8];                                                          \
     _Pragma("unroll") for (int b_ = 0; b_ < 8; b_++) {                                           \
       const int j_ = b0_ + b_;                                                                   \
       xa_[b_] = v[IA(j_)]; ya_[b_] = v[IB(j_)]; wa_[b_] = W(j_); pa_[b_] = WP(j_);               \
     }                                                                                            \
-    ct_bfly_batch<8>(xa_, ya_, wa_, pa_, q, q2);                                                 \
+    ct_bfly_batch<8, CORR>(xa_, ya_, wa_, pa_, q, q2);                                           \
     _Pragma("unroll") for (int b_ = 0; b_ < 8; b_++) {                                           \
       const int j_ = b0_ + b_;                                                                   \
       v[IA(j_)] = xa_[b_]; v[IB(j_)] = ya_[b_];                                                  \
@@ -130,8 +139,10 @@ struct WaveNoHooks {
 };
 
 // ------------------------------------------------------------------------------------------------------------------
-// forward: v[k] = x[64 k + lane] (values < q)  ->  v[k] = X[32 lane + k] (the reference's output order); canonical if
-// CANON, else only < 4q (enough for a multiply-accumulate that is reduced afterwards)
+// forward: v[k] = x[64 k + lane] (values < 2q)  ->  v[k] = X[32 lane + k] (the reference's output order); canonical if
+// CANON, else only < 12q < 2^32 (enough for a multiply-accumulate that is reduced afterwards).
+// Bounds of the lazy reduction (ct_bfly_batch): < 2q in; stages 1-6 add 2q each: < 14q; stage 7 (t = 16) reduces x by
+// 8q: < 10q out; stages 8, 9: < 14q; stage 10 (t = 2) reduces again: < 10q; stage 11: < 12q.  x + 2q < 16q < 2^32.
 // tw: global tables [w | w'] of this modulus (uniform pointer), s: their first 16 entries (wntt_scalar_tw, issued by the
 // caller as early as it can); ltw: LDS copy (wtw_stage); buf: this wave's transpose buffer
 // ------------------------------------------------------------------------------------------------------------------
@@ -153,7 +164,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) (SP_IA(j) + Tk)
 #define SP_W(j) s.w[(1 << mm) + (j) / Tk]
 #define SP_WP(j) s.wp[(1 << mm) + (j) / Tk]
-    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP, false)
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -173,7 +184,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) (2 * (j) + 1)
 #define SP_W(j) w5[j]
 #define SP_WP(j) p5[j]
-  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP, false)
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -205,7 +216,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
         a[i] = r[0];  // lanes 0-31: (x, y) of register 2p; lanes 32-63: (x, y) of register 2p+1
         b[i] = r[1];
       }
-      ct_bfly_batch<4>(a, b, gw[grp], gp[grp], q, q2);
+      ct_bfly_batch<4, false>(a, b, gw[grp], gp[grp], q, q2);
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         const int pp = (4 * grp + i) & 7;
@@ -241,7 +252,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) ((j) + 16)
 #define SP_W(j) w16
 #define SP_WP(j) p16
-  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP, true)   // stage 7: < 14q in, < 10q out
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -254,7 +265,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) (SP_IA(j) + 8)
 #define SP_W(j) ((j) < 8 ? w8.x : w8.y)
 #define SP_WP(j) ((j) < 8 ? p8.x : p8.y)
-  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+  SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP, false)
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -272,7 +283,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) (SP_IA(j) + 4)
 #define SP_W(j) ww[(j) >> 2]
 #define SP_WP(j) pp[(j) >> 2]
-    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP)
+    SP_BFLY_STAGE(16, SP_IA, SP_IB, SP_W, SP_WP, false)
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -297,7 +308,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 #define SP_IB(j) (SP_IA(j) + 2)
 #define SP_W(j) ww[(j) >> 1]
 #define SP_WP(j) pp[(j) >> 1]
-    SP_BFLY_STAGE(8, SP_IA, SP_IB, SP_W, SP_WP)
+    SP_BFLY_STAGE(8, SP_IA, SP_IB, SP_W, SP_WP, true)   // stage 10: < 14q in, < 10q out
 #undef SP_IA
 #undef SP_IB
 #undef SP_W
@@ -319,7 +330,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
         a[g] = v[8 * qq + 2 * g];
         b[g] = v[8 * qq + 2 * g + 1];
       }
-      ct_bfly_batch<4>(a, b, ww, pp, q, q2);
+      ct_bfly_batch<4, false>(a, b, ww, pp, q, q2);
 #pragma unroll
       for (int g = 0; g < 4; g++) {
         v[8 * qq + 2 * g] = a[g];
@@ -328,8 +339,10 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
     }
     if (CANON) {
 #pragma unroll
-      for (int k = 8 * qq; k < 8 * qq + 8; k++) {  // ntt.rs:107-111
+      for (int k = 8 * qq; k < 8 * qq + 8; k++) {  // ntt.rs:107-111, from < 12q
         u32 x = v[k];
+        x -= (x >= 4 * q2 ? 4 * q2 : 0u);
+        x -= (x >= 2 * q2 ? 2 * q2 : 0u);
         x -= (x >= q2 ? q2 : 0u);
         x -= (x >= q ? q : 0u);
         v[k] = x;
