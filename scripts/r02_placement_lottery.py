@@ -1,0 +1,32 @@
+"""Is the sweep time of a database a property of its ALLOCATION?  Allocate C2 databases one after the other (keeping the best
+so far alive, freeing the loser), time the stand-alone per-plane sweep launches of each (sp_bench_sweep, real kernel)."""
+import ctypes as C, json, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+import bench
+import sdk_amd as sp
+
+cfg = bench.CONFIGS["c2"]
+p = sp.Params(cfg)
+pp = sp.PublicParameters.deserialize(p, bench.synthetic_wire_bytes(p.setup_bytes(), 1))
+q = bench.synthetic_wire_bytes(p.query_bytes(), 100)
+
+def sweep_ms(db, iters=6):
+    run = sp.QueryRun(p, pp, q, db=db)
+    ms = C.c_float(0)
+    sp.lib().sp_bench_sweep(C.c_void_p(run.h), C.c_void_p(db.h), C.c_int(iters), C.byref(ms))
+    run.free()
+    return ms.value
+
+best, best_ms = None, 1e9
+for i in range(int(os.environ.get("TRIES", "6"))):
+    db = sp.Database(p).fill_synthetic(bench.SEED)
+    torch.cuda.synchronize()
+    a = sweep_ms(db)
+    b = sweep_ms(db)
+    print(json.dumps({"try": i, "ms_per_launch": [round(a, 3), round(b, 3)], "best_so_far": round(min(best_ms, a, b), 3)}), flush=True)
+    if min(a, b) < best_ms:
+        best, best_ms = db, min(a, b)   # the previous best is released
+    else:
+        del db
+print("re-measure best:", round(sweep_ms(best), 3), round(sweep_ms(best), 3))
