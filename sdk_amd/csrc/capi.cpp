@@ -598,7 +598,10 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     q->ws = q->params->acquire_ws();
     Workspace& W = *q->ws;
     HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
+    // a long (per-plane, pipelined) sweep follows: worth moving the fold's half of the expansion off the critical path
+    W.long_sweep_follows = db && !db->sparse && sweep_is_pipelined(h->p, *db);
     run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0, plan);
+    W.long_sweep_follows = false;
     HIP_CHECK(hipEventRecord(W.ev[1], W.stream));
     q->state = 1;
     q->for_sparse = db && db->sparse ? db : nullptr;
@@ -828,7 +831,7 @@ int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* que
     g_last_error = "sp_process_query needs an unsharded db; use sp_query_begin/sweep/finish for shards";
     return SP_E_ARG;
   }
-  sp_query_t* q = sp_query_begin_for_db(h, pp, query, query_len, db && db->sparse ? db : nullptr);
+  sp_query_t* q = sp_query_begin_for_db(h, pp, query, query_len, db);  // (sparse: pruned expansion; wide: split expansion)
   if (!q) return g_last_error.find("hip") != std::string::npos ? SP_E_HIP : SP_E_ARG;
   int rc = sp_query_sweep(q, db);
   if (rc == SP_OK) rc = guarded([&] { finish_impl(q, false, out, out_cap, out_len); });

@@ -16,6 +16,7 @@ struct Workspace {
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
   bool right_pending = false;               // this query's fold operands are produced on stream2: join_right before use
+  bool long_sweep_follows = false;          // hint for run_begin (set by the caller that knows the database)
   // CU-partitioned overlap (SPIRAL_CU_SPLIT = n > 0): the per-plane sweeps run on a stream masked to all but n CUs
   // (n/8 in every XCD) and the overlapped folds on a stream masked to those n CUs, so the two never share a CU's
   // issue slots, LDS or L1; created on first use (hipExtStreamCreateWithCUMask)

@@ -773,8 +773,10 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
   const DeviceState::PrunedPlan* pl = plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
-  if (p.db_dim_2 > 0 && g >= 2 && tunable("expand_split", 0)) {
-    // SPIRAL_EXPAND_SPLIT=1 (off): after round 0 the tree falls into the even subtree (-> v_reg, what the sweep waits
+  const long split_mode = tunable("expand_split", -1);  // -1: only when a long sweep follows (it hides the odd subtree)
+  if (p.db_dim_2 > 0 && g >= 2 && (split_mode > 0 || (split_mode < 0 && W.long_sweep_follows))) {
+    // SPIRAL_EXPAND_SPLIT (default: only before a per-plane pipelined sweep, i.e. wide packed databases; 1: always;
+    // 0: never): after round 0 the tree falls into the even subtree (-> v_reg, what the sweep waits
     // for) and the odd subtree (-> the GSW bits, regev_to_gsw and G - C, what the FOLD waits for; 56 digits per
     // ciphertext against 8: more than half of the transforms).  The odd side then runs on stream2, beside the even side
     // and the first plane's sweep; consumers of fold_mats order themselves after ev_right (join_right).
