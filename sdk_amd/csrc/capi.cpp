@@ -155,7 +155,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
-                                "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split"};
+                                "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -973,9 +973,15 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
     const Params& p = q->params->p;
     const bool per_plane = per_plane_launches < 0 ? sweep_is_pipelined(p, *db) : per_plane_launches != 0;
     need(!per_plane || db->col_G == 1, "per-plane launches need a row-sharded or unsharded db");
+    // the same launches the pipelined query issues (the last plane may be swept as two chunk-parity classes)
+    const auto plan = per_plane_launches < 0 && per_plane ? pipelined_sweep_launches(p, *db) : std::vector<std::pair<size_t, int>>();
     auto sweep_once = [&] {
       if (!per_plane) return run_sweep(W, *db);
       W.ensure_sweep();
+      if (!plan.empty()) {
+        for (const auto& l : plan) launch_plane_sweep(W, *db, l.first, l.second);
+        return;
+      }
       for (size_t pl = 0; pl < p.planes(); pl++) launch_plane_sweep(W, *db, pl);
     };
     sweep_once();  // warm
@@ -985,7 +991,7 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
     HIP_CHECK(hipStreamSynchronize(W.stream));
     float t = 0;
     HIP_CHECK(hipEventElapsedTime(&t, a, b));
-    *ms_per_launch = t / ((float)iters * (per_plane ? (float)p.planes() : 1.0f));
+    *ms_per_launch = t / ((float)iters * (per_plane ? (float)(plan.empty() ? p.planes() : plan.size()) : 1.0f));
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   });
@@ -993,7 +999,7 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
 
 int sp_sweep_launches(const sp_params_t* h, const sp_db_t* db) {
   if (!h || !db) return 0;
-  return sweep_is_pipelined(h->p, *db) ? (int)h->p.planes() : 1;
+  return sweep_is_pipelined(h->p, *db) ? (int)pipelined_sweep_launches(h->p, *db).size() : 1;
 }
 
 // Placement probe: launches `blocks` small workgroups on a stream whose CU mask has bits [bit_lo, bit_hi) set (the

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
   __shared__ u32 lds0[LDS_WORDS];
   __shared__ u32 lds1[LDS_WORDS];
   const int tau = threadIdx.x;
-  const int i = blockIdx.x, plane = blockIdx.y;
+  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
   __shared__ u32 lds1[2 * LDS_WORDS];
   __shared__ u32 ltw[TW_LDS ? 2 * N : 4];
   const int tau = threadIdx.x;
-  const int i = blockIdx.x, plane = blockIdx.y;
+  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
   constexpr int E = 16 / ES;                // digit differences per 16-byte vector
   const int tau = threadIdx.x, lane = tau & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index and row pointers stay scalar
-  const int i = blockIdx.x, plane = blockIdx.y;
+  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -506,7 +506,7 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
     const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
     const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
     if (lds <= 80 * 1024) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
-      const dim3 grid(d.half, d.planes), block(256);  // > 64 KiB of dynamic LDS needs no opt-in on gfx950 (scripts/ubench/dyn_lds.hip)
+      const dim3 grid(d.cls_on ? d.half / 2 : d.half, d.planes), block(256);  // > 64 KiB of dynamic LDS needs no opt-in on gfx950 (scripts/ubench/dyn_lds.hip)
       if (es == 1)
         hipLaunchKernelGGL(k_fold_wave<1>, grid, block, lds, s, T, d, d.mats_w);
       else if (es == 2)
@@ -518,13 +518,13 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
     }
   }
   if ((variant == 3 || variant == 5) && (d.t % 2) == 0)
-    hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+    hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 2 && (d.t % 2) == 0)
-    hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+    hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
   else if (variant == 1)
-    hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+    hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
   else
-    hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.half, d.planes), dim3(256), 0, s, T, d);
+    hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
   launched(PATH_FOLD_FUSED, "k_fold_fused");
 }
 

@@ -45,7 +45,8 @@ enum PathBit : u64 {
   PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
   PATH_CU_SPLIT = 1ull << 21,         // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
-  PATH_EXPAND_SPLIT = 1ull << 22      // odd expansion subtree + GSW side on the second stream, beside the even subtree
+  PATH_EXPAND_SPLIT = 1ull << 22,     // odd expansion subtree + GSW side on the second stream, beside the even subtree
+  PATH_PIPE_CLASS_SPLIT = 1ull << 23  // a plane swept and folded as two chunk-parity classes (pipe_split)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -114,7 +115,8 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s);
 // from_ntt of the sweep-native buffer [plane][r][crt][z][ii] (num_per = np, np % 4 == 0), four adjacent
 // columns per workgroup (16-byte loads: a quarter of the cache-line traffic of the one-column form);
 // dst raw polys dense in the same order as InvDesc's sweep mode: poly (plane*np + ii)*2 + r.
-void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s);
+// cls >= 0: only the columns whose 128-column chunk has parity cls (np % 256 == 0)
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls = -1);
 
 // ---- NTT-domain multiply-accumulate (poly.rs:437-481) --------------------------------------
 // out[b][r] = (addend ? addend[b][r] : 0) + sum_k A[r][k] * B[b][k]   (pointwise, per crt), r < R
@@ -160,7 +162,13 @@ struct FoldDesc {
   int zero_shortcuts;
   // the level's operands in wave layout (k_fold_wave); nullptr: not available
   const u32* mats_w;
+  // cls_on: only the fold steps of one chunk-parity class (see SweepDesc::chunk_step): block b handles step
+  // i = (b / 128) * 256 + b % 128 + 128 * cls_off; the grid has half / 2 blocks.  Needs half % 256 == 0.
+  int cls_on, cls_off;
 };
+__host__ __device__ inline int fold_step_of_block(const FoldDesc& d, int b) {
+  return d.cls_on ? ((b >> 7) << 8) + (b & 127) + 128 * d.cls_off : b;
+}
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
 // SPIRAL_FOLD_VARIANT: 5 = k_fold_wave (wave-per-transform NTT; used while two workgroups fit a CU's LDS, else falls
@@ -253,6 +261,10 @@ struct SweepDesc {
   // out_G > 1: column-interleaved output for the multi-GPU reduce-scatter -- chunk g = ii % out_G holds
   // [plane][r][crt][z][ii / out_G]; chunks are contiguous (chunk g goes to rank g)
   int out_G;
+  // chunk_step == 2 (persistent PACKED sweep only): only the 128-column chunks of parity chunk_off -- half a plane.  The
+  // first log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and therefore stay inside one parity
+  // class, which lets the pipeline fold one half of a plane while the other half is still being swept.
+  int chunk_step, chunk_off;
 };
 // Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
 // i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.

@@ -255,7 +255,8 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // from_ntt of four adjacent sweep-output columns per workgroup.  grid (np/4 * 2 * planes)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map) {
+__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map,
+                                                        int cls) {
   __shared__ u32 lds0[4 * LDS_WORDS];
   __shared__ u32 lds1[4 * LDS_WORDS];
   const int tau = threadIdx.x;
@@ -267,9 +268,12 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
     const int xcd = g & 7, t = g >> 3;
     g = ((t >> 3) * 8 + xcd) * 8 + (t & 7);
   }
-  const int groups_per_plane = (np / 4) * 2;
+  // cls >= 0: only the column groups of one chunk-parity class (chunk = 128 columns = 32 groups of four)
+  const int gpr = cls >= 0 ? np / 8 : np / 4;  // groups per (plane, r)
+  const int groups_per_plane = gpr * 2;
   const int plane = g / groups_per_plane, rem = g % groups_per_plane;
-  const int r = rem / (np / 4), ii0 = (rem % (np / 4)) * 4;
+  const int r = rem / gpr, gl = rem % gpr;
+  const int ii0 = cls >= 0 ? ((gl >> 5) * 2 + cls) * 128 + (gl & 31) * 4 : gl * 4;
   const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
   u32 res0[4][8];
 #pragma unroll 1
@@ -312,12 +316,12 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
     }
   }
 }
-void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls) {
   if (n_planes <= 0) return;
-  const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
+  const unsigned groups = (unsigned)((np / (cls >= 0 ? 8 : 4)) * 2 * n_planes);
   const int want = (int)tunable("from_sweep_xcd", 1);
   const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
-  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
+  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map, cls);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
 

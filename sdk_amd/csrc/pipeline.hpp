@@ -14,6 +14,7 @@ struct Workspace {
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
+  hipEvent_t ev_class0 = nullptr;           // first chunk-parity class of a plane swept (pipe_split)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
   bool right_pending = false;               // this query's fold operands are produced on stream2: join_right before use
   bool long_sweep_follows = false;          // hint for run_begin (set by the caller that knows the database)
@@ -89,9 +90,11 @@ void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
 void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);
-void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
+bool plane_is_class_split(const Params& p, const sp_db& db, size_t plane);
+std::vector<std::pair<size_t, int>> pipelined_sweep_launches(const Params& p, const sp_db& db);  // (plane, class or -1)
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane, int cls = -1);  // cls >= 0: one chunk-parity class
 bool fused_fold_supported(const Params& p);
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top);
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1, int cls = -1);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_fold_local_plane(Workspace& W, const u32* reduced_plane_chunk, int G, int plane);
 void run_fold_local_join(Workspace& W);

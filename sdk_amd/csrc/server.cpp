@@ -360,6 +360,7 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_round0, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_class0, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_right, hipEventDisableTiming));
   ev_plane.resize(P.planes());
   for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
@@ -383,7 +384,7 @@ Workspace::~Workspace() {
   for (auto& e : ev_plane)
     if (e) (void)hipEventDestroy(e);
   if (ev_fold) (void)hipEventDestroy(ev_fold);
-  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right})
+  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right, ev_class0})
     if (e) (void)hipEventDestroy(e);
   if (s_sweep) (void)hipStreamDestroy(s_sweep);
   if (s_fold) (void)hipStreamDestroy(s_fold);
@@ -869,6 +870,57 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 
+// The pipeline's finer grain: a plane is swept in two launches, the 128-column chunks of even and of odd index; the first
+// L = log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and stay inside such a class, so the
+// from_ntt and those L levels of class 0 run while class 1 is still being swept.
+static int class_fold_levels(const Params& p) {
+  int lg = 0;
+  while (((size_t)1 << lg) < p.num_per()) lg++;
+  return lg - 8;
+}
+static bool class_split_ok(const Params& p) {
+  return p.num_per() % 512 == 0 && class_fold_levels(p) >= 1 && fused_fold_supported(p) && !tunable("from_sweep1", 0);
+}
+static void fold_plane_class(Workspace& W, size_t pl, int cls) {  // from_ntt + class-local levels of one class
+  const Params& p = *W.P;
+  launch_from_sweep4(W.D->T, W.sweep_out.p + pl * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), 1, 0, W.foldX.p, W.stream, cls);
+  (void)run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, class_fold_levels(p), cls);
+}
+static void fold_plane_rest(Workspace& W, size_t pl) {  // the remaining levels of the plane, both classes together
+  const Params& p = *W.P;
+  const int L = class_fold_levels(p);
+  u64* X = (L & 1) ? W.foldY.p : W.foldX.p;   // every level swaps the two buffers
+  u64* Y = (L & 1) ? W.foldX.p : W.foldY.p;
+  u64* res = run_fold(W, X, Y, 1, (int)p.num_per(), -1, L, -1, -1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pl * 2 * POLY_LEN, res, (size_t)2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
+}
+
+// pipe_split (default 0 = off): 2 = every plane is swept as two chunk-parity classes, so that the second stream starts a
+// plane's from_ntt and class-local fold levels half a plane earlier; 1 = only the last plane.  Measured at C2
+// (profiles/r02_sweep_experiments.md): the overlapped folds take as long as the sweeps they hide behind, so the second
+// stream runs late and the finer grain shortens what is exposed at the end (0.74 -> 0.56 ms), but the half-plane
+// launches are 3-4 % less efficient (ramp and tail twice per plane): 11.52 -> 11.44 ms in one process, nothing across
+// runs.  Splitting only the last plane is slower (its class-0 fold queues behind the previous plane's fold).
+bool plane_is_class_split(const Params& p, const sp_db& db, size_t pl) {
+  const long split = class_split_ok(p) && db.packed && tunable("pipe_wgs", 4) > 0 && tunable("fused_min_pairs", 256) <= 256
+                         ? tunable("pipe_split", 0)
+                         : 0;
+  return split == 2 || (split == 1 && pl + 1 == p.planes());
+}
+// the sweep launches of one pipelined query: (plane, class or -1)
+std::vector<std::pair<size_t, int>> pipelined_sweep_launches(const Params& p, const sp_db& db) {
+  std::vector<std::pair<size_t, int>> v;
+  for (size_t pl = 0; pl < p.planes(); pl++) {
+    if (plane_is_class_split(p, db, pl)) {
+      v.push_back({pl, 0});
+      v.push_back({pl, 1});
+    } else {
+      v.push_back({pl, -1});
+    }
+  }
+  return v;
+}
+
 // Single-GPU query on a wide PACKED database: the database is swept one (instance, trial) plane per launch, and
 // the from_ntt + fold of plane p (integer-ALU-bound, ~20 % of the sweep's duration) runs on the second stream while
 // plane p+1 is being swept (HBM-bound, ~20 % VALU use, 40 VGPRs per wave: the fold's workgroups fit beside it).
@@ -879,12 +931,12 @@ bool sweep_is_pipelined(const Params& p, const sp_db& db) {
   return enabled && db.packed && db.num_shards == 1 && db.col_G == 1 && p.planes() > 1 && p.num_per() >= 1024;
 }
 
-void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl, int cls) {
   const Params& p = *W.P;
   const size_t np_ = (size_t)db.np_local;
   const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
-              (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
+              (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G, cls >= 0 ? 2 : 1, cls >= 0 ? cls : 0};
   const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
   if (db.packed && wgs > 0)
     launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);
@@ -926,6 +978,21 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   }
   HIP_CHECK(hipEventRecord(W.ev_sw[0], W.stream));
   for (size_t pl = 0; pl < planes; pl++) {
+    if (plane_is_class_split(p, db, pl)) {
+      launch_plane_sweep(W, db, pl, 0);
+      HIP_CHECK(hipEventRecord(W.ev_class0, W.stream));
+      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_class0, 0));
+      on_stream(W, W.stream2, [&] { fold_plane_class(W, pl, 0); });
+      launch_plane_sweep(W, db, pl, 1);
+      HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
+      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
+      on_stream(W, W.stream2, [&] {
+        fold_plane_class(W, pl, 1);
+        fold_plane_rest(W, pl);
+      });
+      note_path(PATH_PIPE_CLASS_SPLIT);
+      continue;
+    }
     launch_plane_sweep(W, db, pl);
     HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
     HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
@@ -955,25 +1022,31 @@ bool fused_fold_supported(const Params& p) { return 4 * p.t_gsw <= 128 && p.bits
 
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top) {
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin, int d_end, int cls) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
   const int two_t = (int)(2 * p.t_gsw);
   join_right(W);
-  int cur = num_cts;
   int further = 0;
   while (((int)1 << further) < num_cts) further++;
   // level d uses GSW ciphertext v_folding[top - d]; a whole tree has top = further - 1 (server.rs:413,420)
   const int top_idx = top < 0 ? further - 1 : top;
-  for (int d = 0; d < further; d++) {
+  // levels [d_begin, d_end) of the tree (default: all); cls >= 0: only the fold steps of one chunk-parity class (fused
+  // kernels; the caller has checked that these levels qualify: half % 256 == 0)
+  if (d_end < 0) d_end = further;
+  int cur = num_cts >> d_begin;
+  for (int d = d_begin; d < d_end; d++) {
     const int half = cur / 2;
     // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
     // the three-kernel form, which parallelises over digits
     if (W.zero_shortcuts && !fused_fold_supported(p))
       throw ArgError("sparse buckets need gadget parameters the fused fold supports (3 <= t_gsw <= 32)");
-    if (W.zero_shortcuts || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
+    if (cls >= 0 && !(fused_fold_supported(p) && half % 256 == 0)) throw ArgError("internal: class fold on an unfit level");
+    if (W.zero_shortcuts || cls >= 0 || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
       FoldDesc fd{};
+      fd.cls_on = cls >= 0 ? 1 : 0;
+      fd.cls_off = cls >= 0 ? cls : 0;
       fd.zero_shortcuts = W.zero_shortcuts ? 1 : 0;
       fd.mats_w = W.mats_w_ready ? W.fold_mats_w.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN : nullptr;
       fd.X = X;

@@ -189,9 +189,10 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
+  const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;  // one chunk-parity class or all chunks
   for (int unit = wave0; unit < units; unit += nwaves) {
-    const int chunk = unit % chunks;
-    const int zp = unit / chunks;
+    const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
+    const int zp = unit / chunks_l;
     const int z = zp & (N - 1);
     const int plane = zp >> POLY_LEN_LOG2;
     const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);
@@ -239,7 +240,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   }
 }
 void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus) {
-  const int units = d.planes * N * (d.num_per >> 7);
+  const int units = d.planes * N * ((d.num_per >> 7) / (d.chunk_step == 2 ? 2 : 1));
   const dim3 grid((unsigned)std::min(n_cus * wgs_per_cu, (units + 3) / 4));
   const int prio = (int)tunable("sweep_prio", 1);
   switch (unroll) {

@@ -814,11 +814,35 @@ def test_overlapped_fold_many_planes_parity(sp, oracle_mod):
     gpp = sp.PublicParameters.deserialize(p, pp)
     gdb = sp.Database(p).load(db)
     run = sp.QueryRun(p, gpp, q)
-    assert run.sweep_launches(gdb) == (1 if os.environ.get("SPIRAL_PIPELINE") == "0" else 8)
+    assert run.sweep_launches(gdb) == (1 if os.environ.get("SPIRAL_PIPELINE") == "0" else 8)   # t_gsw = 2: no class split
     resp = run.sweep(gdb).finish()
     run.free()
     assert resp == o.process_query(pp, q, db)
     assert sp.process_query(p, gpp, q, gdb) == resp
+
+
+@pytest.mark.parametrize("nu_2,split", [(10, "2"), (10, "1"), (10, "0"), (11, "2")])
+def test_pipelined_class_split_parity(sp, oracle_mod, monkeypatch, nu_2, split):
+    """The pipelined query sweeps a plane as two chunk-parity classes (even / odd 128-column chunks) and folds class 0's
+    first log2(num_per) - 8 levels while class 1 is swept (SPIRAL_PIPE_SPLIT: 2 = every plane; 1 = last plane;
+    0 = off, the default): response bytes equal the oracle's in every mode, with 2 and 3 class-local levels."""
+    monkeypatch.setenv("SPIRAL_PIPE_SPLIT", split)
+    cfg = {"n": 2, "nu_1": 5, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 8192}   # t_gsw = 4: 15-bit digits, k_fold_wave<2>
+    o, cl, pp, q = _session(oracle_mod, cfg, 4321, 16)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(4321)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    run = sp.QueryRun(p, gpp, q, db=gdb)
+    assert run.sweep_launches(gdb) == {"0": 4, "1": 5, "2": 8}[split]
+    sp.paths_taken()
+    resp = run.sweep(gdb).finish()
+    taken = sp.paths_taken()
+    run.free()
+    assert ("pipe_class_split" in taken) == (split != "0") and "pipelined_fold_overlap" in taken, taken
+    assert resp == o.process_query(pp, q, db)
+    assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
 def test_process_query_batch_lds_staged(sp, oracle_mod):
