@@ -265,7 +265,8 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
 //              it into private 64-bit sums for both output rows (32 coefficients per lane) -- the operands are fetched
 //              during the transform's last stages and consumed quarter by quarter as it finishes (FoldMac);
 //              the four partial sums are combined through LDS (two rounds), wave 0 ends up with row 0 and wave 1 with
-//              row 1 and each runs one inverse transform; Garner and + ct_i as before.
+//              row 1
+//   at the end  four inverse transforms (2 rows x 2 moduli), one per wave; Garner and + ct_i as before.
 // mats_w: the level's [G-C | C] operands in wave layout (wave_layout_word), same polynomial order as FoldDesc::mats.
 // LDS: [4 transpose buffers 18 KiB | forward tables of the current modulus 16 KiB | digit planes 2t * 2048 * ES | sign planes 2t * 256];
 // the first 32 KiB double as the cross-wave reduction scratch.
@@ -455,29 +456,56 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
     __syncthreads();  // the scratch is free again: waves 0 and 1 use their own regions for the inverse transform
 #undef SP_PUT
 #undef SP_ADD
-    if (wv < 2) {
-      const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
-      u64* orow = out + (size_t)wv * N;
-      const u64* crow = ct0 + (size_t)wv * N;
+    // Wave 0 now holds row 0 and wave 1 row 1 of modulus c (NTT domain, lane L = coefficients 32 L .. 32 L + 31).  The
+    // four inverse transforms of the step (2 rows x 2 moduli) run at the END, one per wave: modulus 0's rows are parked
+    // in the output slot (as u32, its first 16 KiB) and picked up by waves 2 and 3, so that no wave idles while two
+    // others transform back (with one inverse per modulus round, waves 2-3 were idle for a quarter of the step).
+    u32* park = reinterpret_cast<u32*>(out);
+    if (c == 0) {
+      if (wv < 2) {
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+          u32x4w_t t4;
+          t4.x = wv == 0 ? r0[4 * g] : r1[4 * g]; t4.y = wv == 0 ? r0[4 * g + 1] : r1[4 * g + 1];
+          t4.z = wv == 0 ? r0[4 * g + 2] : r1[4 * g + 2]; t4.w = wv == 0 ? r0[4 * g + 3] : r1[4 * g + 3];
+          *reinterpret_cast<u32x4w_t*>(park + wv * N + 32 * lt + 4 * g) = t4;
+        }
+      }
+    } else {
+      const int irow = wv & 1, imod = wv < 2 ? 1 : 0;
+      const ModConst mi = T.c.mod[imod];
       u32 rr[32];
+      if (wv < 2) {
 #pragma unroll
-      for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
-      wntt_inv(rr, lt, mybuf, iw, m.q, m.two_q);
-      if (c == 0) {  // park the modulus-0 residues in the output slot (the same lane re-reads them below)
-#pragma unroll
-        for (int k = 0; k < 32; k++) orow[64 * k + lt] = rr[k];
+        for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
       } else {
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+          const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + 32 * lt + 4 * g);
+          rr[4 * g] = t4.x; rr[4 * g + 1] = t4.y; rr[4 * g + 2] = t4.z; rr[4 * g + 3] = t4.w;
+        }
+      }
+      wntt_inv(rr, lt, mybuf, T.tw + ((size_t)imod * 4 + 2) * N, mi.q, mi.two_q);  // -> coefficient 64 k + lane
+      u32* exch = smem_fw + 4 * WBUF_WORDS;  // the table area: modulus-1 residues of both rows for Garner
+      if (wv < 2) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) exch[irow * N + 64 * k + lt] = rr[k];
+      }
+      __syncthreads();  // (also: waves 2 and 3 have read their parked rows before anybody overwrites the output slot)
+      if (wv >= 2) {
+        u64* orow = out + (size_t)irow * N;
+        const u64* crow = ct0 + (size_t)irow * N;
         const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
 #pragma unroll
         for (int k = 0; k < 32; k++) {
           const size_t zi = 64 * k + lt;
-          u32 x = (u32)orow[zi], y = rr[k];
-          u32 xm = x >= q1 ? x - q1 : x;
-          u32 dd = y >= xm ? y - xm : y + q1 - xm;
-          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+          const u32 x = rr[k], y = exch[irow * N + zi];
+          const u32 xm = x >= q1 ? x - q1 : x;
+          const u32 dd = y >= xm ? y - xm : y + q1 - xm;
+          const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
           u32 e = dd * T.c.q0_inv_q1 - qt * q1;
           e = e >= q1 ? e - q1 : e;
-          u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
+          const u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
           orow[zi] = val >= T.c.Q ? val - T.c.Q : val;
         }
       }
