@@ -33,12 +33,14 @@ __global__ __launch_bounds__(256) void k_linear(const u32x4* base, long n16, uns
   if (acc == 0x12345678u) sink[0] = acc;
 }
 // "big" mode: one allocation of 56 GiB (after an optional pad allocation), the units-pattern read timed per 14-GiB quarter
-static int big_mode(double pad_gb) {
+static int big_mode(double pad_gb, int contiguous) {
   void* pad = nullptr;
   if (pad_gb > 0) hipMalloc(&pad, (size_t)(pad_gb * (1ull << 30)));
   const size_t quarter = (size_t)(14ull << 30) / (448 * 1024) * (448 * 1024);
   unsigned char* big = nullptr;
-  if (hipMalloc((void**)&big, 4 * quarter) != hipSuccess) { printf("alloc failed\n"); return 1; }
+  hipError_t e = contiguous ? hipExtMallocWithFlags((void**)&big, 4 * quarter, hipDeviceMallocContiguous) : hipMalloc((void**)&big, 4 * quarter);
+  if (e != hipSuccess) { printf("alloc failed: %s\n", hipGetErrorName(e)); return 1; }
+  if (contiguous) printf("(hipDeviceMallocContiguous) ");
   hipMemset(big, 1, 4 * quarter);
   unsigned* sink;
   hipMalloc(&sink, 4);
@@ -62,7 +64,8 @@ static int big_mode(double pad_gb) {
   return 0;
 }
 int main(int argc, char** argv) {
-  if (argc > 2 && argv[1][0] == 'b') return big_mode(atof(argv[2]));
+  if (argc > 2 && argv[1][0] == 'b') return big_mode(atof(argv[2]), 0);
+  if (argc > 2 && argv[1][0] == 'c') return big_mode(atof(argv[2]), 1);
   const double chunk_gb = argc > 1 ? atof(argv[1]) : 2.0;
   const size_t chunk = (size_t)(chunk_gb * (1ull << 30)) / (448 * 1024) * (448 * 1024);
   size_t fr, tot;

@@ -254,7 +254,7 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
       d->np_local = (int)p.num_per();
     }
     d->packed = db_can_pack(d->np_local, d->nj) && !tunable("db_unpacked", 0) ? 1 : 0;
-    d->words.alloc((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8);
+    d->words.alloc_streaming((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8, tunable("db_contiguous", 1) != 0);
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();

@@ -3,6 +3,8 @@
 // deserialisation (client.rs:212-259, 303-329), expand_query, multiply_reg_by_database,
 // fold_ciphertexts, pack, encode, process_query -- with all polynomial data device-resident.
 #pragma once
+#include <cstdio>
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <memory>
@@ -58,6 +60,26 @@ struct DevBuf {
     }
     p = (T*)q;
     n = count;
+  }
+  // Large streaming buffers (the database): ask for PHYSICALLY CONTIGUOUS device memory first.  How a plain hipMalloc of
+  // tens of GiB is backed is a lottery (the physical pages the driver happens to have): the same read stream runs at
+  // 6.7-7.07 TB/s depending on the process, while a contiguous allocation gave 7.05-7.08 TB/s in every run
+  // (scripts/ubench/hbm_map.hip, profiles/r02_sweep_experiments.md).  Falls back to hipMalloc.
+  void alloc_streaming(size_t count, bool want_contiguous) {
+    release();
+    if (count == 0) return;
+    if (want_contiguous) {
+      void* q = nullptr;
+      const hipError_t e = hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocContiguous);
+      if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] contiguous allocation of %zu bytes: %s\n", count * sizeof(T), hipGetErrorName(e));
+      if (e == hipSuccess && q) {
+        p = (T*)q;
+        n = count;
+        return;
+      }
+      (void)hipGetLastError();
+    }
+    alloc(count);
   }
   void ensure(size_t count) { if (count > n) alloc(count); }
   void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
