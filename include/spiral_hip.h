@@ -292,6 +292,9 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
  * [bit_lo, bit_hi) set (no mask when bit_hi <= bit_lo); out2[2b] = HW_REG_XCC_ID, out2[2b+1] = HW_REG_HW_ID of
  * workgroup b.  Used to verify the CU partition of the fold / sweep overlap (SPIRAL_CU_SPLIT). */
 int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2);
+/* Diagnostic: checksums of the resident tables / index lists / public parameters as seen by a kernel, by a
+ * device-to-host copy, by a kernel after an L2 write-back + invalidate, and of the host original (24 values). */
+int sp_debug_resident_check(const sp_params_t* params, const sp_pp_t* pp, uint64_t* out, int cap);
 
 /* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient
  * vectors per thread, `blocks` workgroups each chaining `reps` transforms, no memory traffic but twiddles). */

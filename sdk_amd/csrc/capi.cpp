@@ -126,10 +126,10 @@ void sp_db::ensure_sparse_index() {
   col_ptr.ensure(ptr.size());
   col_rows.ensure(std::max<size_t>(rows.size(), 1));
   col_slots.ensure(std::max<size_t>(slots.size(), 1));
-  HIP_CHECK(hipMemcpy(col_ptr.p, ptr.data(), ptr.size() * sizeof(int), hipMemcpyHostToDevice));
+  upload_words(col_ptr.p, ptr.data(), ptr.size() * sizeof(int));
   if (!rows.empty()) {
-    HIP_CHECK(hipMemcpy(col_rows.p, rows.data(), rows.size() * sizeof(int), hipMemcpyHostToDevice));
-    HIP_CHECK(hipMemcpy(col_slots.p, slots.data(), slots.size() * sizeof(int), hipMemcpyHostToDevice));
+    upload_words(col_rows.p, rows.data(), rows.size() * sizeof(int));
+    upload_words(col_slots.p, slots.data(), slots.size() * sizeof(int));
   }
   if (slots_cap == 0) polys.ensure(1);
   sparse_plan = build_pruned_plan_rows(p, row_set);  // query_expansion.rs:263-280: set_dim0 = rows of the present items
@@ -254,7 +254,11 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
       d->np_local = (int)p.num_per();
     }
     d->packed = db_can_pack(d->np_local, d->nj) && !tunable("db_unpacked", 0) ? 1 : 0;
-    d->words.alloc_streaming((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8, tunable("db_contiguous", 1) != 0);
+    // db_contiguous (default 0): physically contiguous allocation.  It gives the sweep its best case in every process
+    // (profiles/r02_sweep_experiments.md) but is NOT SAFE on this stack: asking the driver for a contiguous range makes
+    // it move other live buffers of the process, and their contents were observed to change (public parameters
+    // allocated just before a 56 GiB database: profiles/r02_stale_reads.md) -- wrong responses on some machines.
+    d->words.alloc_streaming((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8, tunable("db_contiguous", 0) != 0);
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();
@@ -301,7 +305,7 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     DevBuf<u64> stage((size_t)zs * row_words);
     for (int z = 0; z < nz; z += zs) {
       const int cnt = std::min(zs, nz - z);
-      HIP_CHECK(hipMemcpy(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8, hipMemcpyHostToDevice));
+      h2d_sync(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8);
       launch_db_relayout(d->words.p, plane, stage.p, z0 + z, cnt, d->np_local, (int)p.dim0(), d->j0, d->nj,
                          d->packed, d->colmap(), 0);
       HIP_CHECK(hipDeviceSynchronize());
@@ -357,7 +361,7 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
       const size_t off = item0 * p.db_item_size;
       size_t want = (size_t)cnt * 2 * row_bytes + bpc;
       size_t have = off < file_len ? std::min(want, file_len - off) : 0;
-      if (have) HIP_CHECK(hipMemcpy(win.p, file + off, have, hipMemcpyHostToDevice));
+      if (have) h2d_sync(win.p, file + off, have);
       DbEncodeDesc e{};
       e.win = win.p;
       e.win_item0 = item0;
@@ -409,6 +413,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
           const size_t cap = std::max<size_t>(64, d->slots_cap * 2);
           DevBuf<u64> bigger(cap * poly_words);
           if (d->slots_cap) HIP_CHECK(hipMemcpy(bigger.p, d->polys.p, d->slots_cap * poly_words * 8, hipMemcpyDeviceToDevice));
+          if (d->slots_cap && tunable("h2d_cache_sync", 0) != 0) launch_cache_sync(nullptr, 0);  // (as h2d_sync)
           d->polys = std::move(bigger);
           d->slots_cap = cap;
         }
@@ -416,7 +421,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
       }
       DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
       HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
-      if (len) HIP_CHECK(hipMemcpy(win.p, data, len, hipMemcpyHostToDevice));
+      if (len) h2d_sync(win.p, data, len);
       launch_sparse_item_encode(D.T, win.p, (int)p.db_item_size, (int)bpc, (int)logp, (u32)p.pt_modulus,
                                 d->polys.p + slot * poly_words, (int)planes, 0);
       HIP_CHECK(hipDeviceSynchronize());
@@ -434,7 +439,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     const size_t bpc = (p.db_item_size + chunks - 1) / chunks;
     DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
     HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
-    if (len) HIP_CHECK(hipMemcpy(win.p, data, len, hipMemcpyHostToDevice));
+    if (len) h2d_sync(win.p, data, len);
     DbEncodeDesc e{};
     e.win = win.p;
     e.win_item0 = item_idx;
@@ -541,7 +546,7 @@ sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len
       }
     need(wpos == len && ppos == off, "internal: pp layout mismatch");
     DevBuf<u64> d_raw(raw.size());
-    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    h2d_sync(d_raw.p, raw.data(), raw.size() * 8);
     pp->all.alloc(off * 2 * POLY_LEN);
     FwdDesc f{d_raw.p, nullptr, pp->all.p, (int)off, 1, 1, 1, 64, 1, 0, 1};  // to_ntt_alloc (client.rs:244-247)
     launch_ntt_fwd(D.T, f, 0);
@@ -549,10 +554,9 @@ sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len
     const size_t n = p.n, tc = p.t_conv;
     pp->pack_cat.alloc((n + 1) * n * tc * 2 * POLY_LEN);
     for (size_t rr = 0; rr < n + 1; rr++)
-      for (size_t r = 0; r < n; r++)
-        HIP_CHECK(hipMemcpyAsync(pp->pack_cat.p + (rr * n * tc + r * tc) * 2 * POLY_LEN,
-                                 pp->all.p + (pp->off_packing + r * (n + 1) * tc + rr * tc) * 2 * POLY_LEN,
-                                 tc * 2 * POLY_LEN * sizeof(u32), hipMemcpyDeviceToDevice, 0));
+      for (size_t r = 0; r < n; r++)  // (copy kernel, not a copy-engine transfer: see upload_words)
+        launch_copy_words(pp->pack_cat.p + (rr * n * tc + r * tc) * 2 * POLY_LEN,
+                          pp->all.p + (pp->off_packing + r * (n + 1) * tc + rr * tc) * 2 * POLY_LEN, tc * 2 * POLY_LEN, 0);
     HIP_CHECK(hipDeviceSynchronize());
     out = pp.release();
   });
@@ -600,6 +604,8 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
     // a long (per-plane, pipelined) sweep follows: worth moving the fold's half of the expansion off the critical path
     W.long_sweep_follows = db && !db->sparse && sweep_is_pipelined(h->p, *db);
+    debug_stage(1);
+    if (tunable("query_cache_sync", 0) != 0) launch_cache_sync(nullptr, W.stream);  // diagnostic: L2 write-back + invalidate per query
     run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0, plan);
     W.long_sweep_follows = false;
     HIP_CHECK(hipEventRecord(W.ev[1], W.stream));
@@ -622,6 +628,7 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
     check_device(db->device);
     Workspace& W = *q->ws;
     need(q->for_sparse == nullptr || q->for_sparse == db, "the query was expanded for another sparse bucket");
+    debug_stage(2);
     if (db->sparse) {
       // lib/server's process_query over a SparseDb (lib/server/src/server.rs:17-99): present items only, and the
       // fold takes fold.rs:38-44's all-zero shortcuts
@@ -784,6 +791,7 @@ static void finish_impl(sp_query_t* q, bool premod, uint8_t* out, size_t out_cap
   const Params& p = q->params->p;
   need(out_cap >= p.response_bytes(), "output buffer smaller than response_bytes");
   Workspace& W = *q->ws;
+  debug_stage(3);
   run_finish(W, *q->pp, premod);
   HIP_CHECK(hipStreamSynchronize(W.stream));
   memcpy(out, W.h_response, p.response_bytes());
@@ -1023,6 +1031,46 @@ int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2) {
     launch_cu_probe(d.p, blocks, s);
     HIP_CHECK(hipMemcpyAsync(out2, d.p, (size_t)blocks * 8, hipMemcpyDeviceToHost, s));
     HIP_CHECK(hipStreamSynchronize(s));
+    (void)hipStreamDestroy(s);
+  });
+}
+
+// Resident-data check (diagnostic): for each of tw, neg1, gadget_gsw, lists, pp.all, pp.pack_cat -> 4 values:
+// checksum as a kernel on a fresh non-blocking stream sees it, checksum of a device-to-host copy, the kernel view again
+// after k_cache_sync (L2 write-back + invalidate on every XCD), and the checksum of the host original where the
+// library still has it (tw; 0 otherwise).  A kernel view that differs from the copy view is a stale cache line.
+int sp_debug_resident_check(const sp_params_t* h, const sp_pp_t* pp, uint64_t* out, int cap) {
+  return guarded([&] {
+    need(h && pp && out && cap >= 24, "bad argument");
+    DeviceState& D = const_cast<sp_params*>(h)->device_state();
+    struct Item { const u32* p; size_t n; const u32* host; };
+    const Item items[6] = {{D.tw.p, D.tw.n, h->p.ntt_tables.data()}, {D.neg1.p, D.neg1.n, nullptr},
+                           {D.gadget_gsw.p, D.gadget_gsw.n, nullptr}, {(const u32*)D.lists.p, D.lists.n, nullptr},
+                           {pp->all.p, pp->all.n, nullptr}, {pp->pack_cat.p, pp->pack_cat.n, nullptr}};
+    hipStream_t s = nullptr;
+    HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    DevBuf<unsigned long long> acc(12);
+    DevBuf<u32> sink(1);
+    auto host_sum = [](const u32* p, size_t n) {
+      unsigned long long a = 0;
+      for (size_t i = 0; i < n; i++) a += (unsigned long long)p[i] * (unsigned long long)((i << 1) | 1);
+      return a;
+    };
+    HIP_CHECK(hipMemsetAsync(acc.p, 0, 12 * 8, s));
+    for (int i = 0; i < 6; i++) launch_checksum(items[i].p, items[i].n, acc.p + i, s);
+    launch_cache_sync(sink.p, s);
+    for (int i = 0; i < 6; i++) launch_checksum(items[i].p, items[i].n, acc.p + 6 + i, s);
+    unsigned long long k[12];
+    HIP_CHECK(hipMemcpyAsync(k, acc.p, sizeof(k), hipMemcpyDeviceToHost, s));
+    HIP_CHECK(hipStreamSynchronize(s));
+    for (int i = 0; i < 6; i++) {
+      std::vector<u32> hostcopy(items[i].n);
+      if (items[i].n) HIP_CHECK(hipMemcpy(hostcopy.data(), items[i].p, items[i].n * 4, hipMemcpyDeviceToHost));
+      out[4 * i + 0] = k[i];
+      out[4 * i + 1] = host_sum(hostcopy.data(), items[i].n);
+      out[4 * i + 2] = k[6 + i];
+      out[4 * i + 3] = items[i].host ? host_sum(items[i].host, items[i].n) : 0;
+    }
     (void)hipStreamDestroy(s);
   });
 }

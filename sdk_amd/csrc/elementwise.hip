@@ -163,6 +163,39 @@ void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u
   launched(0, "k_copy_polys");
 }
 
+// Diagnostics for resident data: checksum of a buffer as KERNELS see it (through the caches), and a kernel whose
+// waves write back and invalidate the L2 of the XCD they run on (system-scope fence: buffer_wbl2 + buffer_inv).
+__global__ __launch_bounds__(256) void k_checksum(const u32* p, size_t n, unsigned long long* out) {
+  unsigned long long acc = 0;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+    acc += (unsigned long long)p[i] * (unsigned long long)((i << 1) | 1);
+  atomicAdd(out, acc);
+}
+void launch_checksum(const u32* p, size_t n_words, unsigned long long* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_checksum, dim3(512), dim3(256), 0, s, p, n_words, out);
+  launched(0, "k_checksum");
+}
+__global__ __launch_bounds__(64) void k_cache_sync(u32* sink) {
+  __threadfence_system();
+  if (sink && threadIdx.x == 0 && blockIdx.x == 0) sink[0] = 1;
+  __threadfence_system();
+}
+void launch_cache_sync(u32* sink, hipStream_t s) {
+  hipLaunchKernelGGL(k_cache_sync, dim3(1024), dim3(64), 0, s, sink);  // blocks are dealt round-robin to the 8 XCDs
+  launched(0, "k_cache_sync");
+}
+
+// plain word copy (grid-stride): the last hop of every host -> device upload of resident data (upload_words, server.cpp)
+__global__ __launch_bounds__(256) void k_copy_words(u32* dst, const u32* src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+void launch_copy_words(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
+  if (n_words == 0) return;
+  const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 4096);
+  hipLaunchKernelGGL(k_copy_words, dim3(blocks), dim3(256), 0, s, dst, src, n_words);
+  launched(0, "k_copy_words");
+}
+
 __global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, const u32* gadget_ntt, int two_t) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   const int c = e >> POLY_LEN_LOG2;

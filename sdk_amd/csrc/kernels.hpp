@@ -53,6 +53,10 @@ enum PathBit : u64 {
 long tunable(const char* name, long dflt);  // server.cpp
 void launched(u64 path_bits, const char* kernel);  // server.cpp
 void note_path(u64 path_bits);
+void launch_checksum(const u32* p, size_t n_words, unsigned long long* out, hipStream_t s);  // sum p[i] * (2i + 1)
+void launch_cache_sync(u32* sink, hipStream_t s);  // every XCD: L2 write-back + invalidate (system-scope fences)
+void launch_copy_words(u32* dst, const u32* src, size_t n_words, hipStream_t s);  // elementwise.hip
+void debug_stage(int stage);  // 1 expansion, 2 sweep, 3 fold/pack/encode (debug_sync, server.cpp)
 
 // ---- forward NTT family -------------------------------------------------------------------
 // Generic source descriptor for a batch of forward NTTs: output poly `o` (0 <= o < n_out) is the

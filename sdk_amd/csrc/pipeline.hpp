@@ -16,6 +16,7 @@ struct Workspace {
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
   hipEvent_t ev_class0 = nullptr;           // first chunk-parity class of a plane swept (pipe_split)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
+  hipEvent_t ev_even = nullptr;             // even subtree + reorientation done (main): expand_order 2
   bool right_pending = false;               // this query's fold operands are produced on stream2: join_right before use
   bool long_sweep_follows = false;          // hint for run_begin (set by the caller that knows the database)
   // CU-partitioned overlap (SPIRAL_CU_SPLIT = n > 0): the per-plane sweeps run on a stream masked to all but n CUs
@@ -57,6 +58,7 @@ struct Workspace {
   size_t h_packed_words = 0;
   DevBuf<u64> enc_out;       // response bits built on the device
   uint8_t* h_response = nullptr;
+  bool host_pinned = true;  // the three staging buffers above come from hipHostMalloc (false: malloc, debug switch ws_pinned)
   bool delta_tail = true;  // unfused fold levels use the delta form too (false: literal two-matrix form)
   int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
   bool zero_shortcuts = false;  // lib/server fold semantics (sparse buckets): set per query, every level fused

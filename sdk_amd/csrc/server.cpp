@@ -6,6 +6,7 @@
 #include "server.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cstdlib>
 #include <cstring>
 #include <functional>
@@ -24,7 +25,9 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
 // ---- tunables: sp_debug_set(name, v) overrides, else SPIRAL_<NAME> from the environment, else the default
 static std::mutex g_tun_mu;
 static std::vector<std::pair<std::string, long>> g_tun;
+static std::atomic<long> g_fresh_allocs{0};  // allocations seen by devbuf_fresh since poison_skip was last set
 void set_tunable(const char* name, long v) {
+  if (!strcmp(name, "poison_skip")) g_fresh_allocs = 0;
   std::lock_guard<std::mutex> lk(g_tun_mu);
   for (auto& kv : g_tun)
     if (kv.first == name) {
@@ -45,6 +48,91 @@ long tunable(const char* name, long dflt) {
   return e ? atol(e) : dflt;
 }
 
+void devbuf_fresh(void* p, size_t bytes) {
+  const long b = tunable("poison_ws", 0);
+  if (b <= 0 || !p || tunable("guard_ws", 0) > 0) return;
+  const long k = g_fresh_allocs.fetch_add(1);
+  const bool skip = tunable("poison_skip", -1) == k;
+  if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] alloc #%ld: %zu bytes%s\n", k, bytes, skip ? " (zeroed)" : "");
+  HIP_CHECK(hipMemset(p, skip ? 0 : (int)(b & 255), bytes));
+  HIP_CHECK(hipDeviceSynchronize());
+}
+void devbuf_cache_sync();
+bool devbuf_guards_on() { return tunable("guard_ws", 0) > 0; }
+void* devbuf_alloc(size_t bytes, size_t* guard, long* serial) {
+  const long g = tunable("guard_ws", 0);
+  const size_t gb = g > 0 ? ((size_t)g + 255) / 256 * 256 : 0;
+  void* q = nullptr;
+  const hipError_t e = hipMalloc(&q, bytes + 2 * gb);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    throw OomError(std::string("hipMalloc of ") + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+  }
+  *guard = gb;
+  *serial = -1;
+  if (gb) {
+    const long k = g_fresh_allocs.fetch_add(1);
+    *serial = k;
+    const bool skip = tunable("poison_skip", -1) == k;
+    const int fill = skip ? 0 : (int)(tunable("poison_ws", 0xA5) & 255);
+    if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] alloc #%ld: %zu bytes%s\n", k, bytes, skip ? " (guards zeroed)" : "");
+    HIP_CHECK(hipMemset(q, fill, gb));
+    HIP_CHECK(hipMemset((char*)q + gb + bytes, fill, gb));
+    HIP_CHECK(hipDeviceSynchronize());
+    q = (char*)q + gb;
+  }
+  devbuf_fresh(q, bytes);
+  // Fresh device memory is zero-filled and the device drained before the buffer is handed out (alloc_zero, default 1):
+  // no kernel of the library ever reads a word it did not write, but recycled pages hold whatever the previous owner
+  // (this process or an earlier tenant of the GPU) left there, and a defect of that kind would otherwise only show on
+  // some machines.  Allocation is off the query path (workspaces are allocated whole when they are created).
+  if (!gb && tunable("poison_ws", 0) <= 0 && tunable("alloc_zero", 1) != 0) {
+    HIP_CHECK(hipMemset(q, 0, bytes));
+    devbuf_cache_sync();
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  return q;
+}
+// alloc_cache_sync (diagnostic, default 0): a fresh allocation ends with k_cache_sync -- every XCD writes back and
+// invalidates its L2 (used while hunting the corruption that turned out to come from contiguous allocations,
+// profiles/r02_stale_reads.md).
+void devbuf_cache_sync() {
+  if (tunable("alloc_cache_sync", 0) != 0) launch_cache_sync(nullptr, 0);
+}
+void devbuf_free(void* p, size_t bytes, size_t guard, long serial) {
+  if (!p) return;
+  if (guard) {  // an out-of-bounds write shows as a guard byte that is neither the fill value nor zero-filled
+    (void)hipDeviceSynchronize();
+    std::vector<unsigned char> h(2 * guard);
+    if (hipMemcpy(h.data(), (char*)p - guard, guard, hipMemcpyDeviceToHost) == hipSuccess &&
+        hipMemcpy(h.data() + guard, (char*)p + bytes, guard, hipMemcpyDeviceToHost) == hipSuccess) {
+      const unsigned char f0 = h[guard - 1], f1 = h[2 * guard - 1];
+      long bad_pre = -1, bad_post = -1;
+      for (size_t i = 0; i < guard; i++)
+        if (h[i] != h[0]) { bad_pre = (long)(guard - i); break; }
+      for (size_t i = 0; i < guard; i++)
+        if (h[guard + i] != h[2 * guard - 1]) bad_post = (long)i;
+      (void)f0; (void)f1;
+      if (bad_pre >= 0 || bad_post >= 0)
+        fprintf(stderr, "[spiral] OUT-OF-BOUNDS WRITE around alloc #%ld (%zu bytes): %ld bytes before / up to +%ld bytes after\n",
+                serial, bytes, bad_pre, bad_post);
+    }
+    (void)hipGetLastError();
+  }
+  (void)hipFree((char*)p - guard);
+}
+
+extern thread_local int g_debug_stage;
+void h2d_sync(void* dst, const void* host, size_t bytes) {
+  if (bytes == 0) return;
+  HIP_CHECK(hipMemcpy(dst, host, bytes, hipMemcpyHostToDevice));
+  if (tunable("h2d_cache_sync", 0) != 0) launch_cache_sync(nullptr, 0);
+}
+void upload_words(void* dst, const void* host, size_t bytes) {
+  h2d_sync(dst, host, bytes);
+  HIP_CHECK(hipDeviceSynchronize());
+}
+
 static thread_local u64 g_paths = 0;
 void note_path(u64 bits) { g_paths |= bits; }
 u64 paths_taken(bool reset) {
@@ -56,6 +144,15 @@ void launched(u64 bits, const char* kernel) {
   g_paths |= bits;
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw HipError(std::string("launch of ") + kernel + " failed: " + hipGetErrorString(e));
+  // debug_sync: 1 = device-wide synchronisation after every launch (tells a race from a logic error); 11 / 12 / 13 =
+  // only after the launches of the expansion / sweep / fold-pack-encode stage; 2 = only at the stage boundaries (capi.cpp)
+  const long ds = tunable("debug_sync", 0);
+  if (ds == 1 || (ds > 10 && ds == 10 + g_debug_stage)) HIP_CHECK(hipDeviceSynchronize());
+}
+thread_local int g_debug_stage = 0;
+void debug_stage(int stage) {
+  g_debug_stage = stage;
+  if (tunable("debug_sync", 0) == 2) HIP_CHECK(hipDeviceSynchronize());
 }
 
 // ---------------------------------------------------------------------------------- ChaCha20
@@ -185,7 +282,7 @@ const DeviceState::PrunedPlan& DeviceState::pruned_plan(const Params& P, int j0,
   pl->rounds_even = build_round_plans(P, j0, nj, L, nullptr, 1);
   pl->rounds_odd = build_round_plans(P, j0, nj, L, nullptr, 2);
   pl->lists.alloc(std::max<size_t>(L.size(), 1));
-  if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!L.empty()) upload_words(pl->lists.p, L.data(), L.size() * sizeof(int));
   pruned.push_back(std::move(pl));
   return *pruned.back();
 }
@@ -199,7 +296,7 @@ std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P,
   pl->rounds_even = build_round_plans(P, 0, 0, L, &rows, 1);
   pl->rounds_odd = build_round_plans(P, 0, 0, L, &rows, 2);
   pl->lists.alloc(std::max<size_t>(L.size(), 1));
-  if (!L.empty()) HIP_CHECK(hipMemcpy(pl->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!L.empty()) upload_words(pl->lists.p, L.data(), L.size() * sizeof(int));
   return pl;
 }
 
@@ -207,7 +304,7 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
   auto D = std::make_unique<DeviceState>();
   D->device = device;
   D->tw.alloc(P.ntt_tables.size());
-  HIP_CHECK(hipMemcpy(D->tw.p, P.ntt_tables.data(), P.ntt_tables.size() * sizeof(u32), hipMemcpyHostToDevice));
+  upload_words(D->tw.p, P.ntt_tables.data(), P.ntt_tables.size() * sizeof(u32));
   D->T.tw = D->tw.p;
   D->T.c = P.dc;
   const size_t g = P.expand_queries ? P.g() : 0;
@@ -219,7 +316,7 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
     std::vector<u64> raw(std::max<size_t>(g, 1) * POLY_LEN, 0);
     for (size_t r = 0; r < g && r < POLY_LEN_LOG2; r++) raw[r * POLY_LEN + (POLY_LEN - ((size_t)1 << r))] = P.modulus - 1;
     DevBuf<u64> d_raw(raw.size());
-    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    h2d_sync(d_raw.p, raw.data(), raw.size() * 8);
     D->neg1.alloc(std::max<size_t>(g, 1) * 2 * POLY_LEN);
     FwdDesc f{d_raw.p, nullptr, D->neg1.p, (int)g, 1, 1, 1, 64, 1, 0, 1};
     launch_ntt_fwd(D->T, f, 0);
@@ -235,7 +332,7 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
         raw[(i * cols + (i + j * 2)) * POLY_LEN] = 1ULL << (bits * j);
       }
     DevBuf<u64> d_raw(raw.size());
-    HIP_CHECK(hipMemcpy(d_raw.p, raw.data(), raw.size() * 8, hipMemcpyHostToDevice));
+    h2d_sync(d_raw.p, raw.data(), raw.size() * 8);
     D->gadget_gsw.alloc(2 * cols * 2 * POLY_LEN);
     FwdDesc f{d_raw.p, nullptr, D->gadget_gsw.p, (int)(2 * cols), 1, 1, 1, 64, 1, 0, 1};
     launch_ntt_fwd(D->T, f, 0);
@@ -311,7 +408,7 @@ static std::unique_ptr<DeviceState> build_device_state(const Params& P, int devi
     D->v1_sum_dst = put(sd); D->v1_sum_a = put(sa); D->v1_sum_b = put(sb);
   }
   D->lists.alloc(std::max<size_t>(L.size(), 1));
-  if (!L.empty()) HIP_CHECK(hipMemcpy(D->lists.p, L.data(), L.size() * sizeof(int), hipMemcpyHostToDevice));
+  if (!L.empty()) upload_words(D->lists.p, L.data(), L.size() * sizeof(int));
   return D;
 }
 
@@ -341,7 +438,17 @@ std::unique_ptr<Workspace> sp_params::acquire_ws() {
         return w;
       }
   }
-  return std::make_unique<Workspace>(p, device_state());
+  // A new workspace gets every buffer of the expanded-query flow NOW (sizes depend on the parameters only) and the
+  // device is drained afterwards: no hipMalloc / hipFree happens while kernels of a query are in flight, and the
+  // first query of a workspace costs what the later ones cost.  (Direct-upload and sparse flows size theirs later.)
+  auto w = std::make_unique<Workspace>(p, device_state());
+  if (tunable("ws_prealloc", 1) != 0) {
+    if (p.expand_queries) w->ensure_expand();
+    w->ensure_sweep();
+    w->ensure_finish();
+    HIP_CHECK(hipDeviceSynchronize());
+  }
+  return w;
 }
 
 void sp_params::release_ws(std::unique_ptr<Workspace> ws) {
@@ -362,29 +469,44 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   HIP_CHECK(hipEventCreateWithFlags(&ev_round0, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_class0, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_right, hipEventDisableTiming));
+  HIP_CHECK(hipEventCreateWithFlags(&ev_even, hipEventDisableTiming));
   ev_plane.resize(P.planes());
   for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
   for (auto& e : ev_sw) HIP_CHECK(hipEventCreate(&e));
-  HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
   h_packed_words = P.instances * (P.n + 1) * P.n * POLY_LEN;
-  HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
-  HIP_CHECK(hipHostMalloc((void**)&h_response, P.response_bytes() + 16, hipHostMallocDefault));
+  host_pinned = tunable("ws_pinned", 1) != 0;  // 0 (debug): pageable host staging, copies become synchronous
+  if (host_pinned) {
+    HIP_CHECK(hipHostMalloc((void**)&h_query, 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&h_packed, h_packed_words * sizeof(u64), hipHostMallocDefault));
+    HIP_CHECK(hipHostMalloc((void**)&h_response, P.response_bytes() + 16, hipHostMallocDefault));
+  } else {
+    h_query = (u64*)malloc(2 * POLY_LEN * sizeof(u64));
+    h_packed = (u64*)malloc(h_packed_words * sizeof(u64));
+    h_response = (uint8_t*)malloc(P.response_bytes() + 16);
+    if (!h_query || !h_packed || !h_response) throw OomError("host staging allocation failed");
+  }
   enc_out.alloc(P.response_bytes() / 8 + 2);
   q_raw.alloc(2 * POLY_LEN);
   fused_min_pairs = tunable("fused_min_pairs", 256);
 }
 
 Workspace::~Workspace() {
-  if (h_query) (void)hipHostFree(h_query);
-  if (h_packed) (void)hipHostFree(h_packed);
-  if (h_response) (void)hipHostFree(h_response);
+  if (host_pinned) {
+    if (h_query) (void)hipHostFree(h_query);
+    if (h_packed) (void)hipHostFree(h_packed);
+    if (h_response) (void)hipHostFree(h_response);
+  } else {
+    free(h_query);
+    free(h_packed);
+    free(h_response);
+  }
   for (auto& e : ev)
     if (e) (void)hipEventDestroy(e);
   for (auto& e : ev_plane)
     if (e) (void)hipEventDestroy(e);
   if (ev_fold) (void)hipEventDestroy(ev_fold);
-  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right, ev_class0})
+  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right, ev_even, ev_class0})
     if (e) (void)hipEventDestroy(e);
   if (s_sweep) (void)hipStreamDestroy(s_sweep);
   if (s_fold) (void)hipStreamDestroy(s_fold);
@@ -437,6 +559,7 @@ void Workspace::ensure_expand() {
   qv.ensure(POLY_LEN * p.dim0() * 2);
   const size_t nb = p.db_dim_2 * p.t_gsw;
   fold_mats.ensure(std::max<size_t>(p.db_dim_2, 1) * 2 * 4 * p.t_gsw * 2 * POLY_LEN);
+  if (p.db_dim_2 > 0 && fused_fold_supported(p)) fold_mats_w.ensure(p.db_dim_2 * 2 * 4 * p.t_gsw * 2 * POLY_LEN);  // run_mats_to_wave
   gsw_raw.ensure(std::max<size_t>(nb, 1) * 2 * POLY_LEN);
   gsw_dig.ensure(std::max<size_t>(nb, 1) * 2 * p.t_conv * 2 * POLY_LEN);
 }
@@ -806,16 +929,32 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
     }
     run_coefficient_expansion(W, pp, 1, pl, 0, 0);
     HIP_CHECK(hipEventRecord(W.ev_round0, s));
-    HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_round0, 0));
-    on_stream(W, W.stream2, [&] {
-      run_coefficient_expansion(W, pp, g, pl, 2, 1);
-      run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-      run_folding_neg(W);
-    });
-    HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
-    W.right_pending = true;
+    // Enqueue order (expand_order; measured at C2, profiles/r02_expand_order.md).  0 (default): the odd side is queued
+    // first and starts after round 0, beside the even side: 10.95 ms per query.  1: the even side (the critical path:
+    // the first sweep waits for it) is queued first, the odd side still starts after round 0: expansion 0.74 -> 0.62 ms
+    // but the sweeps lose more than that (11.5 ms).  2: the odd side starts when the even side is done, i.e. it runs
+    // beside the first plane's sweep only: expansion 0.49 ms, sweep span +0.22 ms, 10.93 ms -- the odd side's ~0.2 ms
+    // of work costs the same wherever it runs, so the order is left as it was.
+    const long order = tunable("expand_order", 0);
+    auto odd_side = [&](hipEvent_t after) {
+      HIP_CHECK(hipStreamWaitEvent(W.stream2, after, 0));
+      on_stream(W, W.stream2, [&] {
+        run_coefficient_expansion(W, pp, g, pl, 2, 1);
+        run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+        run_folding_neg(W);
+      });
+      HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
+      W.right_pending = true;
+    };
+    if (order == 0) odd_side(W.ev_round0);
     run_coefficient_expansion(W, pp, g, pl, 1, 1);
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+    if (order == 2) {
+      HIP_CHECK(hipEventRecord(W.ev_even, s));
+      odd_side(W.ev_even);
+    } else if (order != 0) {
+      odd_side(W.ev_round0);
+    }
     return;
   }
   run_coefficient_expansion(W, pp, g, pl);

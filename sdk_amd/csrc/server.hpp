@@ -33,48 +33,61 @@ void hip_check(hipError_t e, const char* what, const char* file, int line);
 #define HIP_CHECK(x) ::spiral::hip_check((x), #x, __FILE__, __LINE__)
 u64 paths_taken(bool reset);
 void set_tunable(const char* name, long v);  // thread-local PathBit mask accumulated by launched() / note_path()
+// Debug hook called on every fresh DevBuf allocation (server.cpp): SPIRAL_POISON_WS / sp_debug_set("poison_ws", b)
+// fills the buffer with byte b (1..255) so that a read of never-written device memory shows up deterministically
+// instead of depending on what the pages held before; "poison_skip" = k leaves the k-th allocation since the
+// switch was set zero-filled instead (bisection of the offending buffer).  Off (0) by default: no cost.
+void devbuf_fresh(void* p, size_t bytes);
+// Allocation behind DevBuf (server.cpp).  guard_ws = g > 0 (debug): every buffer gets g bytes of guard region on either
+// side, filled with the poison byte (zero for allocation number poison_skip): an out-of-bounds READ then returns the
+// same garbage in every run instead of whatever the neighbouring allocation holds, and an out-of-bounds WRITE is
+// reported when the buffer is released.  Throws OomError.
+void* devbuf_alloc(size_t bytes, size_t* guard, long* serial);
+void devbuf_free(void* p, size_t bytes, size_t guard, long serial);
+bool devbuf_guards_on();
+void devbuf_cache_sync();
 
 // RAII device buffer
 template <typename T>
 struct DevBuf {
   T* p = nullptr;
   size_t n = 0;
+  size_t guard = 0;  // bytes of guard region on either side of the buffer (debug: guard_ws)
+  long serial = -1;  // allocation number (debug)
   DevBuf() {}
   explicit DevBuf(size_t count) { alloc(count); }
   DevBuf(const DevBuf&) = delete;
   DevBuf& operator=(const DevBuf&) = delete;
-  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n) { o.p = nullptr; o.n = 0; }
+  DevBuf(DevBuf&& o) noexcept : p(o.p), n(o.n), guard(o.guard), serial(o.serial) { o.p = nullptr; o.n = 0; o.guard = 0; }
   DevBuf& operator=(DevBuf&& o) noexcept {
-    if (this != &o) { release(); p = o.p; n = o.n; o.p = nullptr; o.n = 0; }
+    if (this != &o) { release(); p = o.p; n = o.n; guard = o.guard; serial = o.serial; o.p = nullptr; o.n = 0; o.guard = 0; }
     return *this;
   }
   ~DevBuf() { release(); }
   void alloc(size_t count) {
     release();
     if (count == 0) return;
-    void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T));
-    if (e != hipSuccess) {
-      (void)hipGetLastError();
-      throw OomError(std::string("hipMalloc of ") + std::to_string(count * sizeof(T)) + " bytes failed: " + hipGetErrorString(e));
-    }
+    void* q = devbuf_alloc(count * sizeof(T), &guard, &serial);
     p = (T*)q;
     n = count;
   }
-  // Large streaming buffers (the database): ask for PHYSICALLY CONTIGUOUS device memory first.  How a plain hipMalloc of
-  // tens of GiB is backed is a lottery (the physical pages the driver happens to have): the same read stream runs at
-  // 6.7-7.07 TB/s depending on the process, while a contiguous allocation gave 7.05-7.08 TB/s in every run
-  // (scripts/ubench/hbm_map.hip, profiles/r02_sweep_experiments.md).  Falls back to hipMalloc.
+  // Large streaming buffers (the database).  want_contiguous (switch db_contiguous, OFF by default) asks for PHYSICALLY
+  // CONTIGUOUS device memory first: how a plain hipMalloc of tens of GiB is backed is a lottery (the same read stream runs
+  // at 6.7-7.07 TB/s depending on the process, a contiguous allocation gave 7.05-7.08 TB/s in every run:
+  // scripts/ubench/hbm_map.hip, profiles/r02_sweep_experiments.md) -- but the driver makes room for such a range by
+  // moving other live buffers, and their contents did not survive that on every machine (profiles/r02_stale_reads.md).
   void alloc_streaming(size_t count, bool want_contiguous) {
     release();
     if (count == 0) return;
-    if (want_contiguous) {
+    if (want_contiguous && !devbuf_guards_on()) {
       void* q = nullptr;
-      const hipError_t e = hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocContiguous);
+      const hipError_t e = hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocContiguous);  // see db_create_impl: unsafe
       if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] contiguous allocation of %zu bytes: %s\n", count * sizeof(T), hipGetErrorName(e));
       if (e == hipSuccess && q) {
         p = (T*)q;
         n = count;
+        devbuf_cache_sync();
+        (void)hipDeviceSynchronize();
         return;
       }
       (void)hipGetLastError();
@@ -82,9 +95,15 @@ struct DevBuf {
     alloc(count);
   }
   void ensure(size_t count) { if (count > n) alloc(count); }
-  void release() { if (p) { (void)hipFree(p); p = nullptr; n = 0; } }
+  void release() { if (p) { devbuf_free(p, n * sizeof(T), guard, serial); p = nullptr; n = 0; guard = 0; serial = -1; } }
   size_t bytes() const { return n * sizeof(T); }
 };
+
+// Synchronous host -> device upload of resident data (tables, index lists), device drained afterwards.
+void upload_words(void* dst, const void* host, size_t bytes);
+// Synchronous host -> device copy; h2d_cache_sync = 1 (diagnostic, default 0) adds k_cache_sync on the null stream:
+// every XCD writes back and invalidates its L2 (profiles/r02_stale_reads.md).
+void h2d_sync(void* dst, const void* host, size_t bytes);
 
 // ChaCha20 keystream as rand_chacha 0.3.1's ChaCha20Rng::from_seed produces it (key = seed, 64-bit
 // block counter from 0, stream 0); u64 = two consecutive u32 words, low first (client.rs:47-49).
