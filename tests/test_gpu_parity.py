@@ -108,6 +108,29 @@ def test_automorph_and_gadget(sp, oracle_mod):
         assert (g == o.gadget_invert_rdim(inp, rows_in, 1, rows_out, rdim)).all(), (rows_out, rdim)
 
 
+def test_resident_data_survive_database_allocation(sp, oracle_mod):
+    """The public parameters and tables of a handle are device buffers that exist BEFORE its database is allocated:
+    they must be the same bytes afterwards.  (A physically contiguous database allocation made the driver move them
+    and changed their contents on some machines, profiles/r02_stale_reads.md -- the switch db_contiguous is off.)
+    Kernels (through the caches) and a device-to-host copy must also see the same resident data."""
+    import ctypes as C
+    for cfg, seed in ((FAST, 41), (dict(FAST, nu_2=1), 42), (P2, 43)):
+        o, cl, pp, q = _session(oracle_mod, cfg, 5, seed)
+        flat = o.pp_deserialize_flat(pp)
+        p = sp.Params(cfg)
+        gpp = sp.PublicParameters.deserialize(p, pp)
+        assert (gpp.export() == flat).all()
+        gdb = sp.Database(p).fill_synthetic(0x1234 + seed)
+        assert (gpp.export() == flat).all(), "public parameters changed while the database was allocated"
+        out = (C.c_uint64 * 24)()
+        assert sp.lib().sp_debug_resident_check(C.c_void_p(p.h), C.c_void_p(gpp.h), out, 24) == 0
+        for i, name in enumerate(("tw", "neg1", "gadget", "lists", "pp.all", "pp.pack_cat")):
+            kernel_view, copy_view, after_sync, host = out[4 * i], out[4 * i + 1], out[4 * i + 2], out[4 * i + 3]
+            assert kernel_view == copy_view == after_sync, name
+            assert host == 0 or host == copy_view, name
+        del gdb
+
+
 # ------------------------------------------------------------------------------------ stages
 def _session(oracle_mod, cfg, idx, seed):
     o = oracle_mod.Params(cfg)
