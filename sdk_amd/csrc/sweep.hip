@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
 // CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
 // LDS stay free for the fold kernels running concurrently on the second stream.
 template <int U>
-__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio) {
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio, int spread) {
   // the sweep is a latency-bound load stream using ~20 % of the VALU slots: when fold kernels share the CU its
   // waves must win instruction arbitration or the loads in flight (and the HBM rate) drop
   if (hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -200,19 +200,23 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
     u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
     for (int jb = 0; jb < npairs; jb += 128) {
       const int je = min(jb + 128, npairs);
-      for (int jp0 = jb; jp0 < je; jp0 += U) {
+      // spread (sweep_spread, needs (je - jb) % U == 0): the U row pairs a wave has in flight come from U sub-streams of
+      // the block, (je - jb) / U row pairs (56 KiB at U = 4) apart, instead of U adjacent 1792-byte pieces: four times as
+      // many independent address streams over the memory channels.  The sums are order-independent (exact integers).
+      const int sub = spread ? (je - jb) / U : 1, step = spread ? 1 : U;
+      for (int jp0 = jb; jp0 < (spread ? jb + sub : je); jp0 += step) {
         u32x4_t va[U];
         u32x3_t vb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          const int jp = min(jp0 + u, je - 1);
+          const int jp = min(jp0 + u * sub, je - 1);
           const u32* uu = base + (size_t)jp * ustride;
           va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(uu + lane * 4));
           vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(uu + 256 + lane * 3));
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          const int jp = jp0 + u;
+          const int jp = jp0 + u * sub;
           if (jp < je) {
             const u32 d0 = va[u].x, d1 = va[u].y, d2 = va[u].z, d3 = va[u].w, d4 = vb[u].x, d5 = vb[u].y, d6 = vb[u].z;
             const uint4 qa = qrow[2 * jp];
@@ -243,11 +247,15 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
   const int units = d.planes * N * ((d.num_per >> 7) / (d.chunk_step == 2 ? 2 : 1));
   const dim3 grid((unsigned)std::min(n_cus * wgs_per_cu, (units + 3) / 4));
   const int prio = (int)tunable("sweep_prio", 1);
+  const int npairs = d.nj >> 1;
+  const int u_eff = unroll == 1 || unroll == 2 || unroll == 8 ? unroll : 4;
+  // every 128-row-pair block (and the ragged last one) must split evenly into the U sub-streams
+  const int spread = tunable("sweep_spread", 0) != 0 && (npairs % 128) % u_eff == 0 && (128 % u_eff) == 0 ? 1 : 0;
   switch (unroll) {
-    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio); break;
-    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio); break;
-    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio); break;
-    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio); break;
+    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
+    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
   }
   launched(PATH_SWEEP_PERSIST | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_persist");
 }
