@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) 
 // CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
 // LDS stay free for the fold kernels running concurrently on the second stream.
 template <int U>
-__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio, int spread) {
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio, int spread, int zmul) {
   // the sweep is a latency-bound load stream using ~20 % of the VALU slots: when fold kernels share the CU its
   // waves must win instruction arbitration or the loads in flight (and the HBM rate) drop
   if (hi_prio) __builtin_amdgcn_s_setprio(3);
@@ -192,7 +192,10 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;  // one chunk-parity class or all chunks
   for (int unit = wave0; unit < units; unit += nwaves) {
     const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
-    const int zp = unit / chunks_l;
+    // zmul (sweep_zmul, odd; 1 = identity): the z-rows are visited in the order z * zmul mod N, so that the units in flight
+    // at one time are spread over the whole plane instead of one contiguous window of it (the chunks of a z stay together)
+    const int zp_lin = unit / chunks_l;
+    const int zp = (zp_lin & ~(N - 1)) | ((zp_lin * zmul) & (N - 1));
     const int z = zp & (N - 1);
     const int plane = zp >> POLY_LEN_LOG2;
     const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);
@@ -251,11 +254,12 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
   const int u_eff = unroll == 1 || unroll == 2 || unroll == 8 ? unroll : 4;
   // every 128-row-pair block (and the ragged last one) must split evenly into the U sub-streams
   const int spread = tunable("sweep_spread", 0) != 0 && (npairs % 128) % u_eff == 0 && (128 % u_eff) == 0 ? 1 : 0;
+  const int zmul = (int)(tunable("sweep_zmul", 1) | 1);
   switch (unroll) {
-    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
-    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
-    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
-    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio, spread); break;
+    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
+    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
+    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
+    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
   }
   launched(PATH_SWEEP_PERSIST | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_persist");
 }
