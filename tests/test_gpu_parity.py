@@ -971,6 +971,34 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
 
 
+@pytest.mark.parametrize("order", ["1", "2"])
+@pytest.mark.parametrize("ci", [0, 4, 11])
+def test_expansion_enqueue_order_parity(sp, oracle_mod, monkeypatch, ci, order):
+    """SPIRAL_EXPAND_ORDER (profiles/r02_expand_order.txt; default 0): with the odd subtree on the second stream, the even
+    subtree may be queued first (1) or the odd side may start only when the even side is done (2).  Pure scheduling:
+    expand_query and the response must not change."""
+    cfg = _FUZZ[ci]
+    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1")
+    monkeypatch.setenv("SPIRAL_EXPAND_ORDER", order)
+    o = oracle_mod.Params(cfg)
+    idx = (419 * (ci + 1)) % o.num_items
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(90 + ci)
+    q = cl.generate_query(idx, 190 + ci)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(idx)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    sp.paths_taken()
+    v_reg, v_fold = sp.expand_query(p, gpp, q)
+    assert "expand_split" in sp.paths_taken()
+    e_reg, e_fold = o.expand_query(pp, q)
+    assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
+    expect = o.process_query(pp, q, db)
+    assert sp.process_query(p, gpp, q, gdb) == expect
+    assert sp.process_query(p, gpp, q, gdb) == expect    # the same workspace again (join of the previous odd side)
+
+
 @pytest.mark.parametrize("mode", ["split", "split+fused"])
 @pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
 def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
