@@ -101,21 +101,20 @@ void devbuf_cache_sync() {
 }
 void devbuf_free(void* p, size_t bytes, size_t guard, long serial) {
   if (!p) return;
-  if (guard) {  // an out-of-bounds write shows as a guard byte that is neither the fill value nor zero-filled
+  if (guard) {
+    // every guard byte still equals the byte farthest from the buffer (the fill value) unless something wrote there
     (void)hipDeviceSynchronize();
     std::vector<unsigned char> h(2 * guard);
     if (hipMemcpy(h.data(), (char*)p - guard, guard, hipMemcpyDeviceToHost) == hipSuccess &&
         hipMemcpy(h.data() + guard, (char*)p + bytes, guard, hipMemcpyDeviceToHost) == hipSuccess) {
-      const unsigned char f0 = h[guard - 1], f1 = h[2 * guard - 1];
-      long bad_pre = -1, bad_post = -1;
+      long first_before = -1, last_after = -1;  // distance from the buffer, in bytes
       for (size_t i = 0; i < guard; i++)
-        if (h[i] != h[0]) { bad_pre = (long)(guard - i); break; }
+        if (h[i] != h[0]) { first_before = (long)(guard - i); break; }
       for (size_t i = 0; i < guard; i++)
-        if (h[guard + i] != h[2 * guard - 1]) bad_post = (long)i;
-      (void)f0; (void)f1;
-      if (bad_pre >= 0 || bad_post >= 0)
-        fprintf(stderr, "[spiral] OUT-OF-BOUNDS WRITE around alloc #%ld (%zu bytes): %ld bytes before / up to +%ld bytes after\n",
-                serial, bytes, bad_pre, bad_post);
+        if (h[guard + i] != h[2 * guard - 1]) last_after = (long)i;
+      if (first_before >= 0 || last_after >= 0)
+        fprintf(stderr, "[spiral] OUT-OF-BOUNDS WRITE around alloc #%ld (%zu bytes): reaches %ld bytes before / %ld bytes after\n",
+                serial, bytes, first_before, last_after);
     }
     (void)hipGetLastError();
   }
