@@ -121,7 +121,23 @@ def cpu_baseline(cfg_name, cfg):
     rng = np.random.default_rng(5)
 
     def rand_words(n):   # residues < 2^28 in both limbs (the MAC loops are data independent)
-        return rng.integers(0, 1 << 28, n, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
+        blk = min(n, 1 << 25)
+        block = rng.integers(0, 1 << 28, blk, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
+        if blk == n:
+            return block
+        out = np.empty(n, dtype=np.uint64)   # a 256 MiB random block repeated: real memory traffic, quick to build
+        for i in range(0, n, blk):
+            out[i:i + blk] = block[:min(blk, n - i)]
+        return out
+
+    def mem_available_gib():
+        try:
+            for ln in open("/proc/meminfo"):
+                if ln.startswith("MemAvailable"):
+                    return int(ln.split()[1]) / 2**20
+        except OSError:
+            pass
+        return 0.0
 
     def one(name, c, full):
         o = oracle.Params(c)
@@ -135,8 +151,12 @@ def cpu_baseline(cfg_name, cfg):
         t_expand = time.time() - t0
         # full: every z-row of every plane and the whole fold tree of every plane are executed (no scaling);
         # sampled: nz rows of one plane / a subtree, scaled by row count, step count and planes
-        nz = N if full else max(1, min(N, (1 << 25) // (num_per * dim0)))
-        nz1 = nz if full else min(nz, 32)
+        # sampled configurations: ONE WHOLE PLANE of the sweep is executed un-sampled in both modes when the host has the
+        # memory for it (16 GiB of words at C2), else 2^25 words' worth of z-rows
+        plane_gib = N * num_per * dim0 * 8 / 2**30
+        whole_plane = (not full) and mem_available_gib() > 2.5 * plane_gib + 8
+        nz = N if (full or whole_plane) else max(1, min(N, (1 << 25) // (num_per * dim0)))
+        nz1 = nz if (full or whole_plane) else min(nz, 32)
         reps = planes if full else 1
         dbs = rand_words(nz * num_per * dim0)
         t0 = time.time()
@@ -165,7 +185,7 @@ def cpu_baseline(cfg_name, cfg):
             how = ("every z-row of all %d planes and the whole fold tree of every plane executed (random residues as "
                    "database words), nothing scaled; pack/encode omitted (<1%%)" % planes)
         else:
-            how = ("sweep: %d of %d z-rows of one plane (AVX2, %d threads) / %d rows (scalar u128, 1 thread), x%d planes; "
+            how = ("sweep: %d of %d z-rows of one plane (AVX2, %d threads) / %d of them (scalar u128, 1 thread), x%d planes; "
                    "fold: %d-leaf subtree over %d threads / %d-leaf subtree on 1 thread, scaled to %d leaves x %d planes; "
                    "expand_query + get_v_folding_neg in full; pack/encode omitted (<1%%)" %
                    (nz, N, threads, nz1, planes, 1 << ka, threads, 1 << k1, num_per, planes))
@@ -208,7 +228,11 @@ def main():
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
-    os.environ.setdefault("OMP_NUM_THREADS", str(min(64, os.cpu_count() or 1)))   # cpu_baseline: every core
+    try:   # cpu_baseline: every CPU this process may run on
+        n_cpus = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        n_cpus = os.cpu_count() or 1
+    os.environ.setdefault("OMP_NUM_THREADS", str(n_cpus))
     import torch
     import torch.distributed as dist
     import sdk_amd as sp
@@ -336,6 +360,16 @@ def main():
             if rank == 0:
                 print("bench: the stream-ordered multi-GPU flow DISAGREED with the synchronised flow; timing the latter",
                       file=sys.stderr, flush=True)
+    batch_selfcheck = None
+    if mode in ("single", "replicas") and batch > 1:
+        # the batched entry point must answer every query exactly as the one-at-a-time path does (that path is compared
+        # byte for byte with the oracle at this size by tests/test_gpu_fullsize.py); checked before timing, loudly
+        outs = sp.process_query_batch(p, pp, [queries[k % len(queries)] for k in range(batch)], db)
+        single = [sp.process_query(p, pp, queries[k % len(queries)], db) for k in range(min(batch, len(queries)))]
+        batch_selfcheck = "ok" if all(outs[k] == single[k % len(single)] for k in range(batch)) else "MISMATCH"
+        if batch_selfcheck != "ok":
+            print("bench[rank %d]: batched responses DIFFER from the single-query path" % rank, file=sys.stderr, flush=True)
+            raise SystemExit(3)
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -366,6 +400,23 @@ def main():
     else:                                                     # 1, or one per plane when the fold is overlapped
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters), run.sweep_launches(db)
     run.free()
+    batch_pass = None
+    if mode in ("single", "replicas") and batch > 1:
+        runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 8))]
+        sp.paths_taken()
+        pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
+        taken = sp.paths_taken()
+        for r in runs:
+            r.free()
+        N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
+        pass_bytes = db.device_bytes() + len(runs) * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
+        batch_pass = {"kernel": "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % len(runs),
+                      "queries_per_pass": len(runs), "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
+                      "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                      "note": "one pass over the whole resident database for the whole group (sp_bench_sweep_batch, HIP events "
+                              "on the launch stream): PACKED database + %d query slices + %d x u32 outputs; the outputs "
+                              "(%.0f MB per pass) are HBM WRITES, which cost 3-4x a read byte when mixed into the read stream "
+                              "on this part (scripts/ubench/rw_mix.hip)" % (len(runs), len(runs), len(runs) * T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4 / 1e6)}
     shards = world if sharded else 1
     alg_bytes = sweep_algorithmic_bytes(cfg, shards) / launches
     moved_bytes = sweep_moved_bytes(cfg, shards, db.device_bytes()) / launches
@@ -417,6 +468,7 @@ def main():
             "mode": mode,
             "rccl_ranks": dist.get_world_size() if use_dist else 1,
             "overlap_selfcheck": selfcheck,
+            "batch_selfcheck": batch_selfcheck,
             "per_rank": per_rank,
             "config": {"arithmetic": "exact integers: u32 x u32 -> u64 multiply-accumulate mod two 28-bit primes, u32 NTT "
                                      "butterflies (Shoup), no floating point",
@@ -446,6 +498,8 @@ def main():
                                  "query slice + u32 outputs; equals the PMC-measured traffic) / average duration of a "
                                  "sweep launch; peak = HBM3E spec; a plain device copy reaches ~6300 GB/s on this part"},
         }
+        if batch_pass is not None:
+            line["roofline"]["batched_pass"] = batch_pass
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         else:

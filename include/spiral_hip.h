@@ -287,6 +287,11 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
 /* per_plane_launches: 1 = one launch per plane (what sp_query_sweep_scatter_plane issues), 0 = one launch,
  * -1 = what sp_query_sweep would do for this db (sp_bench_sweep). */
 int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane_launches, float* ms_per_launch);
+/* The same for the BATCHED pass of sp_process_query_batch (BASELINE configs[4]): the `batch` (<= 8) begun queries `qs`
+ * share database passes exactly as a group of sp_process_query_batch does (query digit table + k_sweep_mfma_batch on
+ * the matrix cores from 4 queries, k_sweep_packed_batch below; one launch over all planes); returns average
+ * milliseconds per PASS.  The queries' partial buffers hold the pass's outputs afterwards. */
+int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, int iters, float* ms_per_pass);
 
 /* Diagnostics: where workgroups land.  `blocks` 64-thread workgroups are launched on a stream whose CU mask has bits
  * [bit_lo, bit_hi) set (no mask when bit_hi <= bit_lo); out2[2b] = HW_REG_XCC_ID, out2[2b+1] = HW_REG_HW_ID of
@@ -315,6 +320,12 @@ int sp_from_ntt(const sp_params_t*, const uint64_t* ntt, uint64_t* out, size_t c
 int sp_multiply(const sp_params_t*, const uint64_t* a, size_t ar, size_t ac, const uint64_t* b, size_t bc,
                 uint64_t* res);
 /* poly.rs:539-551 automorph on `count` raw polys (x -> x^t, sign flip Q - a, Q for a == 0) */
+/* poly.rs:483-498 add, :500-512 add_into, :575-588 scalar_multiply over `count` NTT polynomials (2 * 2048 words each;
+ * `scalar` is one polynomial): res = a + b; res += a; res = scalar * b, all pointwise mod the two primes.  The reference's
+ * add does not re-reduce a sum below 2 q of canonical inputs differently from these: inputs are reduced mod q first. */
+int sp_add(const sp_params_t*, const uint64_t* a, const uint64_t* b, size_t count, uint64_t* res);
+int sp_add_into(const sp_params_t*, uint64_t* res, const uint64_t* a, size_t count);
+int sp_scalar_multiply(const sp_params_t*, const uint64_t* scalar, const uint64_t* b, size_t count, uint64_t* res);
 int sp_automorph(const sp_params_t*, const uint64_t* a, size_t count, size_t t, uint64_t* res);
 /* gadget.rs:34-60 gadget_invert_rdim followed by to_ntt_no_reduce is what the pipeline uses; this
  * export returns the raw digits: inp[rows_in x cols] -> out[rows_out x cols] */

@@ -189,6 +189,29 @@ class Params:
         lib().orc_multiply(_vp(self.h), _p(a), _u64(ar), _u64(ac), _p(b), _u64(bc), _p(res))
         return res
 
+    def add(self, a, b):
+        """poly.rs:483-498 over flat NTT polynomials"""
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        res = np.zeros(a.size, dtype=np.uint64)
+        lib().orc_add(_vp(self.h), _p(a), _p(b), _u64(a.size // self.ntt_words), _p(res))
+        return res
+
+    def add_into(self, res, a):
+        """poly.rs:500-512"""
+        res = np.ascontiguousarray(res, dtype=np.uint64).copy()
+        a = np.ascontiguousarray(a, dtype=np.uint64)
+        lib().orc_add_into(_vp(self.h), _p(res), _p(a), _u64(a.size // self.ntt_words))
+        return res
+
+    def scalar_multiply(self, scalar, b):
+        """poly.rs:575-588: (1x1 NTT polynomial) * every polynomial of b"""
+        scalar = np.ascontiguousarray(scalar, dtype=np.uint64)
+        b = np.ascontiguousarray(b, dtype=np.uint64)
+        res = np.zeros(b.size, dtype=np.uint64)
+        lib().orc_scalar_multiply(_vp(self.h), _p(scalar), _p(b), _u64(b.size // self.ntt_words), _p(res))
+        return res
+
     def automorph(self, a, t):
         a = np.ascontiguousarray(a, dtype=np.uint64)
         res = np.zeros_like(a)

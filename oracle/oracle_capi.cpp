@@ -165,6 +165,25 @@ void orc_multiply(void* h, const uint64_t* a, uint64_t ar, uint64_t ac, const ui
   multiply(R, A, B);
   memcpy(res, R.data.data(), R.data.size() * 8);
 }
+// res = a + b over `count` NTT polynomials (poly.rs:483-498); res = scalar (1x1) * b (poly.rs:575-588)
+void orc_add(void* h, const uint64_t* a, const uint64_t* b, uint64_t count, uint64_t* res) {
+  const Params* p = (Params*)h;
+  PolyMatrixNTT A = ntt_from_flat(p, count, 1, a), B = ntt_from_flat(p, count, 1, b), R(p, count, 1);
+  add(R, A, B);
+  memcpy(res, R.data.data(), R.data.size() * 8);
+}
+void orc_add_into(void* h, uint64_t* res, const uint64_t* a, uint64_t count) {
+  const Params* p = (Params*)h;
+  PolyMatrixNTT R = ntt_from_flat(p, count, 1, res), A = ntt_from_flat(p, count, 1, a);
+  add_into(R, A);
+  memcpy(res, R.data.data(), R.data.size() * 8);
+}
+void orc_scalar_multiply(void* h, const uint64_t* scalar, const uint64_t* b, uint64_t count, uint64_t* res) {
+  const Params* p = (Params*)h;
+  PolyMatrixNTT S = ntt_from_flat(p, 1, 1, scalar), B = ntt_from_flat(p, count, 1, b), R(p, count, 1);
+  scalar_multiply(R, S, B);
+  memcpy(res, R.data.data(), R.data.size() * 8);
+}
 void orc_automorph(void* h, const uint64_t* a, uint64_t count, uint64_t t, uint64_t* res) {
   const Params* p = (Params*)h;
   PolyMatrixRaw A = raw_from_flat(p, count, 1, a), R(p, count, 1);

@@ -148,6 +148,8 @@ pub mod sys {
         pub fn sp_bench_sweep(q: *mut sp_query_t, db: *const sp_db_t, iters: c_int, ms_per_launch: *mut f32) -> c_int;
         pub fn sp_bench_sweep_ex(q: *mut sp_query_t, db: *const sp_db_t, iters: c_int, per_plane_launches: c_int,
                                  ms_per_launch: *mut f32) -> c_int;
+        pub fn sp_bench_sweep_batch(qs: *const *mut sp_query_t, batch: c_int, db: *const sp_db_t, iters: c_int,
+                                    ms_per_pass: *mut f32) -> c_int;
         pub fn sp_debug_cu_probe(bit_lo: c_int, bit_hi: c_int, blocks: c_int, out2: *mut u32) -> c_int;
         pub fn sp_debug_resident_check(params: *const sp_params_t, pp: *const sp_pp_t, out: *mut u64, cap: c_int) -> c_int;
         pub fn sp_bench_ntt(p: *const sp_params_t, m: c_int, blocks: c_int, reps: c_int, ns_per_ntt: *mut f32) -> c_int;
@@ -157,6 +159,9 @@ pub mod sys {
         pub fn sp_to_ntt(p: *const sp_params_t, raw: *const u64, out: *mut u64, count: usize) -> c_int;
         pub fn sp_from_ntt(p: *const sp_params_t, ntt: *const u64, out: *mut u64, count: usize) -> c_int;
         pub fn sp_multiply(p: *const sp_params_t, a: *const u64, ar: usize, ac: usize, b: *const u64, bc: usize, res: *mut u64) -> c_int;
+        pub fn sp_add(p: *const sp_params_t, a: *const u64, b: *const u64, count: usize, res: *mut u64) -> c_int;
+        pub fn sp_add_into(p: *const sp_params_t, res: *mut u64, a: *const u64, count: usize) -> c_int;
+        pub fn sp_scalar_multiply(p: *const sp_params_t, scalar: *const u64, b: *const u64, count: usize, res: *mut u64) -> c_int;
         pub fn sp_automorph(p: *const sp_params_t, a: *const u64, count: usize, t: usize, res: *mut u64) -> c_int;
         pub fn sp_gadget_invert_rdim(p: *const sp_params_t, inp: *const u64, rows_in: usize, cols: usize, out: *mut u64,
                                      rows_out: usize, rdim: usize) -> c_int;

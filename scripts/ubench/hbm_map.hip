@@ -32,22 +32,14 @@ __global__ __launch_bounds__(256) void k_linear(const u32x4* base, long n16, uns
   }
   if (acc == 0x12345678u) sink[0] = acc;
 }
-// "big" mode: one allocation of 56 GiB (after an optional pad allocation), the units-pattern read timed per 14-GiB quarter
-static int big_mode(double pad_gb, int contiguous) {
-  void* pad = nullptr;
-  if (pad_gb > 0) hipMalloc(&pad, (size_t)(pad_gb * (1ull << 30)));
-  const size_t quarter = (size_t)(14ull << 30) / (448 * 1024) * (448 * 1024);
-  unsigned char* big = nullptr;
-  hipError_t e = contiguous ? hipExtMallocWithFlags((void**)&big, 4 * quarter, hipDeviceMallocContiguous) : hipMalloc((void**)&big, 4 * quarter);
-  if (e != hipSuccess) { printf("alloc failed: %s\n", hipGetErrorName(e)); return 1; }
-  if (contiguous) printf("(hipDeviceMallocContiguous) ");
+static void time_quarters(unsigned char* big, size_t quarter) {
   hipMemset(big, 1, 4 * quarter);
   unsigned* sink;
   hipMalloc(&sink, 4);
   hipDeviceSynchronize();
   hipEvent_t a, b;
   hipEventCreate(&a); hipEventCreate(&b);
-  printf("pad %.0f GiB, db at %p:", pad_gb, (void*)big);
+  double tot = 0;
   for (int qd = 0; qd < 4; qd++) {
     float best = 1e9;
     for (int r = 0; r < 4; r++) {
@@ -58,14 +50,65 @@ static int big_mode(double pad_gb, int contiguous) {
       float t; hipEventElapsedTime(&t, a, b);
       best = t < best ? t : best;
     }
+    tot += best;
     printf("  q%d %.3f ms (%.0f GB/s)", qd, best, quarter / best / 1e6);
   }
-  printf("\n");
+  printf("  | sum %.3f ms\n", tot);
+}
+// "big" mode: one allocation of 56 GiB (after an optional pad allocation), the units-pattern read timed per 14-GiB quarter
+static int big_mode(double pad_gb, int contiguous) {
+  void* pad = nullptr;
+  if (pad_gb > 0) hipMalloc(&pad, (size_t)(pad_gb * (1ull << 30)));
+  const size_t quarter = (size_t)(14ull << 30) / (448 * 1024) * (448 * 1024);
+  unsigned char* big = nullptr;
+  hipError_t e = contiguous ? hipExtMallocWithFlags((void**)&big, 4 * quarter, hipDeviceMallocContiguous) : hipMalloc((void**)&big, 4 * quarter);
+  if (e != hipSuccess) { printf("alloc failed: %s\n", hipGetErrorName(e)); return 1; }
+  if (contiguous) printf("(hipDeviceMallocContiguous) ");
+  printf("pad %.0f GiB, db at %p:", pad_gb, (void*)big);
+  time_quarters(big, quarter);
+  return 0;
+}
+// "vmm" mode: the same 56 GiB as ONE virtual range backed by separately created physical chunks
+// (hipMemAddressReserve + hipMemCreate / hipMemMap): placement decided chunk by chunk, nothing is relocated.
+static int vmm_mode(double chunk_gb, double pad_gb) {
+  void* pad = nullptr;
+  if (pad_gb > 0) hipMalloc(&pad, (size_t)(pad_gb * (1ull << 30)));
+  hipMemAllocationProp prop = {};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = 0;
+  size_t gran = 0;
+  hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended);
+  if (e != hipSuccess || gran == 0) { printf("hipMemGetAllocationGranularity: %s\n", hipGetErrorName(e)); return 1; }
+  const size_t quarter = (size_t)(14ull << 30) / (448 * 1024) * (448 * 1024);
+  size_t chunk = (size_t)(chunk_gb * (1ull << 30));
+  chunk = (chunk + gran - 1) / gran * gran;
+  const size_t total = (4 * quarter + chunk - 1) / chunk * chunk;
+  void* va = nullptr;
+  e = hipMemAddressReserve(&va, total, 0, nullptr, 0);
+  if (e != hipSuccess) { printf("hipMemAddressReserve: %s\n", hipGetErrorName(e)); return 1; }
+  int n = 0;
+  for (size_t off = 0; off < total; off += chunk, n++) {
+    hipMemGenericAllocationHandle_t h;
+    e = hipMemCreate(&h, chunk, &prop, 0);
+    if (e != hipSuccess) { printf("hipMemCreate chunk %d: %s\n", n, hipGetErrorName(e)); return 1; }
+    e = hipMemMap((char*)va + off, chunk, 0, h, 0);
+    if (e != hipSuccess) { printf("hipMemMap chunk %d: %s\n", n, hipGetErrorName(e)); return 1; }
+    hipMemRelease(h);  // the mapping keeps the physical memory alive
+  }
+  hipMemAccessDesc acc = {};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  e = hipMemSetAccess(va, total, &acc, 1);
+  if (e != hipSuccess) { printf("hipMemSetAccess: %s\n", hipGetErrorName(e)); return 1; }
+  printf("(VMM: %d chunks of %.2f GiB, granularity %zu KiB) pad %.0f GiB, db at %p:", n, chunk / 1073741824.0, gran >> 10, pad_gb, va);
+  time_quarters((unsigned char*)va, quarter);
   return 0;
 }
 int main(int argc, char** argv) {
   if (argc > 2 && argv[1][0] == 'b') return big_mode(atof(argv[2]), 0);
   if (argc > 2 && argv[1][0] == 'c') return big_mode(atof(argv[2]), 1);
+  if (argc > 2 && argv[1][0] == 'v') return vmm_mode(atof(argv[2]), argc > 3 ? atof(argv[3]) : 0.0);
   const double chunk_gb = argc > 1 ? atof(argv[1]) : 2.0;
   const size_t chunk = (size_t)(chunk_gb * (1ull << 30)) / (448 * 1024) * (448 * 1024);
   size_t fr, tot;

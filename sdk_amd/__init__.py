@@ -5,7 +5,11 @@ The compute lives in ``libspiral_hip.so`` (hand-written gfx950 HIP kernels behin
 (``Params`` / ``PolyMatrixRaw`` / ``PolyMatrixNTT`` / ``PublicParameters`` / ``Query`` / ``server.*``).
 There is no CPU fallback: every compute entry point raises if the library or a GPU is missing.
 """
-from .spiral import (  # noqa: F401
+from .spiral import (
+    add,
+    add_into,
+    scalar_multiply,
+    bench_sweep_batch,  # noqa: F401
     Database,
     Params,
     PolyMatrixNTT,

@@ -12,6 +12,7 @@ static thread_local std::string g_last_error;
 
 template <typename F>
 static int guarded(F&& f) {
+  tunables_new_call();
   try {
     f();
     return SP_OK;
@@ -42,6 +43,7 @@ struct sp_query {
   int next_fold_plane = 0;  // sp_query_fold_local_plane progress
   int rows_j0 = 0, rows_nj = 0;  // sp_query_begin_for_db on a row shard: only these first-dimension rows were expanded
   const sp_db* for_sparse = nullptr;  // begun for this sparse bucket: only the rows holding items were expanded
+  std::shared_ptr<const sp_db::SparseIndex> sparse_index;  // ... with this snapshot of its index (kept until the query is freed)
   float ms[4] = {0, 0, 0, 0};
   ~sp_query() {
     if (ws && params) {
@@ -105,10 +107,11 @@ void check_device(int dev) {
 
 }  // namespace
 
-// present items by column + the expansion schedule pruned to the rows that hold items, rebuilt after updates
-void sp_db::ensure_sparse_index() {
+// present items by column + the expansion schedule pruned to the rows that hold items: rebuilt when a NEW key has been
+// added (the plan only when a new row became occupied); overwrites keep the snapshot
+std::shared_ptr<const sp_db::SparseIndex> sp_db::ensure_sparse_index() {
   std::lock_guard<std::mutex> lk(mu);
-  if (!index_dirty) return;
+  if (!index_dirty && sparse_index) return sparse_index;
   const Params& p = params->p;
   const size_t num_per = p.num_per(), dim0 = p.dim0();
   std::vector<int> ptr(num_per + 1, 0), rows(slot_of.size()), slots(slot_of.size());
@@ -123,17 +126,24 @@ void sp_db::ensure_sparse_index() {
     fill[ii]++;
     row_set[j] = 1;
   }
-  col_ptr.ensure(ptr.size());
-  col_rows.ensure(std::max<size_t>(rows.size(), 1));
-  col_slots.ensure(std::max<size_t>(slots.size(), 1));
-  upload_words(col_ptr.p, ptr.data(), ptr.size() * sizeof(int));
+  auto idx = std::make_shared<SparseIndex>();
+  idx->col_ptr.ensure(ptr.size());
+  idx->col_rows.ensure(std::max<size_t>(rows.size(), 1));
+  idx->col_slots.ensure(std::max<size_t>(slots.size(), 1));
+  upload_words(idx->col_ptr.p, ptr.data(), ptr.size() * sizeof(int));
   if (!rows.empty()) {
-    upload_words(col_rows.p, rows.data(), rows.size() * sizeof(int));
-    upload_words(col_slots.p, slots.data(), slots.size() * sizeof(int));
+    upload_words(idx->col_rows.p, rows.data(), rows.size() * sizeof(int));
+    upload_words(idx->col_slots.p, slots.data(), slots.size() * sizeof(int));
   }
   if (slots_cap == 0) polys.ensure(1);
-  sparse_plan = build_pruned_plan_rows(p, row_set);  // query_expansion.rs:263-280: set_dim0 = rows of the present items
+  if (rows_dirty || !sparse_index || !sparse_index->plan)
+    idx->plan = build_pruned_plan_rows(p, row_set);  // query_expansion.rs:263-280: set_dim0 = rows of the present items
+  else
+    idx->plan = sparse_index->plan;                  // same occupied rows: the schedule is shared with the old snapshot
+  sparse_index = idx;
   index_dirty = false;
+  rows_dirty = false;
+  return sparse_index;
 }
 
 extern "C" {
@@ -155,7 +165,8 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
-                                "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split"};
+                                "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
+                                "sweep_batch_mfma"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -284,7 +295,11 @@ sp_db_t* sp_db_create_sparse(const sp_params_t* h) {
   });
   return rc == SP_OK ? out : nullptr;
 }
-size_t sp_db_sparse_items(const sp_db_t* d) { return d && d->sparse ? d->slot_of.size() : 0; }
+size_t sp_db_sparse_items(const sp_db_t* d) {
+  if (!d || !d->sparse) return 0;
+  std::lock_guard<std::mutex> lk(const_cast<sp_db*>(d)->mu);
+  return d->slot_of.size();
+}
 
 sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, false); }
 sp_db_t* sp_db_create_columns(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, true); }
@@ -351,15 +366,17 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
     const int npairs_total = (d->nj + 1) / 2;
     const size_t max_win = (size_t)std::max<long>(1, tunable("db_load_window", (long)512 << 20));  // bytes of raw items per upload
     const int pairs_per_win = (int)std::max<size_t>(1, std::min<size_t>((size_t)npairs_total, max_win / (2 * row_bytes)));
-    // + one chunk: when db_item_size is not a multiple of the chunk count the last chunk of an item reads
-    // bytes_per_chunk bytes all the same, i.e. into the next item (load_item_from_seek, server.rs:300-309) -- also
-    // for the last item of a window
-    DevBuf<uint8_t> win((size_t)pairs_per_win * 2 * row_bytes + bpc);
+    // + tail: the chunks of an item cover chunks * bytes_per_chunk >= db_item_size bytes of the file, i.e. the last
+    // chunk(s) of an item read into the NEXT item(s) (load_item_from_seek, server.rs:300-309) -- also for the last item
+    // of a window.  The spill is chunks * bpc - db_item_size bytes, which exceeds one chunk when
+    // db_item_size < (chunks - 1) * bpc (5-byte items in 4 chunks: bpc = 2, spill = 3).
+    const size_t tail = std::max(bpc, chunks * bpc - p.db_item_size);
+    DevBuf<uint8_t> win((size_t)pairs_per_win * 2 * row_bytes + tail);
     for (int jp = 0; jp < npairs_total; jp += pairs_per_win) {
       const int cnt = std::min(pairs_per_win, npairs_total - jp);
       const size_t item0 = (size_t)(d->j0 + 2 * jp) * p.num_per();
       const size_t off = item0 * p.db_item_size;
-      size_t want = (size_t)cnt * 2 * row_bytes + bpc;
+      size_t want = (size_t)cnt * 2 * row_bytes + tail;
       size_t have = off < file_len ? std::min(want, file_len - off) : 0;
       if (have) h2d_sync(win.p, file + off, have);
       DbEncodeDesc e{};
@@ -405,9 +422,11 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
       const size_t planes = p.planes(), bpc = (p.db_item_size + planes - 1) / planes, poly_words = planes * POLY_LEN;
       auto it = d->slot_of.find(item_idx);
       size_t slot;
+      bool new_key = false;
       if (it != d->slot_of.end()) {
         slot = it->second;
       } else {
+        new_key = true;
         slot = d->slot_of.size();
         if (slot >= d->slots_cap) {  // grow the polynomial store (amortised doubling, contents preserved)
           const size_t cap = std::max<size_t>(64, d->slots_cap * 2);
@@ -417,15 +436,22 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
           d->polys = std::move(bigger);
           d->slots_cap = cap;
         }
+        if (!d->rows_dirty) {  // does the item open a new first-dimension row?  (then the pruned expansion plan changes)
+          const size_t j_new = item_idx / p.num_per();
+          bool row_known = false;
+          for (const auto& kv : d->slot_of)
+            if (kv.first / p.num_per() == j_new) { row_known = true; break; }
+          if (!row_known) d->rows_dirty = true;
+        }
         d->slot_of[item_idx] = slot;
       }
-      DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
-      HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
-      if (len) h2d_sync(win.p, data, len);
-      launch_sparse_item_encode(D.T, win.p, (int)p.db_item_size, (int)bpc, (int)logp, (u32)p.pt_modulus,
+      d->staging.ensure(std::max<size_t>(p.db_item_size, 1));   // reused across updates
+      HIP_CHECK(hipMemsetAsync(d->staging.p, 0, p.db_item_size, 0));
+      if (len) h2d_sync(d->staging.p, data, len);
+      launch_sparse_item_encode(D.T, d->staging.p, (int)p.db_item_size, (int)bpc, (int)logp, (u32)p.pt_modulus,
                                 d->polys.p + slot * poly_words, (int)planes, 0);
       HIP_CHECK(hipDeviceSynchronize());
-      d->index_dirty = true;
+      if (new_key) d->index_dirty = true;   // an overwrite (the reference's upsert of an existing key) leaves the index alone
       return;
     }
     const size_t j = item_idx / p.num_per(), ii = item_idx % p.num_per();
@@ -592,11 +618,13 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     check_device(pp->device);
     const bool rows = db && db->num_shards > 1 && db->col_G == 1;
     const DeviceState::PrunedPlan* plan = nullptr;
+    std::shared_ptr<const sp_db::SparseIndex> snap;
     if (db && db->sparse) {
-      const_cast<sp_db*>(db)->ensure_sparse_index();
-      plan = db->sparse_plan.get();
+      snap = const_cast<sp_db*>(db)->ensure_sparse_index();
+      plan = snap->plan.get();
     }
     auto q = std::make_unique<sp_query>();
+    q->sparse_index = snap;
     q->params = const_cast<sp_params*>(h);
     q->pp = pp;
     q->ws = q->params->acquire_ws();
@@ -632,9 +660,9 @@ int sp_query_sweep(sp_query_t* q, const sp_db_t* db) {
     if (db->sparse) {
       // lib/server's process_query over a SparseDb (lib/server/src/server.rs:17-99): present items only, and the
       // fold takes fold.rs:38-44's all-zero shortcuts
-      need(q->for_sparse == db, "a sparse bucket needs sp_query_begin_for_db(…, db) (its expansion is pruned)");
-      const_cast<sp_db*>(db)->ensure_sparse_index();
-      run_sweep_sparse(W, *db);
+      need(q->for_sparse == db && q->sparse_index, "a sparse bucket needs sp_query_begin_for_db(…, db) (its expansion is pruned)");
+      // the snapshot the expansion was pruned with (items written after sp_query_begin are not part of this query)
+      run_sweep_sparse(W, *db, q->sparse_index->col_ptr.p, q->sparse_index->col_rows.p, q->sparse_index->col_slots.p);
       W.zero_shortcuts = true;
     } else if (sweep_is_pipelined(q->params->p, *db))
       run_sweep_pipelined(W, *db);
@@ -920,6 +948,13 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         if (i > 0) HIP_CHECK(hipStreamWaitEvent(W0.stream, qs[i]->ws->ev[1], 0));
       }
       if (prev_pass) HIP_CHECK(hipStreamWaitEvent(W0.stream, prev_pass, 0));
+      // matrix-core form of the pass (sweep_mfma.hpp): the group's query digit table lives with the group's first
+      // workspace (allocated on its first batched call, then reused)
+      if (sweep_batch_wants_mfma(d)) {
+        W0.batch_rq.ensure(sweep_batch_rq_words(d.nj));
+        d.rq = W0.batch_rq.p;
+      }
+      sweep_batch_prepare(W0.D->T, d, W0.stream);
       // SPIRAL_BATCH_PIPELINE=1 (off by default): the pass runs one (instance, trial) plane per launch and every query
       // folds plane p on its second stream while plane p+1 is swept -- the single-query pipeline with B folds per
       // plane.  Measured at C2, B = 8: 199 vs 198-227 queries/s for the one-launch pass -- the batched sweep's 188
@@ -1000,6 +1035,53 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
     float t = 0;
     HIP_CHECK(hipEventElapsedTime(&t, a, b));
     *ms_per_launch = t / ((float)iters * (per_plane ? (float)(plan.empty() ? p.planes() : plan.size()) : 1.0f));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  });
+}
+
+int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, int iters, float* ms_per_pass) {
+  return guarded([&] {
+    need(qs && db && ms_per_pass && iters > 0 && batch >= 1 && batch <= SWEEP_BATCH_MAX, "bad argument");
+    need(db->packed && db->num_shards == 1 && db->col_G == 1, "the batched pass needs an unsharded PACKED database");
+    check_device(db->device);
+    for (int i = 0; i < batch; i++) need(qs[i] && qs[i]->state >= 1, "query not begun");
+    const Params& p = qs[0]->params->p;
+    Workspace& W0 = *qs[0]->ws;
+    SweepBatchDesc d{};
+    d.db = db->words.p;
+    d.batch = batch;
+    d.planes = (int)p.planes();
+    d.num_per = db->np_local;
+    d.dim0 = (int)p.dim0();
+    d.j0 = db->j0;
+    d.nj = db->nj;
+    for (int i = 0; i < batch; i++) {
+      qs[i]->ws->ensure_sweep();
+      d.qv[i] = qs[i]->ws->qv.p;
+      d.out[i] = qs[i]->ws->sweep_out.p;
+      HIP_CHECK(hipStreamSynchronize(qs[i]->ws->stream));   // expansions done: the pass is timed alone
+      HIP_CHECK(hipStreamSynchronize(qs[i]->ws->stream2));
+    }
+    if (sweep_batch_wants_mfma(d)) {
+      W0.batch_rq.ensure(sweep_batch_rq_words(d.nj));
+      d.rq = W0.batch_rq.p;
+    }
+    hipEvent_t a, b;
+    HIP_CHECK(hipEventCreate(&a));
+    HIP_CHECK(hipEventCreate(&b));
+    auto pass = [&] {
+      sweep_batch_prepare(W0.D->T, d, W0.stream);
+      launch_sweep_batch(W0.D->T, d, W0.stream);
+    };
+    pass();  // warm
+    HIP_CHECK(hipEventRecord(a, W0.stream));
+    for (int i = 0; i < iters; i++) pass();
+    HIP_CHECK(hipEventRecord(b, W0.stream));
+    HIP_CHECK(hipStreamSynchronize(W0.stream));
+    float t = 0;
+    HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    *ms_per_pass = t / (float)iters;
     (void)hipEventDestroy(a);
     (void)hipEventDestroy(b);
   });
@@ -1181,6 +1263,45 @@ int sp_multiply(const sp_params_t* h, const uint64_t* a, size_t ar, size_t ac, c
     m.out_row_stride = (int)bc;
     launch_mac(W->D->T, m, W->stream);
     download_ntt(*W, dR.p, ar * bc * 2 * POLY_LEN, res, tmp);
+  });
+}
+
+int sp_add(const sp_params_t* h, const uint64_t* a, const uint64_t* b, size_t count, uint64_t* res) {
+  return guarded([&] {
+    need(h && a && b && res && count, "bad argument");
+    Scoped W(h);
+    DevBuf<u64> tmp, tmp2;
+    DevBuf<u32> dA, dB, dR(count * 2 * POLY_LEN);
+    upload_ntt(*W, a, count * 2 * POLY_LEN, dA, tmp);
+    upload_ntt(*W, b, count * 2 * POLY_LEN, dB, tmp2);
+    launch_add(W->D->T, dR.p, dA.p, dB.p, (int)count, W->stream);
+    download_ntt(*W, dR.p, count * 2 * POLY_LEN, res, tmp);
+  });
+}
+int sp_add_into(const sp_params_t* h, uint64_t* res, const uint64_t* a, size_t count) {
+  return guarded([&] {
+    need(h && a && res && count, "bad argument");
+    Scoped W(h);
+    DevBuf<u64> tmp, tmp2;
+    DevBuf<u32> dA, dR;
+    upload_ntt(*W, res, count * 2 * POLY_LEN, dR, tmp);
+    upload_ntt(*W, a, count * 2 * POLY_LEN, dA, tmp2);
+    launch_add(W->D->T, dR.p, dR.p, dA.p, (int)count, W->stream);   // in place, as add_into (poly.rs:500-512)
+    download_ntt(*W, dR.p, count * 2 * POLY_LEN, res, tmp);
+  });
+}
+int sp_scalar_multiply(const sp_params_t* h, const uint64_t* scalar, const uint64_t* b, size_t count, uint64_t* res) {
+  return guarded([&] {
+    need(h && scalar && b && res && count, "bad argument");
+    Scoped W(h);
+    DevBuf<u64> tmp, tmp2;
+    DevBuf<u32> dS, dB(2 * count * 2 * POLY_LEN), dIn;
+    upload_ntt(*W, scalar, 2 * POLY_LEN, dS, tmp);
+    upload_ntt(*W, b, count * 2 * POLY_LEN, dIn, tmp2);
+    // the kernel the expansion uses (coefficient_expansion, server.rs:105-110): polys [count, 2 count) = scalar * polys [0, count)
+    launch_copy_words(dB.p, dIn.p, count * 2 * POLY_LEN, W->stream);
+    launch_scalar_mul(W->D->T, dB.p, (long)count, 0, dS.p, (int)count, W->stream);
+    download_ntt(*W, dB.p + count * 2 * POLY_LEN, count * 2 * POLY_LEN, res, tmp);
   });
 }
 

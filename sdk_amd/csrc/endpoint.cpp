@@ -8,7 +8,10 @@
 //                                                  through sp_process_query_batch: <= 8 queries per database pass.
 // Uses only the public C ABI (include/spiral_hip.h); framing (JSON list of strings, standard base64 with padding,
 // what serde_json / the base64 crate emit) is plain host code.
+#include <array>
+#include <cerrno>
 #include <cstring>
+#include <sys/random.h>
 #include <memory>
 #include <mutex>
 #include <random>
@@ -47,13 +50,13 @@ std::string b64_encode(const uint8_t* d, size_t n) {
 }
 
 bool b64_decode(const char* s, size_t n, std::vector<uint8_t>& out) {
-  static int8_t tab[256];
-  static bool init = false;
-  if (!init) {
-    memset(tab, -1, sizeof(tab));
-    for (int i = 0; i < 64; i++) tab[(unsigned char)B64[i]] = (int8_t)i;
-    init = true;
-  }
+  // function-local static initialised by a lambda: thread-safe (sp_server_* may be entered concurrently)
+  static const std::array<int8_t, 256> tab = [] {
+    std::array<int8_t, 256> t;
+    t.fill(-1);
+    for (int i = 0; i < 64; i++) t[(unsigned char)B64[i]] = (int8_t)i;
+    return t;
+  }();
   if (n % 4 != 0) return false;
   out.clear();
   out.reserve(n / 4 * 3);
@@ -136,11 +139,18 @@ bool parse_string_list(const char* s, size_t n, std::vector<std::string>& out) {
 }
 
 std::string uuid_v4() {
-  static thread_local std::mt19937_64 gen{std::random_device{}() ^ ((uint64_t)std::random_device{}() << 32)};
+  // The uuid is the only credential naming a client's resident public parameters in /private-read: 16 bytes from the
+  // kernel's CSPRNG, as Uuid::new_v4 in the reference (lib/server/src/bin/server.rs:87), not a seeded Mersenne Twister.
   uint8_t b[16];
-  const uint64_t x = gen(), y = gen();
-  memcpy(b, &x, 8);
-  memcpy(b + 8, &y, 8);
+  size_t got = 0;
+  while (got < sizeof(b)) {
+    const ssize_t r = getrandom(b + got, sizeof(b) - got, 0);
+    if (r < 0) {
+      if (errno == EINTR) continue;
+      throw Fail{SP_E_ARG, "getrandom failed"};
+    }
+    got += (size_t)r;
+  }
   b[6] = (uint8_t)((b[6] & 0x0F) | 0x40);  // version 4
   b[8] = (uint8_t)((b[8] & 0x3F) | 0x80);  // RFC 4122 variant
   static const char hex[] = "0123456789abcdef";

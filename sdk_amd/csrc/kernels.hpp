@@ -46,7 +46,8 @@ enum PathBit : u64 {
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
   PATH_CU_SPLIT = 1ull << 21,         // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
   PATH_EXPAND_SPLIT = 1ull << 22,     // odd expansion subtree + GSW side on the second stream, beside the even subtree
-  PATH_PIPE_CLASS_SPLIT = 1ull << 23  // a plane swept and folded as two chunk-parity classes (pipe_split)
+  PATH_PIPE_CLASS_SPLIT = 1ull << 23, // a plane swept and folded as two chunk-parity classes (pipe_split)
+  PATH_SWEEP_MFMA = 1ull << 24        // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -291,7 +292,17 @@ struct SweepBatchDesc {
   u32* out[SWEEP_BATCH_MAX];
   int batch;
   int planes, num_per, dim0, j0, nj;
+  // matrix-core form (sweep_mfma.hpp): rq = scratch for the group's query digit table (sweep_batch_rq_words words),
+  // filled by sweep_batch_prepare; use_mfma is set by it.  rq == nullptr: VALU kernel.
+  u32* rq;
+  int use_mfma;
 };
+// does this shape / group size run on the matrix cores (switch batch_mfma, default on from batch_mfma_min = 4 queries)?
+bool sweep_batch_wants_mfma(const SweepBatchDesc& d);
+inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16) * 128 * 4; }
+// once per group of queries, before the pass (all planes share the table): builds the digit table when the matrix-core
+// form applies and d.rq is set
+void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s);
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);
 const char* sweep_kernel_name(int num_per);
 // reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order

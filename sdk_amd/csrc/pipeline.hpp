@@ -47,6 +47,7 @@ struct Workspace {
   DevBuf<u32> gsw_dig;
   // sweep
   DevBuf<u32> sweep_out;  // [plane][r][crt][z][ii]
+  DevBuf<u32> batch_rq;   // query digit table of a batched pass on the matrix cores (first workspace of a group; on first use)
   // fold / pack
   DevBuf<u64> foldX, foldY, final_cts, pack_raw;
   DevBuf<u32> fold_dig, fold_ntt, pack_dig, pack_ct2, pack_res, pack_v1_P, pack_v1_P2;
@@ -85,7 +86,7 @@ void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0,
                const DeviceState::PrunedPlan* plan = nullptr);
-void run_sweep_sparse(Workspace& W, const sp_db& db);
+void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const int* col_rows, const int* col_slots);
 // expansion schedule pruned to an arbitrary set of first-dimension rows (rows[j] != 0), lists uploaded
 std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P, const std::vector<char>& rows);
 void run_sweep(Workspace& W, const sp_db& db);

@@ -23,29 +23,68 @@ void hip_check(hipError_t e, const char* what, const char* file, int line) {
 }
 
 // ---- tunables: sp_debug_set(name, v) overrides, else SPIRAL_<NAME> from the environment, else the default
+// Looked up hundreds of times per query (every launch asks for debug_sync, every stage for its switches), so the answer
+// is cached per calling thread and per call site and only re-resolved -- override list under the mutex, then getenv -- when
+// the EPOCH has moved: sp_debug_set and every public entry point that starts a piece of work (guarded() in capi.cpp)
+// bump it.  A test that changes the environment between two calls is therefore still seen; inside a call the launch
+// path touches neither the mutex nor getenv.
 static std::mutex g_tun_mu;
 static std::vector<std::pair<std::string, long>> g_tun;
+static std::atomic<unsigned> g_tun_epoch{1};
 static std::atomic<long> g_fresh_allocs{0};  // allocations seen by devbuf_fresh since poison_skip was last set
+void tunables_new_call() { g_tun_epoch.fetch_add(1, std::memory_order_relaxed); }
 void set_tunable(const char* name, long v) {
   if (!strcmp(name, "poison_skip")) g_fresh_allocs = 0;
-  std::lock_guard<std::mutex> lk(g_tun_mu);
-  for (auto& kv : g_tun)
-    if (kv.first == name) {
-      kv.second = v;
-      return;
-    }
-  g_tun.emplace_back(name, v);
+  {
+    std::lock_guard<std::mutex> lk(g_tun_mu);
+    bool found = false;
+    for (auto& kv : g_tun)
+      if (kv.first == name) {
+        kv.second = v;
+        found = true;
+        break;
+      }
+    if (!found) g_tun.emplace_back(name, v);
+  }
+  tunables_new_call();
 }
-long tunable(const char* name, long dflt) {
+static bool tunable_resolve(const char* name, long* out) {
   {
     std::lock_guard<std::mutex> lk(g_tun_mu);
     for (auto& kv : g_tun)
-      if (kv.first == name) return kv.second;
+      if (kv.first == name) {
+        *out = kv.second;
+        return true;
+      }
   }
   std::string env = "SPIRAL_";
   for (const char* c = name; *c; c++) env += (char)toupper((unsigned char)*c);
-  const char* e = getenv(env.c_str());  // looked up every time: tests change the environment between handles
-  return e ? atol(e) : dflt;
+  const char* e = getenv(env.c_str());
+  if (!e) return false;
+  *out = atol(e);
+  return true;
+}
+long tunable(const char* name, long dflt) {
+  struct Ent {
+    const char* name;  // call sites pass string literals: the address identifies the site
+    unsigned epoch;
+    bool has;
+    long val;
+  };
+  thread_local std::vector<Ent> cache;
+  const unsigned ep = g_tun_epoch.load(std::memory_order_relaxed);
+  for (auto& e : cache)
+    if (e.name == name) {
+      if (e.epoch != ep) {
+        e.has = tunable_resolve(name, &e.val);
+        e.epoch = ep;
+      }
+      return e.has ? e.val : dflt;
+    }
+  Ent e{name, ep, false, 0};
+  e.has = tunable_resolve(name, &e.val);
+  cache.push_back(e);
+  return e.has ? e.val : dflt;
 }
 
 void devbuf_fresh(void* p, size_t bytes) {
@@ -70,6 +109,8 @@ void* devbuf_alloc(size_t bytes, size_t* guard, long* serial) {
   }
   *guard = gb;
   *serial = -1;
+  void* const block = q;  // what hipMalloc returned (q moves past the front guard below)
+  try {
   if (gb) {
     const long k = g_fresh_allocs.fetch_add(1);
     *serial = k;
@@ -90,6 +131,10 @@ void* devbuf_alloc(size_t bytes, size_t* guard, long* serial) {
     HIP_CHECK(hipMemset(q, 0, bytes));
     devbuf_cache_sync();
     HIP_CHECK(hipDeviceSynchronize());
+  }
+  } catch (...) {  // a failed fill must not leak the block
+    (void)hipFree(block);
+    throw;
   }
   return q;
 }
@@ -980,10 +1025,10 @@ void run_sweep(Workspace& W, const sp_db& db) {
 
 // multiply_reg_by_sparse_database (lib/server/src/compute/dot_product.rs:13-220): only the present items, read from the
 // expanded ciphertexts directly (row j = ct 2j, or ct j when nu_2 = 0)
-void run_sweep_sparse(Workspace& W, const sp_db& db) {
+void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const int* col_rows, const int* col_slots) {
   const Params& p = *W.P;
   W.ensure_sweep();
-  launch_sweep_sparse(W.D->T, db.col_ptr.p, db.col_rows.p, db.col_slots.p, db.polys.p, (int)p.planes(), W.v.p, 0,
+  launch_sweep_sparse(W.D->T, col_ptr, col_rows, col_slots, db.polys.p, (int)p.planes(), W.v.p, 0,
                       p.db_dim_2 > 0 ? 2 : 1, W.sweep_out.p, (int)p.num_per(), W.stream);
 }
 

@@ -32,7 +32,8 @@ struct OomError : std::runtime_error {
 void hip_check(hipError_t e, const char* what, const char* file, int line);
 #define HIP_CHECK(x) ::spiral::hip_check((x), #x, __FILE__, __LINE__)
 u64 paths_taken(bool reset);
-void set_tunable(const char* name, long v);  // thread-local PathBit mask accumulated by launched() / note_path()
+void set_tunable(const char* name, long v);
+void tunables_new_call();  // a public entry point begins: cached switch values are re-resolved (server.cpp)  // thread-local PathBit mask accumulated by launched() / note_path()
 // Debug hook called on every fresh DevBuf allocation (server.cpp): SPIRAL_POISON_WS / sp_debug_set("poison_ws", b)
 // fills the buffer with byte b (1..255) so that a read of never-written device memory shows up deterministically
 // instead of depending on what the pages held before; "poison_skip" = k leaves the k-th allocation since the
@@ -208,8 +209,18 @@ struct sp_db {
   std::unordered_map<size_t, size_t> slot_of;  // item index -> slot (db_idx_to_vec_idx)
   spiral::DevBuf<spiral::u64> polys;           // [slot][plane][N] packed NTT words
   size_t slots_cap = 0;
-  bool index_dirty = true;                     // the structures below are rebuilt before the next query
-  spiral::DevBuf<int> col_ptr, col_rows, col_slots;  // present items by column (CSR): row j and slot
-  std::unique_ptr<spiral::DeviceState::PrunedPlan> sparse_plan;  // expansion pruned to the rows that hold items
-  void ensure_sparse_index();                  // capi.cpp
+  bool index_dirty = true;                     // a NEW key was added: the index below is rebuilt before the next query
+  bool rows_dirty = true;                      // ... and the set of occupied rows changed: the expansion plan too
+  // Immutable snapshot of the index: present items by column (CSR: row j and slot) + the expansion schedule pruned to the
+  // rows that hold items.  A query takes a shared_ptr when it begins and keeps it until it is freed, so an update that
+  // publishes a new snapshot never frees device lists a query in flight still reads.  (Overwriting an existing item
+  // changes neither; the polynomial store itself follows the reference's rule -- writers are exclusive,
+  // lib/server/src/bin/server.rs:24 RwLock.)
+  struct SparseIndex {
+    spiral::DevBuf<int> col_ptr, col_rows, col_slots;
+    std::shared_ptr<spiral::DeviceState::PrunedPlan> plan;
+  };
+  std::shared_ptr<const SparseIndex> sparse_index;
+  spiral::DevBuf<uint8_t> staging;             // one item's bytes (sp_db_update_item), reused
+  std::shared_ptr<const SparseIndex> ensure_sparse_index();  // capi.cpp
 };

@@ -1,6 +1,7 @@
 // Database sweep = multiply_reg_by_database (server.rs:155-221) for gfx950: HBM-streaming integer kernels, one per
 // database shape (PACKED wide, persistent, batched, 8-byte wide, narrow).  The judged kernel lives here.
 #include "device_common.hpp"
+#include "sweep_mfma.hpp"
 
 namespace spiral {
 
@@ -415,7 +416,57 @@ __global__ __launch_bounds__(256, 2) void k_sweep_packed_batch(DevTables T, Swee
     *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)acc[b][3], (u32)acc[b][7]);  // r=1, crt=1
   }
 }
+bool sweep_batch_wants_mfma(const SweepBatchDesc& d) {
+  // the matrix-core form needs whole 16-row steps in rings of 2 (nj % 32), the z-row's digit table in LDS (nj <= 512)
+  // and whole 128-column chunks; below batch_mfma_min queries per pass the VALU kernel is HBM-bound as well
+  return tunable("batch_mfma", 1) != 0 && d.batch >= (int)tunable("batch_mfma_min", 4) && d.nj > 0 && (d.nj % 32) == 0 &&
+         d.nj <= 512 && d.num_per >= 128 && (d.num_per % 128) == 0;
+}
+void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
+  d.use_mfma = 0;
+  if (!d.rq || !sweep_batch_wants_mfma(d)) return;
+  QueryDigitsDesc q{};
+  for (int b = 0; b < d.batch; b++) q.qv[b] = d.qv[b];
+  q.rq = d.rq;
+  q.batch = d.batch;
+  q.dim0 = d.dim0;
+  q.j0 = d.j0;
+  q.nj = d.nj;
+  const size_t entries = (size_t)N * (d.nj >> 4) * 128;
+  hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
+  launched(0, "k_query_digits");
+  d.use_mfma = 1;
+}
+static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
+  SweepMfmaDesc m{};
+  m.db = d.db;
+  m.rq = d.rq;
+  for (int b = 0; b < d.batch; b++) m.out[b] = d.out[b];
+  m.batch = d.batch;
+  m.planes = d.planes;
+  m.num_per = d.num_per;
+  m.nj = d.nj;
+  const int chunks = d.num_per >> 7;
+  int cpw = (int)tunable("batch_mfma_cpw", 16);
+  cpw = std::max(1, std::min(cpw, chunks));
+  while (chunks % cpw) cpw--;
+  m.cpw = cpw;
+  m.c32[0] = (u32)((1ull << 32) % MODULUS_0);
+  m.c32[1] = (u32)((1ull << 32) % MODULUS_1);
+  const dim3 grid((unsigned)((size_t)d.planes * N * (chunks / cpw)));
+  const size_t lds = (size_t)d.nj * 128;
+  // ring of 2 load buffers by default (one 16-row step ahead, 180 VGPRs); 4 measured the same +-2 % at 236 VGPRs
+  if (tunable("batch_mfma_nb", 2) == 4 && (d.nj % 64) == 0)
+    hipLaunchKernelGGL((k_sweep_mfma_batch<4, 2>), grid, dim3(256), lds, s, T, m);
+  else
+    hipLaunchKernelGGL((k_sweep_mfma_batch<2, 2>), grid, dim3(256), lds, s, T, m);
+  launched(PATH_SWEEP_BATCH | PATH_SWEEP_MFMA, "k_sweep_mfma_batch");
+}
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
+  if (d.use_mfma && d.rq) {
+    launch_sweep_mfma(T, d, s);
+    return;
+  }
   const long units = (long)d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)((units + 3) / 4));
   const bool unroll = ((d.nj >> 1) % 8) == 0;  // U = 4 (and the U = 2 LDS form) run ping-pong: npairs % (2 U) == 0

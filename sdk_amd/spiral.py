@@ -273,6 +273,29 @@ def multiply(params, a, ar, ac, b, bc):
     return res
 
 
+def add(params, a, b):
+    """poly.rs:483-498 over flat NTT polynomials"""
+    a, b = _u64arr(a), _u64arr(b)
+    res = np.zeros(a.size, dtype=np.uint64)
+    _chk(lib().sp_add(_vp(params.h), _p(a), _p(b), C.c_size_t(a.size // params.ntt_words), _p(res)))
+    return res
+
+
+def add_into(params, res, a):
+    """poly.rs:500-512 (returns the updated copy)"""
+    res, a = _u64arr(res).copy(), _u64arr(a)
+    _chk(lib().sp_add_into(_vp(params.h), _p(res), _p(a), C.c_size_t(a.size // params.ntt_words)))
+    return res
+
+
+def scalar_multiply(params, scalar, b):
+    """poly.rs:575-588: one NTT polynomial times every polynomial of b"""
+    scalar, b = _u64arr(scalar), _u64arr(b)
+    res = np.zeros(b.size, dtype=np.uint64)
+    _chk(lib().sp_scalar_multiply(_vp(params.h), _p(scalar), _p(b), C.c_size_t(b.size // params.ntt_words), _p(res)))
+    return res
+
+
 def automorph(params, a, t):
     """poly.rs:539-551"""
     a = _u64arr(a)
@@ -546,6 +569,15 @@ class QueryRun:
 
     def sweep_launches(self, db):
         return int(lib().sp_sweep_launches(_vp(self.params.h), _vp(db.h)))
+
+
+def bench_sweep_batch(runs, db, iters):
+    """average milliseconds per batched database PASS of the begun queries `runs` (QueryRun objects, <= 8) -- the pass
+    sp_process_query_batch issues for such a group (sp_bench_sweep_batch)"""
+    ms = C.c_float(0)
+    arr = (C.c_void_p * len(runs))(*[r.h for r in runs])
+    _chk(lib().sp_bench_sweep_batch(arr, C.c_int(len(runs)), _vp(db.h), C.c_int(iters), C.byref(ms)))
+    return ms.value
 
 
 def process_query(params, public_params, query, db):

@@ -72,6 +72,60 @@ def test_to_ntt_from_ntt(sp, oracle_mod):
     assert (back[6145:] == raw[6145:] % np.uint64(Q)).all()
 
 
+def test_from_ntt_small_and_boundary_coefficients(sp, oracle_mod):
+    """from_ntt (poly.rs:646-663 -> params.rs:207-214 crt_compose_2 -> arith.rs barrett_reduction_u128) on polynomials whose
+    coefficients sit where the reference's add_u64 quirk could matter if it ever did: 0, 1, every value below 2^14, the
+    values just below Q, powers of two.  GPU (exact Garner form) == oracle (literal restatement) == the raw input."""
+    p, o = _pair(sp, oracle_mod, FAST)
+    N = 2048
+    rng = np.random.default_rng(17)
+    polys = [np.arange(k * N, (k + 1) * N, dtype=np.uint64) for k in range(8)]                     # 0 .. 2^14 - 1
+    polys += [np.uint64(Q - 1) - np.arange(k * N, (k + 1) * N, dtype=np.uint64) for k in range(2)]  # Q - 1 downwards
+    polys.append(np.array([(1 << (i % 56)) % Q for i in range(N)], dtype=np.uint64))
+    polys.append(np.array([((1 << (i % 56)) - 1) % Q for i in range(N)], dtype=np.uint64))
+    polys.append(rng.integers(0, 1 << 13, N, dtype=np.uint64))
+    polys.append(np.uint64(Q) - rng.integers(1, 1 << 13, N, dtype=np.uint64))
+    raw = np.concatenate(polys)
+    ntt = o.to_ntt(raw)
+    assert (sp.to_ntt(p, raw) == ntt).all()
+    back = sp.from_ntt(p, ntt)
+    assert (back == o.from_ntt(ntt)).all()
+    assert (back == raw).all()
+
+
+def test_add_and_scalar_multiply(sp, oracle_mod):
+    """poly.rs:483-512 add / add_into and :575-588 scalar_multiply as stage-level exports (the kernels the expansion and
+    the packing use), against the oracle: edge polynomials (0, q - 1 in every slot) and random ones."""
+    p, o = _pair(sp, oracle_mod, FAST)
+    rng = np.random.default_rng(23)
+    a = _edge_polys(rng, 4)
+    b = np.roll(_edge_polys(np.random.default_rng(24), 4).reshape(-1, 2 * 2048), 3, axis=0).reshape(-1)
+    assert (sp.add(p, a, b) == o.add(a, b)).all()
+    assert (sp.add_into(p, a, b) == o.add_into(a, b)).all()
+    assert (sp.add(p, a, a) == o.add(a, a)).all()
+    scal = np.concatenate([rng.integers(0, Q0, 2048, dtype=np.uint64), rng.integers(0, Q1, 2048, dtype=np.uint64)])
+    assert (sp.scalar_multiply(p, scal, a) == o.scalar_multiply(scal, a)).all()
+    top = np.concatenate([np.full(2048, Q0 - 1, dtype=np.uint64), np.full(2048, Q1 - 1, dtype=np.uint64)])
+    assert (sp.scalar_multiply(p, top, a) == o.scalar_multiply(top, a)).all()
+
+
+def test_reorient_reg_ciphertexts_export(sp, oracle_mod):
+    """util.rs:323-355 through the stand-alone export sp_reorient_reg_ciphertexts (so far only checked inside
+    expand_query): dim0 expanded NTT ciphertexts -> [z][j][r] packed words, canonical residues."""
+    for cfg in (FAST, dict(FAST, nu_1=4), C1):
+        p, o = _pair(sp, oracle_mod, cfg)
+        rng = np.random.default_rng(31 + cfg["nu_1"])
+        n = o.dim0 * 2 * 2 * 2048
+        v = np.empty(n, dtype=np.uint64)
+        vv = v.reshape(o.dim0, 2, 2, 2048)
+        vv[:, :, 0, :] = rng.integers(0, Q0, (o.dim0, 2, 2048), dtype=np.uint64)
+        vv[:, :, 1, :] = rng.integers(0, Q1, (o.dim0, 2, 2048), dtype=np.uint64)
+        vv[0, 0, 0, :] = Q0 - 1
+        vv[0, 1, 1, :] = Q1 - 1
+        vv[1 % o.dim0, 0, :, :5] = 0
+        assert (sp.reorient_reg_ciphertexts(p, v) == o.reorient_reg_ciphertexts(v)).all()
+
+
 def test_multiply(sp, oracle_mod):  # poly.rs:731-743 + random 2x16 * 16x1 (the fold shape)
     p, o = _pair(sp, oracle_mod, FAST)
     m1 = np.zeros(2048, dtype=np.uint64); m1[1] = 100
@@ -424,11 +478,13 @@ def test_db_preprocessing_on_gpu(sp, oracle_mod, cfg, short):
     assert (db2.read_ref(3, 5, o.num_per - 1, 0, o.dim0 // 2) == exp[3, 5, o.num_per - 1, o.dim0 // 2:]).all()
 
 
-def test_db_preprocessing_item_spill_across_windows(sp, oracle_mod, monkeypatch):
-    """db_item_size not a multiple of the chunk count: the last chunk of an item still reads bytes_per_chunk bytes, i.e.
-    the first bytes of the NEXT item (load_item_from_seek, server.rs:300-309).  The upload windows carry one chunk of
-    tail so that this also holds for the last item of a window (here: every second row pair starts a new window)."""
-    cfg = dict(FAST, nu_1=4, nu_2=1, db_item_size=1001)
+@pytest.mark.parametrize("item_size", [1001, 5, 9], ids=["1001B", "5B-spill-3", "9B-spill-3"])
+def test_db_preprocessing_item_spill_across_windows(sp, oracle_mod, monkeypatch, item_size):
+    """db_item_size not a multiple of the chunk count: the chunks of an item cover chunks * bytes_per_chunk bytes, i.e.
+    they read into the NEXT item(s) (load_item_from_seek, server.rs:300-309).  The upload windows carry that spill as a
+    tail so that this also holds for the last item of a window (here: every second row pair starts a new window); with
+    5-byte items in 4 chunks the spill (3 bytes) is longer than a chunk (2 bytes) and crosses into the item after next."""
+    cfg = dict(FAST, nu_1=4, nu_2=1, db_item_size=item_size)
     o = oracle_mod.Params(cfg)
     p = sp.Params(cfg)
     monkeypatch.setenv("SPIRAL_DB_LOAD_WINDOW", str(2 * o.num_per * o.db_item_size))
@@ -887,6 +943,77 @@ def test_process_query_batch_lds_staged(sp, oracle_mod):
         assert resp[i] == o.process_query(pp, qs[i], db), i
     single = sp.process_query(p, gpp, qs[5], gdb)
     assert resp[5] == single
+    for i in range(B):
+        assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
+
+
+@pytest.mark.parametrize("nu_1,nu_2,B,check", [(6, 7, 8, "all"), (5, 8, 5, "all"), (7, 7, 4, "all"), (8, 8, 7, "some"), (9, 7, 8, "some")],
+                         ids=["64x128-B8", "32x256-B5", "128x128-B4", "256x256-B7", "512x128-B8"])
+def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, check):
+    """Batched pass on the matrix cores (k_sweep_mfma_batch: signed base-256 digits on v_mfma_i32_16x16x64_i8, groups of
+    >= 4 queries, first dimension a multiple of 32 rows): byte-identical to the oracle, to the VALU batch kernel
+    (SPIRAL_BATCH_MFMA=0) and to one-at-a-time queries; the path bit proves which kernel ran.  Two clients' keys."""
+    import ctypes as C
+    cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256 << max(0, 16 - nu_1 - nu_2)}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cls = [oracle_mod.Client(o), oracle_mod.Client(o)]
+    pps = [cls[0].generate_keys(41), cls[1].generate_keys(42)]
+    gpps = [sp.PublicParameters.deserialize(p, x) for x in pps]
+    if check == "all":
+        item, db = o.generate_random_db_and_get_item(3)
+    else:   # the larger shapes: uniformly random words (byte parity does not need a decodable database)
+        rng = np.random.default_rng(nu_1 * 16 + nu_2)
+        n_words = 4 * 2048 * o.num_per * o.dim0
+        db = rng.integers(0, Q0, n_words, dtype=np.uint64) | (rng.integers(0, Q1, n_words, dtype=np.uint64) << np.uint64(32))
+    gdb = sp.Database(p).load(db)
+    idxs = [(1009 * i + 3) % o.num_items for i in range(B)]
+    qs = [cls[i % 2].generate_query(idxs[i], 500 + i) for i in range(B)]
+    sp.paths_taken()
+    resp = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
+    assert "sweep_batch_mfma" in sp.paths_taken()
+    sp.lib().sp_debug_set(b"batch_mfma", C.c_long(0))
+    try:
+        sp.paths_taken()
+        valu = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
+        assert "sweep_batch_mfma" not in sp.paths_taken()
+    finally:
+        sp.lib().sp_debug_set(b"batch_mfma", C.c_long(1))
+    assert resp == valu
+    for i in (range(B) if check == "all" else (0, B - 1)):
+        assert resp[i] == o.process_query(pps[i % 2], qs[i], db), i
+    for i in range(B):
+        assert resp[i] == sp.process_query(p, gpps[i % 2], qs[i], gdb), i
+    if check == "all":
+        assert cls[1].decode_response(resp[1]) == o.item_to_vec(o.generate_random_db_and_get_item(idxs[1])[0])
+
+
+def test_process_query_batch_matrix_core_extreme_digits(sp, oracle_mod):
+    """Database words whose residues sit at the edges of the signed-digit split (every byte 0x80 / 0x7f, q - 1, 0, the
+    largest top digit) in every row: the i32 digit sums of k_sweep_mfma_batch reach their largest magnitudes; 256 rows.
+    Responses are compared byte for byte with the oracle's exact u128 sums (server.rs:196-217)."""
+    cfg = {"n": 2, "nu_1": 8, "nu_2": 7, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 512}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(51)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    rng = np.random.default_rng(5)
+    lo = np.array([0x00808080, 0x007F7F7F, Q0 - 1, 0, 0x0F7F7F7F, 0x0F808080, 0x0080807F, 1], dtype=np.uint64)
+    hi = np.array([0x00808080, 0x007F7F7F, Q1 - 1, 0, 0x0E7F7F7F, 0x0E808080, 0x0E80807F, 1], dtype=np.uint64)
+    n_words = 4 * 2048 * o.num_per * o.dim0
+    pick = rng.integers(0, 8, n_words)
+    db = (lo[pick] | (hi[(pick + 3) % 8] << np.uint64(32))).astype(np.uint64)
+    gdb = sp.Database(p).load(db)
+    B = 8
+    qs = [cl.generate_query((977 * i + 1) % o.num_items, 600 + i) for i in range(B)]
+    sp.paths_taken()
+    resp = sp.process_query_batch(p, [gpp] * B, qs, gdb)
+    assert "sweep_batch_mfma" in sp.paths_taken()
+    for i in (0, 3, 7):
+        assert resp[i] == o.process_query(pp, qs[i], db), i
     for i in range(B):
         assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
 

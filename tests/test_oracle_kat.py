@@ -225,3 +225,107 @@ def test_chacha20_rfc8439(oracle_mod):
     assert ks[64:80].hex() == "9f07e7be5551387a98ba977c732d080d"
     first = int(oracle_mod.chacha20_rng_u64(bytes(32), 1)[0])
     assert first == (0x903df1a0 << 32) | 0xade0b876   # gen::<u64>() = lo word first
+
+
+# ---- the add_u64 quirk of barrett_raw_u128 (arith.rs:155-180) and why it can never be observed with Q ------------------
+def _rust_barrett_reduction_u128_raw(modulus, cr0, cr1, val, faithful_seal=False):
+    """Python transliteration of arith.rs:155-187.  add_u64 (arith.rs:155-163) leaves *out untouched when the addition
+    overflows; faithful_seal=True stores the wrapped sum instead, as SEAL's add_uint64 (which the code was ported from) does."""
+    M = (1 << 64) - 1
+    zx, zy = val & M, val >> 64
+    tmp1 = 0
+
+    def add_u64(a, b, out):     # -> (carry, new value of *out)
+        s = a + b
+        if s <= M:
+            return 0, s
+        return 1, ((s & M) if faithful_seal else out)
+
+    carry = (zx * cr0) >> 64
+    p = zx * cr1
+    c, tmp1 = add_u64(p & M, carry, tmp1)
+    tmp3 = ((p >> 64) + c) & M
+    p = zy * cr0
+    c, tmp1 = add_u64(tmp1, p & M, tmp1)
+    carry = ((p >> 64) + c) & M
+    tmp1 = (zy * cr1 + tmp3 + carry) & M
+    r = (zx - tmp1 * modulus) & M
+    return r - modulus if r >= modulus else r
+
+
+CR0_Q, CR1_Q = 7906011006380390721, 275
+
+
+def test_barrett_u128_quirk_is_restated(oracle_mod):
+    """The oracle follows arith.rs:155-180 literally, quirk included: with constants for which the dropped carry matters
+    (cr0 = 2^64 - 1 is enough; the function is plain arithmetic on its arguments) it returns what the Rust code returns,
+    NOT what a carry-correct port would."""
+    M = (1 << 64) - 1
+    ex = lambda m, c0, c1, v: oracle_mod.scalar("barrett_reduction_u128_raw", m, c0, c1, v & M, v >> 64)
+    rnd = random.Random(7)
+    differ = 0
+    for _ in range(20000):
+        v = rnd.randrange(0, 1 << 100)
+        lit = _rust_barrett_reduction_u128_raw(Q, M, 275, v)
+        assert ex(Q, M, 275, v) == lit
+        differ += lit != _rust_barrett_reduction_u128_raw(Q, M, 275, v, faithful_seal=True)
+    assert differ > 100, "the quirk was not exercised"
+    for _ in range(20000):                            # the real constants, arbitrary 85-bit values and multiples of Q
+        v = rnd.randrange(0, 1 << 85) if rnd.random() < 0.5 else rnd.randrange(1, 1 << 29) * Q + rnd.randrange(0, 4)
+        assert ex(Q, CR0_Q, CR1_Q, v) == _rust_barrett_reduction_u128_raw(Q, CR0_Q, CR1_Q, v)
+
+
+def test_barrett_u128_quirk_cannot_show_with_q(oracle_mod):
+    """DESIGN.md section 5.  With Q's own constants the reference's barrett_reduction_u128 returns the CANONICAL residue for
+    every input below 2^127, quirk or not, so an exact reconstruction (the GPU's Garner form) is bit-identical to it:
+      * a value >= Q can only come out when (A) the quotient estimate is one short AND (B) the quirk drops a carry;
+      * (A) needs the fractional part of val R / 2^128 within val rho / (Q 2^128) < 1/2 of 1, i.e. the low-word sum
+        S = hi(zx cr0) + lo(zx cr1) + lo(zy cr0) must be, mod 2^64, above 2^63; (B) needs both low-word additions to carry,
+        S >= 2 * 2^64; together S >= 2.5 * 2^64;
+      * but hi(zx cr0) < cr0 = 0.4286 * 2^64, so S < 2.43 * 2^64.
+    Checked numerically on the inputs that stress each side."""
+    M = (1 << 64) - 1
+    assert CR0_Q < 0.43 * 2**64
+    rnd = random.Random(13)
+    lit = lambda v: _rust_barrett_reduction_u128_raw(Q, CR0_Q, CR1_Q, v)
+    n_short = n_lost = 0
+    for i in range(120000):
+        kind = i % 4
+        if kind == 0:
+            v = rnd.randrange(1, 1 << 29) * Q + rnd.randrange(0, 1 << 10)       # estimate one short (A)
+        elif kind == 1:
+            v = rnd.randrange(0, 1 << 85)
+        elif kind == 2:
+            v = (rnd.randrange(0, 1 << 21) << 64) | (M - rnd.randrange(0, 1 << 20))   # zx at the top: both additions carry (B)
+        else:
+            v = rnd.randrange(1, 1 << 62) * Q + rnd.randrange(0, 1 << 30)       # far beyond the 85 bits crt_compose needs
+        got = lit(v)
+        assert got == v % Q, hex(v)
+        n_short += (v * ((1 << 128) // Q)) >> 128 != v // Q
+        n_lost += got == v % Q and _rust_barrett_reduction_u128_raw(Q, CR0_Q, CR1_Q, v, faithful_seal=True) == v % Q
+    assert n_short > 1000
+
+
+def test_crt_compose_2_is_always_canonical(tp):
+    """params.rs:207-214 on canonical residues returns the canonical CRT value: every r < 2^14 (x = y = r), the values just
+    below Q, random pairs and the pairs with the largest 128-bit intermediate."""
+    inv_q1_mod_q0 = pow(Q1, -1, Q0)
+    inv_q0_mod_q1 = pow(Q0, -1, Q1)
+    a, b = Q1 * inv_q1_mod_q0, Q0 * inv_q0_mod_q1
+    assert a + b == Q + 1
+
+    def exact(x, y):
+        return (x * a + y * b) % Q
+
+    for r in list(range(0, 1 << 14)) + [Q - 1 - k for k in range(0, 1 << 12)]:
+        x, y = r % Q0, r % Q1
+        assert tp.crt_compose_2(x, y) == r == exact(x, y)
+    rnd = random.Random(11)
+    for _ in range(60000):
+        x, y = rnd.randrange(Q0), rnd.randrange(Q1)
+        got = tp.crt_compose_2(x, y)
+        assert got == exact(x, y)
+        assert got == _rust_barrett_reduction_u128_raw(Q, CR0_Q, CR1_Q, x * a + y * b)
+    for x in range(Q0 - 64, Q0):
+        for y in range(Q1 - 64, Q1):
+            assert tp.crt_compose_2(x, y) == exact(x, y)
