@@ -116,8 +116,12 @@ def cpu_baseline(cfg_name, cfg):
                lib/server/src/compute/dot_product.rs:59-95, every core busy: z-rows of the sweep and subtrees of the
                fold spread over the threads, lib/server/src/server.rs:53-55).  C1 (configs[0]) is also timed in full."""
     import oracle
-    threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    max_threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     N = 2048
+    # "every core" is not automatically the fastest team on an SMT host: the all-core mode is timed with the team size
+    # that a short scan over {all logical CPUs, half, a quarter} finds best for the sweep, and `cores` reports that size
+    scan = {}
+    threads = max_threads
     rng = np.random.default_rng(5)
 
     def rand_words(n):   # residues < 2^28 in both limbs (the MAC loops are data independent)
@@ -164,6 +168,17 @@ def cpu_baseline(cfg_name, cfg):
             oracle.sweep_rows(dbs[:nz1 * num_per * dim0], v_reg[:nz1 * dim0 * 2], nz1, dim0, num_per)
         t_sweep_1 = (time.time() - t0) * (1 if full else (N / nz1) * planes)
         oracle.sweep_rows_avx2(dbs[:num_per * dim0], v_reg[:dim0 * 2], 1, dim0, num_per)   # thread-pool warm-up
+        nonlocal threads
+        if not scan and max_threads >= 8:
+            nzs = min(nz, max(8, (1 << 27) // (num_per * dim0)))   # ~1 GiB of words per trial
+            for t in sorted({max_threads, max(1, max_threads // 2), max(1, max_threads // 4)}):
+                oracle.set_threads(t)
+                oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
+                t0 = time.time()
+                oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
+                scan[t] = time.time() - t0
+            threads = min(scan, key=scan.get)
+        oracle.set_threads(threads)
         t0 = time.time()
         for _ in range(reps):
             oracle.sweep_rows_avx2(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
@@ -201,6 +216,7 @@ def cpu_baseline(cfg_name, cfg):
     return {
         "value": main["all_core_qps"], "unit": "queries/s", "cores": threads, "kind": "port",
         "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        "thread_scan_seconds": {str(k): v for k, v in sorted(scan.items())},
         "modes": {"all_core": main["all_core_qps"], "faithful": main["faithful_qps"]},
         "seconds_per_query": main["seconds"],
         "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = all_core mode (every core busy: AVX2 "
@@ -401,7 +417,7 @@ def main():
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters), run.sweep_launches(db)
     run.free()
     batch_pass = None
-    if mode in ("single", "replicas") and batch > 1:
+    if mode in ("single", "replicas") and batch > 1 and cfg["nu_2"] >= 7 and (1 << cfg["nu_1"]) % 2 == 0:   # PACKED databases only
         runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 8))]
         sp.paths_taken()
         pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)

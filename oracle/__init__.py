@@ -529,6 +529,11 @@ class Client:
 
 
 # ---- free functions used by the KAT tests
+def set_threads(n):
+    """OpenMP team size of the parallel sections (returns the previous maximum)"""
+    return int(lib().orc_set_threads(C.c_int(n)))
+
+
 def get_barrett_crs(m):
     o = np.zeros(2, dtype=np.uint64)
     lib().orc_get_barrett_crs(_u64(m), _p(o))

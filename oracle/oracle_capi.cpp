@@ -108,6 +108,17 @@ void orc_ntt_table(void* h, uint64_t crt, uint64_t which, uint64_t* out) {
 }
 
 // ------------------------------------------------------------------- arith
+// OpenMP team size for the parallel sections that follow (cpu_baseline scans it); returns the previous maximum
+int orc_set_threads(int n) {
+#ifdef _OPENMP
+  const int prev = omp_get_max_threads();
+  if (n > 0) omp_set_num_threads(n);
+  return prev;
+#else
+  (void)n;
+  return 1;
+#endif
+}
 void orc_get_barrett_crs(uint64_t modulus, uint64_t* out2) { get_barrett_crs(modulus, &out2[0], &out2[1]); }
 void orc_divide_uint192(const uint64_t* num3, uint64_t den, uint64_t* rem3, uint64_t* quot3) {
   divide_uint192_inplace(num3, den, rem3, quot3);

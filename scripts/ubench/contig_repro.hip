@@ -5,7 +5,10 @@
 // Mode 2 ("fragment"): first fill most of the device with 1-GiB buffers, free every other one (free memory = many 1-GiB
 // holes), THEN ask for the contiguous range: it can only be satisfied by relocating live buffers -- the situation the
 // round-2 record blames.  The surviving 1-GiB buffers are checked as well.
-// hipcc --offload-arch=gfx950 -O2 contig_repro.hip -o contig_repro ;  ./contig_repro [big_gib=56] [nbuf=96] [rounds=3] [contiguous=1|2]
+// Mode 3 ("history"): what the library did when the corruption was seen (scripts/diag_c2.py): a few SMALL contiguous
+// allocations are made, filled and freed first (the databases of small configurations), then the plain small buffers
+// (public parameters), then the big contiguous one.
+// hipcc --offload-arch=gfx950 -O2 contig_repro.hip -o contig_repro ;  ./contig_repro [big_gib=56] [nbuf=96] [rounds=3] [contiguous=1|2|3]
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
@@ -20,7 +23,55 @@ __global__ void k_check(const unsigned* p, size_t n, unsigned buf, unsigned long
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b += p[i] != pat(buf, i);
   if (b) atomicAdd(bad, b);
 }
+// Mode 4 ("reuse"): the sequence that actually fails in the library (scripts/diag_c2b.py: the public parameters are wrong
+// right after sp_pp_deserialize, before any large allocation): small contiguous buffers are written by a KERNEL and freed;
+// a plain hipMalloc then reuses the memory, is zero-filled (hipMemset), receives host data (hipMemcpy H2D) and is read by
+// a kernel.  Does the kernel see the host data?
+__global__ void k_scramble(unsigned* p, size_t n, unsigned seed) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = (unsigned)(i * 747796405u) ^ seed ^ 0xDEAD0000u;
+}
+__global__ void k_copy(unsigned* dst, const unsigned* src, size_t n) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) dst[i] = src[i];
+}
+static int reuse_mode(int rounds, int use_contig, int use_memset) {
+  int any = 0;
+  for (int round = 0; round < rounds; round++) {
+    for (int i = 0; i < 5; i++) {   // the databases of the small configurations
+      void* p = nullptr;
+      const size_t b = (size_t)(i == 1 || i == 2 ? 32 : 16) << 20;
+      hipError_t e = use_contig ? hipExtMallocWithFlags(&p, b, hipDeviceMallocContiguous) : hipMalloc(&p, b);
+      if (e != hipSuccess) { printf("small allocation failed: %s\n", hipGetErrorName(e)); return 2; }
+      k_scramble<<<1024, 256>>>((unsigned*)p, b / 4, (unsigned)(round * 16 + i));
+      k_check<<<64, 256>>>((const unsigned*)p, b / 4, 1u, nullptr == p ? nullptr : (unsigned long long*)p);  // a second kernel reads it (result unused)
+      CK(hipDeviceSynchronize());
+      CK(hipFree(p));
+    }
+    const size_t words = 17956864 / 4;
+    std::vector<unsigned> host(words), back(words);
+    for (size_t i = 0; i < words; i++) host[i] = pat(4242u + round, i);
+    unsigned *a = nullptr, *b = nullptr;
+    CK(hipMalloc(&a, words * 4));
+    if (use_memset) { CK(hipMemset(a, 0, words * 4)); CK(hipDeviceSynchronize()); }
+    CK(hipMemcpy(a, host.data(), words * 4, hipMemcpyHostToDevice));
+    CK(hipMalloc(&b, words * 4));
+    if (use_memset) { CK(hipMemset(b, 0, words * 4)); CK(hipDeviceSynchronize()); }
+    k_copy<<<2048, 256>>>(b, a, words);          // the kernel that consumes the upload (the NTT of the public parameters)
+    CK(hipDeviceSynchronize());
+    CK(hipMemcpy(back.data(), b, words * 4, hipMemcpyDeviceToHost));
+    size_t bad = 0, first = 0, zeros = 0;
+    for (size_t i = 0; i < words; i++)
+      if (back[i] != host[i]) { if (!bad) first = i; bad++; zeros += back[i] == 0; }
+    printf("round %d (%s small buffers, %s hipMemset): %zu of %zu words read by the kernel differ from the upload (first at byte 0x%zx, %zu of them zero)\n", round,
+           use_contig ? "CONTIGUOUS" : "plain", use_memset ? "with" : "without", bad, words, first * 4, zeros);
+    any |= bad != 0;
+    CK(hipFree(a));
+    CK(hipFree(b));
+  }
+  printf(any ? "RESULT: a kernel read STALE data from a freshly uploaded buffer\n" : "RESULT: uploads were read correctly\n");
+  return any;
+}
 int main(int argc, char** argv) {
+  if (argc > 4 && atoi(argv[4]) >= 4) return reuse_mode(argc > 3 ? atoi(argv[3]) : 3, atoi(argv[4]) == 4 || atoi(argv[4]) == 6, atoi(argv[4]) != 6);   // 4: contiguous + memset, 5: plain + memset, 6: contiguous, no memset
   const double big_gib = argc > 1 ? atof(argv[1]) : 56.0;
   const int nbuf = argc > 2 ? atoi(argv[2]) : 96, rounds = argc > 3 ? atoi(argv[3]) : 3, contiguous = argc > 4 ? atoi(argv[4]) : 1;
   unsigned long long* d_bad;
@@ -44,6 +95,21 @@ int main(int argc, char** argv) {
       CK(hipDeviceSynchronize());
       CK(hipMemGetInfo(&fr, &tot));
       printf("round %d: fragmented: %zu live 1-GiB buffers, %.1f GiB free in 1-GiB holes\n", round, gib.size(), fr / 1073741824.0);
+    }
+    if (contiguous == 3) {
+      for (int i = 0; i < 5; i++) {
+        void* p = nullptr;
+        const size_t b = (size_t)(16 + 8 * i) << 20;
+        hipError_t e3 = hipExtMallocWithFlags(&p, b, hipDeviceMallocContiguous);
+        if (e3 == hipSuccess) {
+          CK(hipMemset(p, 0x11 * (i + 1), b));
+          CK(hipDeviceSynchronize());
+          CK(hipFree(p));
+        } else {
+          (void)hipGetLastError();
+        }
+      }
+      printf("round %d: five small contiguous allocations made, filled and freed\n", round);
     }
     std::vector<unsigned*> bufs(nbuf);
     std::vector<size_t> words(nbuf);

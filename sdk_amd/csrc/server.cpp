@@ -109,6 +109,7 @@ void* devbuf_alloc(size_t bytes, size_t* guard, long* serial) {
   }
   *guard = gb;
   *serial = -1;
+  if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] hipMalloc %zu bytes -> [%p, %p)\n", bytes + 2 * gb, q, (char*)q + bytes + 2 * gb);
   void* const block = q;  // what hipMalloc returned (q moves past the front guard below)
   try {
   if (gb) {
@@ -146,6 +147,7 @@ void devbuf_cache_sync() {
 }
 void devbuf_free(void* p, size_t bytes, size_t guard, long serial) {
   if (!p) return;
+  if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] hipFree %p\n", (void*)((char*)p - guard));
   if (guard) {
     // every guard byte still equals the byte farthest from the buffer (the fill value) unless something wrote there
     (void)hipDeviceSynchronize();

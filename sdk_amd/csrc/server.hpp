@@ -83,7 +83,7 @@ struct DevBuf {
     if (want_contiguous && !devbuf_guards_on()) {
       void* q = nullptr;
       const hipError_t e = hipExtMallocWithFlags(&q, count * sizeof(T), hipDeviceMallocContiguous);  // see db_create_impl: unsafe
-      if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] contiguous allocation of %zu bytes: %s\n", count * sizeof(T), hipGetErrorName(e));
+      if (getenv("SPIRAL_ALLOC_DEBUG")) fprintf(stderr, "[spiral] contiguous allocation of %zu bytes: %s -> [%p, %p)\n", count * sizeof(T), hipGetErrorName(e), q, (char*)q + count * sizeof(T));
       if (e == hipSuccess && q) {
         p = (T*)q;
         n = count;
