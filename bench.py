@@ -458,8 +458,8 @@ def main():
     if rank == 0:
         q_per_step = batch * (world if replicas else 1) if mode in ("single", "replicas") else 1
         traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches)
-        # the roofline block always describes the kernel sp_bench_sweep / the stage events time: the single-query sweep
-        # (batched steps run k_sweep_packed_batch<B>, whose pass time is in profiles/r02_batch8_kernel_stats.md)
+        # the roofline block describes the kernel sp_bench_sweep / the stage events time: the single-query sweep; batched
+        # steps add roofline.batched_pass (the pass kernel of the group, timed by sp_bench_sweep_batch)
         kernel = "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2"
         workload_how = {
             "single": "unsharded, one query per step" if batch == 1 else "unsharded, %d queries per step (<= 8 per database pass)" % batch,

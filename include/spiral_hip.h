@@ -243,6 +243,17 @@ int sp_comm_barrier(sp_comm_t*);  /* one tiny all-gather + host wait: every rank
  * world).  Byte-identical to sp_process_query over the unsharded database. */
 int sp_process_query_sharded(sp_comm_t*, const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
                              const sp_db_t* shard, uint8_t* out, size_t out_cap, size_t* out_len);
+/* The same for a LIST of queries (what a /private-read request carries, lib/server/src/bin/server.rs:152-158),
+ * software-pipelined: query k + 1 is deserialised and expanded while query k's planes are swept and exchanged, so the
+ * replicated expansion leaves the per-query critical path.  Every rank passes the same list; response k is written at
+ * out + k * out_stride on rank 0 (out_stride >= response_bytes), *out_len = response_bytes there and 0 elsewhere.
+ * Byte-identical to n calls of sp_process_query_sharded. */
+int sp_process_queries_sharded(sp_comm_t*, const sp_params_t*, const sp_pp_t* const* pps, const uint8_t* const* queries,
+                               const size_t* query_lens, int n, const sp_db_t* shard, uint8_t* out, size_t out_stride,
+                               size_t* out_len);
+/* Allocates the communicator's exchange buffers and events for `params` now, so that no sharded query allocates
+ * anything (otherwise the first query with new params does).  Not a collective. */
+int sp_comm_reserve(sp_comm_t*, const sp_params_t* params);
 /* milliseconds of the last sharded query on this rank (HIP events on the query stream): [0] the per-plane sweep
  * launches (the exchanges of the earlier planes run beside them), [1] exchange tail + local fold + all-gather,
  * [2] reserved */

@@ -129,6 +129,10 @@ pub mod sys {
         pub fn sp_process_query_sharded(c: *mut sp_comm_t, p: *const sp_params_t, pp: *const sp_pp_t, query: *const u8,
                                         query_len: usize, shard: *const sp_db_t, out: *mut u8, out_cap: usize,
                                         out_len: *mut usize) -> c_int;
+        pub fn sp_process_queries_sharded(c: *mut sp_comm_t, p: *const sp_params_t, pps: *const *const sp_pp_t, queries: *const *const u8,
+                                          query_lens: *const usize, n: c_int, shard: *const sp_db_t, out: *mut u8, out_stride: usize,
+                                          out_len: *mut usize) -> c_int;
+        pub fn sp_comm_reserve(c: *mut sp_comm_t, p: *const sp_params_t) -> c_int;
         pub fn sp_comm_timings(c: *const sp_comm_t, ms3: *mut f32) -> c_int;
         // ---- request layer: lib/server/src/bin/server.rs ServerState, /setup, /private-read (no HTTP)
         pub fn sp_server_create(params: *const sp_params_t, db: *const sp_db_t) -> *mut sp_server_t;

@@ -166,7 +166,7 @@ const char* sp_path_name(int bit) {
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
-                                "sweep_batch_mfma"};
+                                "sweep_batch_mfma", "custom_transport"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -269,7 +269,42 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
     // (profiles/r02_sweep_experiments.md) but is NOT SAFE on this stack: asking the driver for a contiguous range makes
     // it move other live buffers of the process, and their contents were observed to change (public parameters
     // allocated just before a 56 GiB database: profiles/r02_stale_reads.md) -- wrong responses on some machines.
-    d->words.alloc_streaming((db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8, tunable("db_contiguous", 0) != 0);
+    const size_t db_words = (db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8;
+    d->words.alloc_streaming(db_words, tunable("db_contiguous", 0) != 0);
+    // Placement lottery: how a multi-GiB hipMalloc happens to be backed moves the sweep by up to
+    // 9 % (2.19 .. 2.40 ms per C2 plane, same binary).  db_place_tries = n > 1 (default 1 = off; PACKED databases of
+    // at least 4 GiB, and only while a second copy fits in free memory): time the sweep's read pattern on up to n
+    // fresh plain allocations and keep the fastest; the others are freed again.  Plain hipMalloc / hipFree only.
+    // Measured (profiles/r03_placement.md): the candidates of one process differ by ~1 %, the spread is between
+    // processes / machines -- best-of-n buys nothing, so it is off.
+    const long tries = tunable("db_place_tries", 1);
+    if (d->packed && tries > 1 && d->words.bytes() >= ((size_t)4 << 30) && tunable("db_contiguous", 0) == 0) {
+      DevBuf<u32> sink(16);
+      float best = stream_probe_ms(d->words.p, d->words.bytes(), sink.p, 0);
+      const float first = best;
+      int kept = 0, made = 1;
+      for (long t = 1; t < tries && best > 0.f; t++) {
+        size_t fr = 0, tot = 0;
+        HIP_CHECK(hipMemGetInfo(&fr, &tot));
+        if (fr < d->words.bytes() + ((size_t)8 << 30)) break;
+        DevBuf<u64> cand;
+        try {
+          cand.alloc(db_words);
+        } catch (const OomError&) {
+          break;
+        }
+        made++;
+        const float ms = stream_probe_ms(cand.p, cand.bytes(), sink.p, 0);
+        if (ms > 0.f && ms < best) {
+          best = ms;
+          kept = (int)t;
+          std::swap(d->words, cand);   // `cand` now owns the slower buffer and frees it at the end of this iteration
+        }
+      }
+      if (getenv("SPIRAL_ALLOC_DEBUG"))
+        fprintf(stderr, "[spiral] database placement: %d candidates, first %.3f ms, kept #%d at %.3f ms per %.1f GiB pass\n", made, first, kept, best,
+                d->words.bytes() / 1073741824.0);
+    }
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();

@@ -186,6 +186,94 @@ int sp_comm_timings(const sp_comm_t* c, float* ms3) {
   return SP_OK;
 }
 
+// sizes of the exchange buffers for `h`, allocated now (sp_comm_reserve) or, failing that, by the first sharded query
+static void comm_reserve(sp_comm_t* c, const sp_params_t* h) {
+  const int G = c->world;
+  const size_t planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
+  const size_t num_per = (size_t)1 << sp_params_get(h, "db_dim_2");
+  if ((size_t)G > num_per) throw Fail{SP_E_ARG, "more ranks than second-dimension columns (num_per): use fewer shards"};
+  const size_t chunk = 4 * (size_t)sp_params_get(h, "poly_len") * num_per / (size_t)G;   // u32 [r][crt][z][ii / G] of one plane
+  const size_t local_words = planes * 2 * (size_t)sp_params_get(h, "poly_len");         // one raw ciphertext per plane
+  c->ensure(c->mine, c->mine_bytes, planes * chunk * sizeof(uint32_t));
+  c->ensure(c->gathered, c->gathered_bytes, (size_t)G * local_words * sizeof(uint64_t));
+  if (c->ev_plane.size() < planes) {
+    const size_t old = c->ev_plane.size();
+    c->ev_plane.resize(planes, nullptr);
+    for (size_t i = old; i < planes; i++) hip_ok(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming), "hipEventCreate");
+  }
+}
+
+int sp_comm_reserve(sp_comm_t* c, const sp_params_t* h) {
+  if (!c || !h) {
+    sp_set_last_error_("null argument");
+    return SP_E_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  return guarded_comm([&] { comm_reserve(c, h); });
+}
+
+namespace {
+// One sharded query as three enqueue stages, so that a list of queries can be software-pipelined: while query k's planes are
+// swept, query k + 1 is already expanding on its own streams.
+struct ShardedRun {
+  sp_query_t* q = nullptr;
+  hipStream_t main = nullptr;
+  size_t planes = 0, local_words = 0;
+};
+void sharded_begin(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
+                   const sp_db_t* shard, ShardedRun& r) {
+  r.planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
+  r.q = sp_query_begin_for_db(h, pp, query, query_len, shard);
+  if (!r.q) throw Fail{SP_E_ARG, std::string("sp_query_begin_for_db: ") + sp_last_error()};
+  r.main = (hipStream_t)sp_query_stream(r.q);
+  r.local_words = sp_query_local_cts_words(r.q);
+  (void)c;
+}
+void sharded_sweeps(sp_comm_t* c, const sp_db_t* shard, ShardedRun& r, bool timed) {
+  const int G = c->world;
+  uint32_t* part = (uint32_t*)sp_query_partial_ptr(r.q);
+  if (!part) throw Fail{SP_E_OOM, std::string("partial buffer: ") + sp_last_error()};
+  const size_t words = sp_query_partial_words(r.q), pw = words / r.planes, chunk = pw / (size_t)G;
+  if (timed) hip_ok(hipEventRecord(c->ev_t[0], r.main), "hipEventRecord");
+  for (size_t pl = 0; pl < r.planes; pl++) {
+    sp_ok(sp_query_sweep_scatter_plane(r.q, shard, G, (int)pl), "sp_query_sweep_scatter_plane");
+    hip_ok(hipEventRecord(c->ev_plane[pl], r.main), "hipEventRecord");
+    hip_ok(hipStreamWaitEvent(c->stream, c->ev_plane[pl], 0), "hipStreamWaitEvent");
+    // plane pl's region is [g][r][crt][z][ii / G]: rank g receives the sum of everybody's chunk g
+    if (c->reduce_scatter(part + pl * pw, (uint32_t*)c->mine + pl * chunk, chunk) != 0)
+      throw Fail{SP_E_HIP, "custom reduce_scatter_u32 failed"};
+  }
+  if (timed) hip_ok(hipEventRecord(c->ev_t[1], r.main), "hipEventRecord");
+  hip_ok(hipEventRecord(c->ev_x, c->stream), "hipEventRecord");
+  hip_ok(hipStreamWaitEvent(r.main, c->ev_x, 0), "hipStreamWaitEvent");
+}
+void sharded_finish(sp_comm_t* c, ShardedRun& r, uint8_t* out, size_t out_cap, size_t* out_len, bool timed) {
+  const int G = c->world;
+  sp_ok(sp_query_fold_local(r.q, c->mine, G), "sp_query_fold_local");
+  hip_ok(hipEventRecord(c->ev_f, r.main), "hipEventRecord");
+  hip_ok(hipStreamWaitEvent(c->stream, c->ev_f, 0), "hipStreamWaitEvent");
+  if (c->all_gather(sp_query_local_cts_ptr(r.q), c->gathered, r.local_words) != 0)
+    throw Fail{SP_E_HIP, "custom all_gather_u64 failed"};
+  hip_ok(hipEventRecord(c->ev_g, c->stream), "hipEventRecord");
+  hip_ok(hipStreamWaitEvent(r.main, c->ev_g, 0), "hipStreamWaitEvent");
+  if (timed) hip_ok(hipEventRecord(c->ev_t[2], r.main), "hipEventRecord");
+  if (c->rank == 0) {
+    sp_ok(sp_query_finish_gathered(r.q, c->gathered, G, out, out_cap, out_len), "sp_query_finish_gathered");
+  } else {
+    *out_len = 0;
+    sp_ok(sp_query_sync(r.q), "sp_query_sync");
+  }
+  // the exchange buffers (mine / gathered) are reused by the next query: its reduce-scatters are enqueued on c->stream
+  // after this query's all-gather, and this query's local fold (reader of `mine`) is complete once the host returned
+  // from finish / sync above
+  hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+}
+void note_transport(const sp_comm_t* c) {
+  // PATH_RCCL (bit 19): the collectives were RCCL's, issued by the library; PATH_CUSTOM_TRANSPORT (bit 25): the host's
+  sp_note_path_(c->custom ? (1ull << 25) : (1ull << 19));
+}
+}  // namespace
+
 int sp_process_query_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query,
                              size_t query_len, const sp_db_t* shard, uint8_t* out, size_t out_cap, size_t* out_len) {
   if (!c || !h || !pp || !query || !shard || !out_len || (c->rank == 0 && !out)) {
@@ -193,68 +281,69 @@ int sp_process_query_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* 
     return SP_E_ARG;
   }
   std::lock_guard<std::mutex> lk(c->mu);
-  sp_query_t* q = nullptr;
+  ShardedRun r;
   int rc = guarded_comm([&] {
-    const int G = c->world;
     int dev = 0;
     hip_ok(hipGetDevice(&dev), "hipGetDevice");
     if (dev != c->device) throw Fail{SP_E_ARG, "the communicator was created on another HIP device"};
-    const size_t planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
-    if ((size_t)G > ((size_t)1 << sp_params_get(h, "db_dim_2")))
-      throw Fail{SP_E_ARG, "more ranks than second-dimension columns (num_per): use fewer shards"};
-    if (c->ev_plane.size() < planes) {
-      const size_t old = c->ev_plane.size();
-      c->ev_plane.resize(planes, nullptr);
-      for (size_t i = old; i < planes; i++) hip_ok(hipEventCreateWithFlags(&c->ev_plane[i], hipEventDisableTiming), "hipEventCreate");
-    }
-    q = sp_query_begin_for_db(h, pp, query, query_len, shard);
-    if (!q) throw Fail{SP_E_ARG, std::string("sp_query_begin_for_db: ") + sp_last_error()};
-    hipStream_t main = (hipStream_t)sp_query_stream(q);
-    uint32_t* part = (uint32_t*)sp_query_partial_ptr(q);
-    if (!part) throw Fail{SP_E_OOM, std::string("partial buffer: ") + sp_last_error()};
-    const size_t words = sp_query_partial_words(q), pw = words / planes, chunk = pw / (size_t)G;
-    const size_t local_words = sp_query_local_cts_words(q);
-    c->ensure(c->mine, c->mine_bytes, planes * chunk * sizeof(uint32_t));
-    c->ensure(c->gathered, c->gathered_bytes, (size_t)G * local_words * sizeof(uint64_t));
-    hip_ok(hipEventRecord(c->ev_t[0], main), "hipEventRecord");
-    for (size_t pl = 0; pl < planes; pl++) {
-      sp_ok(sp_query_sweep_scatter_plane(q, shard, G, (int)pl), "sp_query_sweep_scatter_plane");
-      hip_ok(hipEventRecord(c->ev_plane[pl], main), "hipEventRecord");
-      hip_ok(hipStreamWaitEvent(c->stream, c->ev_plane[pl], 0), "hipStreamWaitEvent");
-      // plane pl's region is [g][r][crt][z][ii / G]: rank g receives the sum of everybody's chunk g
-      if (c->reduce_scatter(part + pl * pw, (uint32_t*)c->mine + pl * chunk, chunk) != 0)
-        throw Fail{SP_E_HIP, "custom reduce_scatter_u32 failed"};
-    }
-    hip_ok(hipEventRecord(c->ev_t[1], main), "hipEventRecord");
-    hip_ok(hipEventRecord(c->ev_x, c->stream), "hipEventRecord");
-    hip_ok(hipStreamWaitEvent(main, c->ev_x, 0), "hipStreamWaitEvent");
-    sp_ok(sp_query_fold_local(q, c->mine, G), "sp_query_fold_local");
-    hip_ok(hipEventRecord(c->ev_f, main), "hipEventRecord");
-    hip_ok(hipStreamWaitEvent(c->stream, c->ev_f, 0), "hipStreamWaitEvent");
-    if (c->all_gather(sp_query_local_cts_ptr(q), c->gathered, local_words) != 0)
-      throw Fail{SP_E_HIP, "custom all_gather_u64 failed"};
-    hip_ok(hipEventRecord(c->ev_g, c->stream), "hipEventRecord");
-    hip_ok(hipStreamWaitEvent(main, c->ev_g, 0), "hipStreamWaitEvent");
-    hip_ok(hipEventRecord(c->ev_t[2], main), "hipEventRecord");
-    if (c->rank == 0) {
-      sp_ok(sp_query_finish_gathered(q, c->gathered, G, out, out_cap, out_len), "sp_query_finish_gathered");
-    } else {
-      *out_len = 0;
-      sp_ok(sp_query_sync(q), "sp_query_sync");
-    }
-    hip_ok(hipStreamSynchronize(c->stream), "hipStreamSynchronize");
+    comm_reserve(c, h);   // no-op after sp_comm_reserve / the first query with these params
+    sharded_begin(c, h, pp, query, query_len, shard, r);
+    sharded_sweeps(c, shard, r, true);
+    sharded_finish(c, r, out, out_cap, out_len, true);
     // [0] sweep launches incl. the exchanges overlapped with them, [1] exchange tail + local fold + all-gather
     (void)hipEventElapsedTime(&c->ms[0], c->ev_t[0], c->ev_t[1]);
     (void)hipEventElapsedTime(&c->ms[1], c->ev_t[1], c->ev_t[2]);
-    sp_note_path_(1ull << 19);  // PATH_RCCL (kernels.hpp)
+    note_transport(c);
   });
-  if (q) {
+  if (r.q) {
     if (rc != SP_OK) {
       (void)hipStreamSynchronize(c->stream);
-      (void)sp_query_sync(q);
+      (void)sp_query_sync(r.q);
     }
-    sp_query_free(q);
+    sp_query_free(r.q);
   }
+  return rc;
+}
+
+int sp_process_queries_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* const* pps, const uint8_t* const* queries,
+                               const size_t* query_lens, int n, const sp_db_t* shard, uint8_t* out, size_t out_stride,
+                               size_t* out_len) {
+  if (!c || !h || !pps || !queries || !query_lens || n < 0 || !shard || !out_len || (c->rank == 0 && n > 0 && !out)) {
+    sp_set_last_error_("null argument");
+    return SP_E_ARG;
+  }
+  std::lock_guard<std::mutex> lk(c->mu);
+  ShardedRun cur, nxt;
+  int rc = guarded_comm([&] {
+    int dev = 0;
+    hip_ok(hipGetDevice(&dev), "hipGetDevice");
+    if (dev != c->device) throw Fail{SP_E_ARG, "the communicator was created on another HIP device"};
+    *out_len = 0;
+    if (n == 0) return;
+    comm_reserve(c, h);
+    sharded_begin(c, h, pps[0], queries[0], query_lens[0], shard, cur);
+    for (int k = 0; k < n; k++) {
+      sharded_sweeps(c, shard, cur, k == n - 1);
+      // query k + 1 expands (on its own workspace's streams) while query k's planes are swept and exchanged
+      if (k + 1 < n) sharded_begin(c, h, pps[k + 1], queries[k + 1], query_lens[k + 1], shard, nxt);
+      size_t len = 0;
+      sharded_finish(c, cur, c->rank == 0 ? out + (size_t)k * out_stride : nullptr, out_stride, &len, k == n - 1);
+      if (c->rank == 0) *out_len = len;
+      sp_query_free(cur.q);
+      cur = nxt;
+      nxt = ShardedRun{};
+    }
+    cur = ShardedRun{};
+    (void)hipEventElapsedTime(&c->ms[0], c->ev_t[0], c->ev_t[1]);
+    (void)hipEventElapsedTime(&c->ms[1], c->ev_t[1], c->ev_t[2]);
+    note_transport(c);
+  });
+  for (ShardedRun* r : {&cur, &nxt})
+    if (r->q) {
+      (void)hipStreamSynchronize(c->stream);
+      (void)sp_query_sync(r->q);
+      sp_query_free(r->q);
+    }
   return rc;
 }
 

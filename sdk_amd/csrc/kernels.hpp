@@ -42,12 +42,13 @@ enum PathBit : u64 {
   PATH_FOLD_TAIL_PERSIST = 1ull << 16,// k_fold_tail (all small levels in one launch, grid barrier per level)
   PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_head (first expansion rounds in one launch)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
-  PATH_RCCL = 1ull << 19,             // collectives issued by the library itself (sp_comm_*)
+  PATH_RCCL = 1ull << 19,             // RCCL collectives issued by the library itself (sp_comm_create)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
   PATH_CU_SPLIT = 1ull << 21,         // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
   PATH_EXPAND_SPLIT = 1ull << 22,     // odd expansion subtree + GSW side on the second stream, beside the even subtree
   PATH_PIPE_CLASS_SPLIT = 1ull << 23, // a plane swept and folded as two chunk-parity classes (pipe_split)
-  PATH_SWEEP_MFMA = 1ull << 24        // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
+  PATH_SWEEP_MFMA = 1ull << 24,       // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
+  PATH_CUSTOM_TRANSPORT = 1ull << 25  // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -270,6 +271,9 @@ struct SweepDesc {
   // first log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and therefore stay inside one parity
   // class, which lets the pipeline fold one half of a plane while the other half is still being swept.
   int chunk_step, chunk_off;
+  // non-temporal (streaming) output stores: HBM writes mixed into the read stream cost 3-4x a read byte on this part, a
+  // quarter less as streaming stores (scripts/ubench/rw_mix.hip); switch sweep_nt_store
+  int nt_store;
 };
 // Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
 // i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.
@@ -305,6 +309,8 @@ inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s);
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);
 const char* sweep_kernel_name(int num_per);
+// milliseconds to stream `bytes` with the PACKED sweep's access pattern (best of two timed passes; 0 = buffer too small)
+float stream_probe_ms(const void* buf, size_t bytes, u32* sink, hipStream_t s);
 // reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order
 // words already on the device), dst plane base; keeps rows j0..j0+nj
 void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,

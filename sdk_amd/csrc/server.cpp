@@ -509,8 +509,18 @@ namespace spiral {
 // ---------------------------------------------------------------------------------- workspace
 Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   device = D.device;
-  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-  HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  // stream_prio (default 0 = off): 1 = the main stream (even expansion chain, sweeps) at the highest dispatch priority and
+  // the second stream (odd expansion subtree, overlapped folds) at the lowest; 2 = the other way round
+  const long sprio = tunable("stream_prio", 0);
+  if (sprio == 1 || sprio == 2) {
+    int lo = 0, hi = 0;  // numerically lower = higher priority
+    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+    HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, sprio == 1 ? hi : lo));
+    HIP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, sprio == 1 ? lo : hi));
+  } else {
+    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+    HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
+  }
   HIP_CHECK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_round0, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_class0, hipEventDisableTiming));
@@ -1022,6 +1032,7 @@ void run_sweep(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
   SweepDesc d{db.words.p, W.qv.p, W.sweep_out.p, (int)p.planes(), db.np_local, (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
+  d.nt_store = (int)tunable("sweep_nt_store", 1);
   launch_sweep(W.D->T, d, W.stream);
 }
 
@@ -1122,6 +1133,7 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl, int cls) {
   const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
               (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G, cls >= 0 ? 2 : 1, cls >= 0 ? cls : 0};
+  d.nt_store = (int)tunable("sweep_nt_store", 1);
   const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
   if (db.packed && wgs > 0)
     launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);

@@ -24,7 +24,14 @@ __device__ __forceinline__ size_t sweep_out_index(const SweepDesc& d, int plane,
 __device__ __forceinline__ void sweep_store_pair(const SweepDesc& d, int plane, int z, int ii0, u32 r0c0_a, u32 r0c0_b,
                                                  u32 r0c1_a, u32 r0c1_b, u32 r1c0_a, u32 r1c0_b, u32 r1c1_a,
                                                  u32 r1c1_b) {
-  if (d.out_G <= 1) {
+  if (d.out_G <= 1 && d.nt_store) {
+    const size_t rc = (size_t)N * d.num_per;
+    u32* o = d.out + (size_t)plane * 4 * rc + (size_t)z * d.num_per + ii0;
+    __builtin_nontemporal_store(mf_u32x2_t{r0c0_a, r0c0_b}, reinterpret_cast<mf_u32x2_t*>(o + 0 * rc));
+    __builtin_nontemporal_store(mf_u32x2_t{r0c1_a, r0c1_b}, reinterpret_cast<mf_u32x2_t*>(o + 1 * rc));
+    __builtin_nontemporal_store(mf_u32x2_t{r1c0_a, r1c0_b}, reinterpret_cast<mf_u32x2_t*>(o + 2 * rc));
+    __builtin_nontemporal_store(mf_u32x2_t{r1c1_a, r1c1_b}, reinterpret_cast<mf_u32x2_t*>(o + 3 * rc));
+  } else if (d.out_G <= 1) {
     const size_t rc = (size_t)N * d.num_per;
     u32* o = d.out + (size_t)plane * 4 * rc + (size_t)z * d.num_per + ii0;
     *reinterpret_cast<uint2*>(o + 0 * rc) = make_uint2(r0c0_a, r0c0_b);
@@ -454,7 +461,13 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
   m.c32[0] = (u32)((1ull << 32) % MODULUS_0);
   m.c32[1] = (u32)((1ull << 32) % MODULUS_1);
   const dim3 grid((unsigned)((size_t)d.planes * N * (chunks / cpw)));
-  const size_t lds = (size_t)d.nj * 128;
+  // batch_mfma_lds_pad (bytes, default 0): extra dynamic LDS per workgroup; 26624 leaves exactly one pass workgroup per CU
+  // and 70 KiB for a fold workgroup beside it (per-plane batch pipeline experiments)
+  const size_t lds = (size_t)d.nj * 128 + (size_t)std::max<long>(0, tunable("batch_mfma_lds_pad", 0));
+  if (lds > 65536) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  }
   // ring of 2 load buffers by default (one 16-row step ahead, 180 VGPRs); 4 measured the same +-2 % at 236 VGPRs
   if (tunable("batch_mfma_nb", 2) == 4 && (d.nj % 64) == 0)
     hipLaunchKernelGGL((k_sweep_mfma_batch<4, 2>), grid, dim3(256), lds, s, T, m);
@@ -594,6 +607,52 @@ __global__ __launch_bounds__(256) void k_sweep_narrow2(DevTables T, SweepDesc d)
     const int rr = which & 1, cc = which >> 1;
     d.out[sweep_out_index(d, plane, rr * 2 + cc, z, ii)] = r;
   }
+}
+
+// Placement probe: the PACKED sweep's access pattern (one wave per 448-KiB stream, 28 B per lane per row pair, 4 row pairs
+// in flight, non-temporal) over a buffer, nothing computed.  How a multi-GiB hipMalloc is backed decides 2.19 vs 2.40 ms
+// per C2 plane (profiles/r02_sweep_experiments.md); db_create_impl times this kernel on freshly allocated candidates and
+// keeps the fastest (switch db_place_tries).
+__global__ __launch_bounds__(256) void k_stream_probe(const u32* base, long units, u32* sink) {
+  const int lane = threadIdx.x & 63;
+  const long nw = (long)gridDim.x * 4;
+  u32 acc = 0;
+  for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += nw) {
+    const u32* p = base + u * (448 * 256);
+    for (int jp = 0; jp < 256; jp += 4) {
+      u32x4_t a[4];
+      u32x3_t b[4];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const u32* q = p + (jp + k) * 448;
+        a[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(q + lane * 4));
+        b[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(q + 256 + lane * 3));
+      }
+#pragma unroll
+      for (int k = 0; k < 4; k++) acc += a[k].x ^ a[k].y ^ a[k].z ^ a[k].w ^ b[k].x ^ b[k].y ^ b[k].z;
+    }
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+float stream_probe_ms(const void* buf, size_t bytes, u32* sink, hipStream_t s) {
+  const long units = (long)(bytes / (448 * 1024));
+  if (units < 1024) return 0.f;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.f;
+  float best = 1e30f;
+  for (int r = 0; r < 3; r++) {  // first pass warms the TLBs; best of the next two
+    (void)hipEventRecord(a, s);
+    hipLaunchKernelGGL(k_stream_probe, dim3(1024), dim3(256), 0, s, reinterpret_cast<const u32*>(buf), units, sink);
+    (void)hipEventRecord(b, s);
+    (void)hipEventSynchronize(b);
+    float t = 0;
+    (void)hipEventElapsedTime(&t, a, b);
+    if (r > 0 && t < best) best = t;
+  }
+  (void)hipEventDestroy(a);
+  (void)hipEventDestroy(b);
+  launched(0, "k_stream_probe");
+  return best;
 }
 
 const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }

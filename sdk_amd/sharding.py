@@ -82,7 +82,7 @@ def scatter_fold_query(run, db, rank, world, overlap=True, fold_per_plane=False)
     is copied out); the database is swept one plane per launch and the reduce-scatter of plane p (RCCL's own
     stream) runs while the later planes are swept; then one local fold over all planes.
     fold_per_plane=True additionally folds plane p on the second stream as soon as its exchange is done.  Measured
-    with the exchange replaced by a local copy (scripts/rank_emulation.py flow, C2): the per-plane fold chains are
+    with the exchange replaced by a local copy (scripts/archive/r02/rank_emulation.py flow, C2): the per-plane fold chains are
     latency-bound and serialise, 3.22 vs 2.64 ms per query at 8 shards, 4.51 vs 4.11 at 4, 7.08 vs 6.97 at 2 —
     hence off by default.  overlap=False: one sweep launch, one reduce-scatter, host
     synchronisation between the steps (the reference implementation of the same data flow)."""
@@ -273,6 +273,42 @@ class Comm:
                                             C.c_size_t(d.size), C.c_void_p(shard.h), _p(out, u8p), C.c_size_t(n),
                                             C.byref(ln)))
         return out[:ln.value].tobytes()
+
+
+    def reserve(self, params):
+        """sp_comm_reserve: exchange buffers for `params` allocated now (no allocation inside a sharded query)"""
+        import ctypes as C
+        from .spiral import _chk, lib
+        _chk(lib().sp_comm_reserve(C.c_void_p(self.h), C.c_void_p(params.h)))
+
+    def process_queries(self, params, pps, queries, shard):
+        """sp_process_queries_sharded: a list of queries, query k + 1 expanding while query k is swept; the list of
+        responses on rank 0, [] elsewhere"""
+        import ctypes as C
+        from .spiral import _bytes, _chk, _p, lib, u8p
+        n = len(queries)
+        if not isinstance(pps, (list, tuple)):
+            pps = [pps] * n
+        bufs = [_bytes(q.data if hasattr(q, "data") else bytes(q)) for q in queries]
+        rb = params.get("response_bytes")
+        out = np.zeros(max(1, n * rb), dtype=np.uint8)
+        ln = C.c_size_t(0)
+        pp_arr = (C.c_void_p * n)(*[pp.h for pp in pps])
+        q_arr = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        l_arr = (C.c_size_t * n)(*[b.size for b in bufs])
+        _chk(lib().sp_process_queries_sharded(C.c_void_p(self.h), C.c_void_p(params.h), pp_arr, q_arr, l_arr, C.c_int(n),
+                                              C.c_void_p(shard.h), _p(out, u8p), C.c_size_t(rb), C.byref(ln)))
+        if ln.value == 0:
+            return []
+        return [out[k * rb:(k + 1) * rb].tobytes() for k in range(n)]
+
+
+class NullTransport:
+    """Collectives that return at once (no data moves): the custom transport for timing ONE rank's critical path of a
+    G-rank sharded query on a single GPU (scripts/r03_rank_critical_path.py).  Results are meaningless."""
+
+    def __init__(self, rank, world):
+        self.comm = Comm.custom(rank, world, lambda send, recv, count, stream: 0, lambda send, recv, count, stream: 0)
 
 
 class LoopbackWorld:

@@ -255,7 +255,7 @@ def test_c2_row_sharded_flow_on_one_gpu(sp, oracle_mod, G):
     res = world.run(rank_main)
     assert res[0][0] == expect
     for r in range(G):
-        assert {"sweep_packed_persist", "scatter_out", "expand_pruned", "from_sweep4", "rccl_in_library"} <= res[r][1], res[r][1]
+        assert {"sweep_packed_persist", "scatter_out", "expand_pruned", "from_sweep4", "custom_transport"} <= res[r][1], res[r][1]
     print("G=%d per-rank ms (all ranks sharing one GPU): sweep+exchange %s" % (G, ["%.2f" % t[0] for _, _, t in res]))
     del shards, world
     gc.collect()

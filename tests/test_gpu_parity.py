@@ -858,13 +858,45 @@ def test_process_query_sharded_c_abi_loopback(sp, oracle_mod, cfg, G):
     for r in range(1, G):
         assert res[r][0] == [b"", b""]
     for r in range(G):
-        assert {"scatter_out", "rccl_in_library"} <= res[r][1], res[r][1]
+        assert {"scatter_out", "custom_transport"} <= res[r][1] and "rccl_in_library" not in res[r][1], res[r][1]
         if G > 1 and o.num_per >= 2:
             assert "expand_pruned" in res[r][1]
     if cfg.get("t_gsw") == 8:       # the reduced gadget widths of the other configs are not decodable (nor need be)
         assert cl.decode_response(expect[0]) == o.item_to_vec(item)
     with pytest.raises(sp.SpiralError):
         world.comm(0).process_query(p, gpp, q[:-8], shards[0])      # bad query length: no collective is entered
+
+
+@pytest.mark.parametrize("G", [2, 4])
+def test_process_queries_sharded_pipelined_list(sp, oracle_mod, G):
+    """sp_process_queries_sharded: a list of queries through the sharded flow, query k + 1 expanding while query k's planes
+    are swept and exchanged (loopback transport, G ranks on this GPU).  Rank 0's responses must equal the oracle's and the
+    one-at-a-time entry point's; the exchange buffers come from sp_comm_reserve."""
+    from sdk_amd.sharding import LoopbackWorld
+    cfg = dict(FAST, nu_1=5, nu_2=8, t_gsw=4, db_item_size=1024)
+    o, cl, pp, q0 = _session(oracle_mod, cfg, 5, 91)
+    qs = [q0] + [cl.generate_query((311 * k + 9) % o.num_items, 40 + k) for k in range(1, 5)]
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(5)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    expect = [o.process_query(pp, q, db) for q in qs]
+    shards = [sp.Database(p, s, G).load(db) for s in range(G)]
+    world = LoopbackWorld(G)
+
+    def rank_main(r):
+        sp.lib().sp_set_device(0)
+        world.comm(r).reserve(p)
+        sp.paths_taken()
+        out = world.comm(r).process_queries(p, gpp, qs, shards[r])
+        single = world.comm(r).process_query(p, gpp, qs[2], shards[r])
+        return out, single, sp.paths_taken()
+    res = world.run(rank_main)
+    assert res[0][0] == expect and res[0][1] == expect[2]
+    for r in range(1, G):
+        assert res[r][0] == [] and res[r][1] == b""
+    for r in range(G):
+        assert {"scatter_out", "custom_transport", "expand_pruned"} <= res[r][2], res[r][2]
+    assert world.comm(0).process_queries(p, gpp, [], shards[0]) == []
 
 
 def test_overlapped_fold_direct_upload_parity(sp, oracle_mod):
