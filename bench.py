@@ -162,7 +162,8 @@ def cpu_baseline(cfg_name, cfg):
         nz = N if (full or whole_plane) else max(1, min(N, (1 << 25) // (num_per * dim0)))
         nz1 = nz if (full or whole_plane) else min(nz, 32)
         reps = planes if full else 1
-        dbs = rand_words(nz * num_per * dim0)
+        oracle.set_threads(max_threads)
+        dbs = oracle.words_first_touch(nz, num_per * dim0)   # pages placed by the threads that will stream them
         t0 = time.time()
         for _ in range(reps):
             oracle.sweep_rows(dbs[:nz1 * num_per * dim0], v_reg[:nz1 * dim0 * 2], nz1, dim0, num_per)
@@ -178,6 +179,9 @@ def cpu_baseline(cfg_name, cfg):
                 oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
                 scan[t] = time.time() - t0
             threads = min(scan, key=scan.get)
+            if threads != max_threads:      # re-place the pages for the team that will actually run
+                oracle.set_threads(threads)
+                dbs = oracle.words_first_touch(nz, num_per * dim0)
         oracle.set_threads(threads)
         t0 = time.time()
         for _ in range(reps):

@@ -529,6 +529,14 @@ class Client:
 
 
 # ---- free functions used by the KAT tests
+def words_first_touch(nz, words_per_z, seed=5):
+    """nz * words_per_z database words (residues < 2^28), written by the OpenMP team with the z-row schedule of
+    sweep_rows_avx2: pages land on the NUMA node of the thread that will read them"""
+    out = np.empty(nz * words_per_z, dtype=np.uint64)
+    lib().orc_fill_words_first_touch(_p(out), _u64(nz), _u64(words_per_z), _u64(seed))
+    return out
+
+
 def set_threads(n):
     """OpenMP team size of the parallel sections (returns the previous maximum)"""
     return int(lib().orc_set_threads(C.c_int(n)))

@@ -108,6 +108,20 @@ void orc_ntt_table(void* h, uint64_t crt, uint64_t which, uint64_t* out) {
 }
 
 // ------------------------------------------------------------------- arith
+// Database words for the cpu_baseline: residues < 2^28 in both limbs, written with the SAME static schedule over z-rows as
+// orc_sweep_rows_avx2 reads them, so that on a multi-socket host every page is first touched -- i.e. placed -- by the
+// thread that will stream it (a server would load its database the same way).
+void orc_fill_words_first_touch(uint64_t* p, uint64_t nz, uint64_t words_per_z, uint64_t seed) {
+#pragma omp parallel for schedule(static)
+  for (uint64_t z = 0; z < nz; z++) {
+    uint64_t x = seed + 0x9E3779B97F4A7C15ULL * (z + 1);
+    uint64_t* row = p + z * words_per_z;
+    for (uint64_t i = 0; i < words_per_z; i++) {
+      x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+      row[i] = (x & 0x0FFFFFFFULL) | (((x >> 32) & 0x0FFFFFFFULL) << 32);
+    }
+  }
+}
 // OpenMP team size for the parallel sections that follow (cpu_baseline scans it); returns the previous maximum
 int orc_set_threads(int n) {
 #ifdef _OPENMP

@@ -266,9 +266,9 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
     }
     d->packed = db_can_pack(d->np_local, d->nj) && !tunable("db_unpacked", 0) ? 1 : 0;
     // db_contiguous (default 0): physically contiguous allocation.  It gives the sweep its best case in every process
-    // (profiles/r02_sweep_experiments.md) but is NOT SAFE on this stack: asking the driver for a contiguous range makes
-    // it move other live buffers of the process, and their contents were observed to change (public parameters
-    // allocated just before a 56 GiB database: profiles/r02_stale_reads.md) -- wrong responses on some machines.
+    // (profiles/r02_sweep_experiments.md) but is NOT SAFE on this stack: memory that belonged to a FREED contiguous
+    // allocation is zeroed some time after the next hipMalloc already owns it (stand-alone reproducer
+    // scripts/ubench/contig_repro.hip modes 4-6, profiles/r03_contiguous_alloc.md) -- the next handle's uploads vanish.
     const size_t db_words = (db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8;
     d->words.alloc_streaming(db_words, tunable("db_contiguous", 0) != 0);
     // Placement lottery: how a multi-GiB hipMalloc happens to be backed moves the sweep by up to

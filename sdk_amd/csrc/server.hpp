@@ -75,8 +75,8 @@ struct DevBuf {
   // Large streaming buffers (the database).  want_contiguous (switch db_contiguous, OFF by default) asks for PHYSICALLY
   // CONTIGUOUS device memory first: how a plain hipMalloc of tens of GiB is backed is a lottery (the same read stream runs
   // at 6.7-7.07 TB/s depending on the process, a contiguous allocation gave 7.05-7.08 TB/s in every run:
-  // scripts/ubench/hbm_map.hip, profiles/r02_sweep_experiments.md) -- but the driver makes room for such a range by
-  // moving other live buffers, and their contents did not survive that on every machine (profiles/r02_stale_reads.md).
+  // scripts/ubench/hbm_map.hip, profiles/r02_sweep_experiments.md) -- but on this stack memory of a FREED contiguous
+  // allocation is zeroed after its next owner has already written to it (profiles/r03_contiguous_alloc.md).
   void alloc_streaming(size_t count, bool want_contiguous) {
     release();
     if (count == 0) return;

@@ -458,8 +458,12 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
   cpw = std::max(1, std::min(cpw, chunks));
   while (chunks % cpw) cpw--;
   m.cpw = cpw;
-  m.c32[0] = (u32)((1ull << 32) % MODULUS_0);
-  m.c32[1] = (u32)((1ull << 32) % MODULUS_1);
+  const u64 qs[2] = {MODULUS_0, MODULUS_1};
+  for (int c = 0; c < 2; c++) {
+    m.c4[c] = (u32)((1ull << 32) % qs[c]);
+    m.c5[c] = (u32)((1ull << 40) % qs[c]);
+    m.c6[c] = (u32)((1ull << 48) % qs[c]);
+  }
   const dim3 grid((unsigned)((size_t)d.planes * N * (chunks / cpw)));
   // batch_mfma_lds_pad (bytes, default 0): extra dynamic LDS per workgroup; 26624 leaves exactly one pass workgroup per CU
   // and 70 KiB for a fold workgroup beside it (per-plane batch pipeline experiments)

@@ -40,7 +40,7 @@ struct SweepMfmaDesc {
   int batch;                      // 1 .. 8 (unused query columns of the table are zero)
   int planes, num_per, nj;        // nj % 16 == 0, nj <= 512 (LDS-staged table), num_per % 128 == 0
   int cpw;                        // chunks per workgroup, divides num_per / 128
-  u32 c32[2];                     // 2^32 mod q_crt
+  u32 c4[2], c5[2], c6[2];        // 2^32, 2^40, 2^48 mod q_crt
 };
 
 // Query digit table for one group of queries: dword i of entry (z, step, crt, lane = kb * 16 + n) = byte-reversed signed
@@ -71,18 +71,16 @@ __global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
   reinterpret_cast<mf_u32x4_t*>(d.rq)[idx] = o;
 }
 
-// sum_s 256^s D[s] mod q for |D[s]| < 2^26 (exact: the sum is the non-negative integer sum_j x_j y_j)
+// sum_s 256^s D[s] mod q for |D[s]| < 2^26 (exact: the sum is the non-negative integer sum_j x_j y_j).  The three high
+// digit sums are multiplied by 256^s mod q (c4 = 2^32, c5 = 2^40, c6 = 2^48 mod q, each < 2^28: |products| < 2^54) and added
+// to the low part as signed 64-bit integers; q 2^29 makes the total positive, one Barrett fold finishes.
 __device__ __forceinline__ u32 combine_digit_sums(int d0, int d1, int d2, int d3, int d4, int d5, int d6, const ModConst m,
-                                                  u32 c32) {
-  const long long lo = (long long)d0 + ((long long)d1 << 8) + ((long long)d2 << 16) + ((long long)d3 << 24);  // |lo| < 2^51
-  const long long hi = (long long)d4 + ((long long)d5 << 8) + ((long long)d6 << 16);                          // |hi| < 2^43
-  const u32 h = reduce64((u64)(hi + ((long long)m.q << 16)), m);      // hi mod q  (q 2^16 > 2^43.8)
-  const u64 v = (u64)h * c32 + (u64)(lo + ((long long)m.q << 25));    // < 2^56 + 2^53 + 2^51
-  return reduce64(v, m);
+                                                  u32 c4, u32 c5, u32 c6) {
+  long long v = (long long)d0 + ((long long)d1 << 8) + ((long long)d2 << 16) + ((long long)d3 << 24);  // |.| < 2^51
+  v += (long long)d4 * (long long)c4 + (long long)d5 * (long long)c5 + (long long)d6 * (long long)c6;   // |.| < 2^56
+  return reduce64((u64)(v + ((long long)m.q << 29)), m);
 }
 
-// NB = ring of load buffers (NB - 1 steps of 16 rows in flight per wave while one is multiplied); MINWG = workgroups
-// per CU the register budget is set for (2: <= 256 VGPR + AGPR per lane, 1: <= 512).  (nj / 16) % NB == 0.
 // DIAG (microbenchmark only, scripts/ubench/mfma_sweep.hip; 0 in the library): 1 = no database loads after the
 // prologue (compute only), 2 = MFMAs replaced by one XOR each (loads + VALU only), 3 = raw dwords fed to the MFMAs (no
 // digit extraction, no operand shifts: loads + MFMA only), 4 = no output stores, 5 = every workgroup stores to the first
@@ -235,9 +233,9 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
         for (int c = 0; c < 2; c++) {
           const ModConst mc = c ? m1 : m0;
           const u32 v0 = combine_digit_sums(acc[0][c][0][i], acc[0][c][1][i], acc[0][c][2][i], acc[0][c][3][i],
-                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c32[c]);
+                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
           const u32 v1 = combine_digit_sums(acc[1][c][0][i], acc[1][c][1][i], acc[1][c][2][i], acc[1][c][3][i],
-                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c32[c]);
+                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
           if (DIAG == 4 && (v0 ^ v1) != 0xDEADBEEFu) continue;  // (practically) no stores
           if (DIAG == 7) {
             u32* o7 = d.out[0] + ((((size_t)zp * chunks + chunk0 + ch) * 4 + g) * 8 + (i * 2 + c)) * 128 + 2 * lane;
