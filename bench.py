@@ -144,15 +144,15 @@ def cpu_baseline(cfg_name, cfg):
         return 0.0
 
     def one(name, c, full):
+        nonlocal threads
         o = oracle.Params(c)
         cl = oracle.Client(o)
         pp = cl.generate_keys(11)
         q = cl.generate_query(12345 % o.num_items, 12)
         dim0, num_per, planes = o.dim0, o.num_per, o.instances * o.n * o.n
-        t0 = time.time()
-        v_reg, v_fold = o.expand_query(pp, q)
-        v_neg = o.get_v_folding_neg(v_fold)
-        t_expand = time.time() - t0
+        if max_threads >= 8:
+            oracle.set_threads(threads if scan else max(1, max_threads // 2))   # before the scan: one thread per physical core
+        v_reg, v_fold = o.expand_query(pp, q)       # (untimed: the inputs of the sweep; timed below with the chosen team)
         # full: every z-row of every plane and the whole fold tree of every plane are executed (no scaling);
         # sampled: nz rows of one plane / a subtree, scaled by row count, step count and planes
         # sampled configurations: ONE WHOLE PLANE of the sweep is executed un-sampled in both modes when the host has the
@@ -169,7 +169,6 @@ def cpu_baseline(cfg_name, cfg):
             oracle.sweep_rows(dbs[:nz1 * num_per * dim0], v_reg[:nz1 * dim0 * 2], nz1, dim0, num_per)
         t_sweep_1 = (time.time() - t0) * (1 if full else (N / nz1) * planes)
         oracle.sweep_rows_avx2(dbs[:num_per * dim0], v_reg[:dim0 * 2], 1, dim0, num_per)   # thread-pool warm-up
-        nonlocal threads
         if not scan and max_threads >= 8:
             nzs = min(nz, max(8, (1 << 27) // (num_per * dim0)))   # ~1 GiB of words per trial
             for t in sorted({max_threads, max(1, max_threads // 2), max(1, max_threads // 4)}):
@@ -187,6 +186,10 @@ def cpu_baseline(cfg_name, cfg):
         for _ in range(reps):
             oracle.sweep_rows_avx2(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
         t_sweep_all = (time.time() - t0) * (1 if full else (N / nz) * planes)
+        t0 = time.time()
+        v_reg, v_fold = o.expand_query(pp, q)
+        v_neg = o.get_v_folding_neg(v_fold)
+        t_expand = time.time() - t0
         # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
         k1 = o.db_dim_2 if full else min(o.db_dim_2, 5)
         ka = o.db_dim_2 if full else min(o.db_dim_2, 11)   # all-core: the whole tree of a plane (its serial top included)
