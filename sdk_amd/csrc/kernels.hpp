@@ -48,7 +48,8 @@ enum PathBit : u64 {
   PATH_EXPAND_SPLIT = 1ull << 22,     // odd expansion subtree + GSW side on the second stream, beside the even subtree
   PATH_PIPE_CLASS_SPLIT = 1ull << 23, // a plane swept and folded as two chunk-parity classes (pipe_split)
   PATH_SWEEP_MFMA = 1ull << 24,       // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
-  PATH_CUSTOM_TRANSPORT = 1ull << 25  // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
+  PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
+  PATH_FROM_SWEEP_WAVE = 1ull << 26   // k_from_sweep_wave (from_ntt of the sweep output, one wave per polynomial)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -123,6 +124,8 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s);
 // dst raw polys dense in the same order as InvDesc's sweep mode: poly (plane*np + ii)*2 + r.
 // cls >= 0: only the columns whose 128-column chunk has parity cls (np % 256 == 0)
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls = -1);
+// the same on the wave-per-transform NTT (fold.hip); launch_from_sweep4 dispatches to it unless from_sweep_wave = 0
+void launch_from_sweep_wave(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls = -1);
 
 // ---- NTT-domain multiply-accumulate (poly.rs:437-481) --------------------------------------
 // out[b][r] = (addend ? addend[b][r] : 0) + sum_k A[r][k] * B[b][k]   (pointwise, per crt), r < R
@@ -171,6 +174,7 @@ struct FoldDesc {
   // cls_on: only the fold steps of one chunk-parity class (see SweepDesc::chunk_step): block b handles step
   // i = (b / 128) * 256 + b % 128 + 128 * cls_off; the grid has half / 2 blocks.  Needs half % 256 == 0.
   int cls_on, cls_off;
+  int nt_store;  // k_fold_wave: streaming stores of the folded ciphertext (switch fold_nt; measured in profiles/r03_switch_ab.md)
 };
 __host__ __device__ inline int fold_step_of_block(const FoldDesc& d, int b) {
   return d.cls_on ? ((b >> 7) << 8) + (b & 127) + 128 * d.cls_off : b;

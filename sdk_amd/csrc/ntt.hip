@@ -264,7 +264,8 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
   // The 8 column groups that share one 128-byte line of the [z][ii] source should go through ONE XCD's L2, back
   // to back (workgroups are dealt to the 8 XCDs round-robin): block b -> XCD b % 8 handles line (b/64)*8 + b%8,
   // group (b/8) % 8 of that line.  Otherwise every line is fetched from HBM by up to 8 L2s.
-  if (xcd_map) {
+  const bool nt = (xcd_map & 2) != 0;  // from_sweep_nt: streaming stores of the raw ciphertexts
+  if (xcd_map & 1) {
     const int xcd = g & 7, t = g >> 3;
     g = ((t >> 3) * 8 + xcd) * 8 + (t & 7);
   }
@@ -310,7 +311,11 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
           u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
           u32 e = dd * T.c.q0_inv_q1 - qt * q1;
           e = e >= q1 ? e - q1 : e;
-          out[tau + 256 * k] = (u64)x + (u64)q0 * (u64)e;
+          const u64 val = (u64)x + (u64)q0 * (u64)e;
+          if (nt)
+            __builtin_nontemporal_store(val, out + tau + 256 * k);
+          else
+            out[tau + 256 * k] = val;
         }
       }
     }
@@ -318,10 +323,15 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
 }
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls) {
   if (n_planes <= 0) return;
+  if (tunable("from_sweep_wave", 0) != 0) {
+    launch_from_sweep_wave(T, src, np, n_planes, premod, dst, s, cls);
+    return;
+  }
   const unsigned groups = (unsigned)((np / (cls >= 0 ? 8 : 4)) * 2 * n_planes);
   const int want = (int)tunable("from_sweep_xcd", 1);
   const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
-  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map, cls);
+  const int flags = (xcd_map ? 1 : 0) | (tunable("from_sweep_nt", 0) ? 2 : 0);   // bit 1: streaming stores
+  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, flags, cls);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
 

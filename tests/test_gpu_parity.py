@@ -899,6 +899,29 @@ def test_process_queries_sharded_pipelined_list(sp, oracle_mod, G):
     assert world.comm(0).process_queries(p, gpp, [], shards[0]) == []
 
 
+@pytest.mark.parametrize("cfg", [FAST56, dict(FAST, nu_1=4, nu_2=8, t_gsw=4, db_item_size=2048), SMALL_INST2],
+                         ids=["8-columns", "256-columns-packed", "two-instances"])
+def test_from_sweep_wave_kernel_parity(sp, oracle_mod, cfg):
+    """k_from_sweep_wave (from_ntt of the sweep output with one wave per polynomial, switch from_sweep_wave; measured as fast
+    as the default k_from_sweep4, kept as an alternative): responses byte-identical to the oracle and to the default."""
+    import ctypes as C
+    o, cl, pp, q = _session(oracle_mod, cfg, 3, 44)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(3)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    ref = sp.process_query(p, gpp, q, gdb)
+    sp.lib().sp_debug_set(b"from_sweep_wave", C.c_long(1))
+    try:
+        sp.paths_taken()
+        got = sp.process_query(p, gpp, q, gdb)
+        assert "from_sweep_wave" in sp.paths_taken()
+    finally:
+        sp.lib().sp_debug_set(b"from_sweep_wave", C.c_long(0))
+    assert got == ref == o.process_query(pp, q, db)
+    assert cl.decode_response(got) == o.item_to_vec(item)
+
+
 def test_overlapped_fold_direct_upload_parity(sp, oracle_mod):
     """Non-expanded ('direct_upload') query on a wide packed database: the overlapped per-plane path with the
     fold matrices coming straight from the wire (server.rs:666-679) instead of regev_to_gsw."""
