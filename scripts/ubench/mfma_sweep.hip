@@ -6,6 +6,7 @@
 // Build:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../sdk_amd/csrc -I../../include mfma_sweep.hip -o mfma_sweep
 // Run:    ./mfma_sweep [nz = 2048] [reps = 3]
 #include "sweep_mfma.hpp"
+#include "mfma_sweep6.hpp"
 
 #include <chrono>
 #include <cstdio>
@@ -227,6 +228,37 @@ static void run_variant(Ctx& c, int cpw, size_t lds_pad, int reps, const char* t
   if (DIAG == 0) verify(c, tag, 400);
 }
 
+template <int NB, int DIAG = 0>
+static void run_variant6(Ctx& c, int cpw, int reps, const char* tag) {
+  c.d.cpw = cpw;
+  const size_t lds = (size_t)c.nj * 128;
+  for (int b = 0; b < c.batch; b++) CK(hipMemset(c.out[b], 0xEE, (size_t)4 * N * c.num_per * 4));
+  const dim3 grid((unsigned)((size_t)c.nz * (c.chunks / cpw)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_sweep_mfma_batch6<NB, DIAG>), grid, dim3(384), lds, 0, c.T, c.d);
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  float best = 1e9f, sum = 0;
+  for (int r = 0; r < reps; r++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_sweep_mfma_batch6<NB, DIAG>), grid, dim3(384), lds, 0, c.T, c.d);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  const double bytes = (double)c.nz * c.chunks * c.npairs * 1792.0;
+  hipFuncAttributes fa;
+  CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sweep_mfma_batch6<NB, DIAG>)));
+  printf("[mfma6 %s] 6 waves per workgroup, NB=%d cpw=%d regs=%d scratch=%zu: best %.3f ms avg %.3f ms per plane-pass = %.0f GB/s of database (x4 planes: %.2f ms per B=8 pass)\n",
+         tag, NB, cpw, fa.numRegs, (size_t)fa.localSizeBytes, best, sum / reps, bytes / (best * 1e-3) / 1e9, 4.0 * best * 2048.0 / c.nz);
+  if (DIAG == 0) verify(c, tag, 400);
+}
+
 // ---- 4. issue rates: independent MFMAs alone and with VALU work between them (inline asm: the compiler's own version of
 // this loop shuffled the accumulators through v_accvgpr moves and measured that instead) ----------------------------------
 template <int VALU_PER_MFMA>
@@ -372,8 +404,14 @@ int main(int argc, char** argv) {
   c.d.planes = 1;
   c.d.num_per = c.num_per;
   c.d.nj = c.nj;
-  c.d.c32[0] = (u32)((1ull << 32) % MODULUS_0);
-  c.d.c32[1] = (u32)((1ull << 32) % MODULUS_1);
+  {
+    const u64 qs[2] = {MODULUS_0, MODULUS_1};
+    for (int k = 0; k < 2; k++) {
+      c.d.c4[k] = (u32)((1ull << 32) % qs[k]);
+      c.d.c5[k] = (u32)((1ull << 40) % qs[k]);
+      c.d.c6[k] = (u32)((1ull << 48) % qs[k]);
+    }
+  }
 
   if (!getenv("MFMA_UBENCH_NORATE")) {
     int* o;
@@ -389,6 +427,12 @@ int main(int argc, char** argv) {
     mfma_rate<8>(3, o);
   }
   run_variant<2, 2>(c, 16, 0, reps, "a");
+  run_variant6<2>(c, 16, reps, "six-wave NB=2");
+  run_variant6<1>(c, 16, reps, "six-wave NB=1");
+  run_variant6<2>(c, 8, reps, "six-wave NB=2 cpw=8");
+  run_variant6<2, 1>(c, 16, reps, "six-wave NB=2 DIAG1 compute only");
+  run_variant6<2, 4>(c, 16, reps, "six-wave NB=2 DIAG4 no stores");
+  if (getenv("MFMA_UBENCH_SIX_ONLY")) return 0;
   run_variant<2, 2, 1>(c, 16, 0, reps, "a DIAG1 compute only (no loads)");
   run_variant<2, 2, 2>(c, 16, 0, reps, "a DIAG2 no MFMA (loads + VALU)");
   run_variant<2, 2, 3>(c, 16, 0, reps, "a DIAG3 no digit VALU (loads + MFMA)");
