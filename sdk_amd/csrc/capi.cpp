@@ -166,7 +166,8 @@ const char* sp_path_name(int bit) {
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
-                                "sweep_batch_mfma", "custom_transport", "from_sweep_wave"};
+                                "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
+                                "fold_tail_batched", "sweep_ring"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 

@@ -49,7 +49,9 @@ enum PathBit : u64 {
   PATH_PIPE_CLASS_SPLIT = 1ull << 23, // a plane swept and folded as two chunk-parity classes (pipe_split)
   PATH_SWEEP_MFMA = 1ull << 24,       // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
   PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
-  PATH_FROM_SWEEP_WAVE = 1ull << 26   // k_from_sweep_wave (from_ntt of the sweep output, one wave per polynomial)
+  PATH_FROM_SWEEP_WAVE = 1ull << 26,  // k_from_sweep_wave (from_ntt of the sweep output, one wave per polynomial)
+  PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
+  PATH_SWEEP_RING = 1ull << 28        // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -278,6 +280,11 @@ struct SweepDesc {
   // non-temporal (streaming) output stores: HBM writes mixed into the read stream cost 3-4x a read byte on this part, a
   // quarter less as streaming stores (scripts/ubench/rw_mix.hip); switch sweep_nt_store
   int nt_store;
+  // persistent PACKED sweep: two zeroed words (next ticket, waves done) or null.  Non-null = the (z, chunk) streams after
+  // a wave's first are handed out by an atomic counter instead of a fixed stride, so that waves slowed down by the fold
+  // kernels sharing their CU take fewer streams instead of holding the launch back (switch sweep_tickets).  The last wave
+  // to leave zeroes both words again.
+  u32* ticket;
 };
 // Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
 // i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.

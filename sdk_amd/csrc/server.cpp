@@ -634,6 +634,10 @@ size_t Workspace::plane_group() const {
 void Workspace::ensure_sweep() {
   const Params& p = *P;
   sweep_out.ensure(p.planes() * 4 * POLY_LEN * p.num_per());
+  if (!sweep_ticket.p) {  // SweepDesc::ticket: zero once, the kernel leaves it zeroed
+    sweep_ticket.ensure(64);
+    HIP_CHECK(hipMemset(sweep_ticket.p, 0, 64 * sizeof(u32)));
+  }
 }
 
 void Workspace::ensure_finish() {
@@ -1066,6 +1070,33 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 
+// Pipelined queries (switch pipe_tail_defer = cts per plane, 0 = off): under the sweeps a plane is folded only down to
+// `stop` ciphertexts (the levels with enough independent steps for one fused launch each) and parked; the remaining
+// levels of ALL planes run as one batch once the last plane is there.  The tail levels are latency-bound -- 24 launches of
+// 10 us alone, ~45 us each beside a sweep -- so a plane's overlapped fold took longer than the sweep it hides behind and
+// the second stream fell further behind with every plane; batched, the four tails cost what one costs.
+static int tail_defer_levels(const Params& p, long stop) {  // levels folded per plane before parking (0 = do not defer)
+  if (stop <= 0 || !fused_fold_supported(p) || p.planes() < 2) return 0;
+  int lv = 0;
+  size_t cur = p.num_per();
+  while (cur > (size_t)stop && cur / 2 >= 1 && (cur & 1) == 0) { cur >>= 1; lv++; }
+  return cur == (size_t)stop && lv > 0 && stop >= 2 ? lv : 0;
+}
+static void fold_plane_head(Workspace& W, size_t pl, int levels) {  // from_ntt + the first `levels` levels, parked
+  const Params& p = *W.P;
+  launch_from_sweep4(W.D->T, W.sweep_out.p + pl * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), 1, 0, W.foldX.p, W.stream);
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, levels, -1);
+  const size_t cts = p.num_per() >> levels;
+  HIP_CHECK(hipMemcpyAsync(W.fold_tail.p + pl * cts * 2 * POLY_LEN, res, cts * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
+}
+static void fold_tails(Workspace& W, int levels) {  // the parked planes together, down to one ciphertext each
+  const Params& p = *W.P;
+  const size_t cts = p.num_per() >> levels;
+  u64* other = W.fold_tail.p + p.planes() * cts * 2 * POLY_LEN;
+  u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1, -1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, p.planes() * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
+}
+
 // The pipeline's finer grain: a plane is swept in two launches, the 128-column chunks of even and of odd index; the first
 // L = log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and stay inside such a class, so the
 // from_ntt and those L levels of class 0 run while class 1 is still being swept.
@@ -1134,6 +1165,7 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl, int cls) {
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
               (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G, cls >= 0 ? 2 : 1, cls >= 0 ? cls : 0};
   d.nt_store = (int)tunable("sweep_nt_store", 1);
+  d.ticket = tunable("sweep_tickets", 0) != 0 ? W.sweep_ticket.p : nullptr;
   const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
   if (db.packed && wgs > 0)
     launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);
@@ -1174,8 +1206,13 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
     return;
   }
   HIP_CHECK(hipEventRecord(W.ev_sw[0], W.stream));
+  const int defer_levels = tail_defer_levels(p, tunable("pipe_tail_defer", 256));
+  if (defer_levels > 0) {
+    W.fold_tail.ensure(2 * planes * (p.num_per() >> defer_levels) * 2 * POLY_LEN);
+    note_path(PATH_FOLD_TAIL_BATCHED);
+  }
   for (size_t pl = 0; pl < planes; pl++) {
-    if (plane_is_class_split(p, db, pl)) {
+    if (plane_is_class_split(p, db, pl) && (defer_levels == 0 || defer_levels == class_fold_levels(p))) {
       launch_plane_sweep(W, db, pl, 0);
       HIP_CHECK(hipEventRecord(W.ev_class0, W.stream));
       HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_class0, 0));
@@ -1185,7 +1222,15 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
       HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
       on_stream(W, W.stream2, [&] {
         fold_plane_class(W, pl, 1);
-        fold_plane_rest(W, pl);
+        if (defer_levels > 0) {  // the class-local levels are exactly the levels folded before parking
+          const size_t cts = p.num_per() >> defer_levels;
+          u64* res = (defer_levels & 1) ? W.foldY.p : W.foldX.p;
+          HIP_CHECK(hipMemcpyAsync(W.fold_tail.p + pl * cts * 2 * POLY_LEN, res, cts * 2 * POLY_LEN * sizeof(u64),
+                                   hipMemcpyDeviceToDevice, W.stream));
+          if (pl + 1 == planes) fold_tails(W, defer_levels);
+        } else {
+          fold_plane_rest(W, pl);
+        }
       });
       note_path(PATH_PIPE_CLASS_SPLIT);
       continue;
@@ -1193,6 +1238,13 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
     launch_plane_sweep(W, db, pl);
     HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
     HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
+    if (defer_levels > 0) {
+      on_stream(W, W.stream2, [&] {
+        fold_plane_head(W, pl, defer_levels);
+        if (pl + 1 == planes) fold_tails(W, defer_levels);
+      });
+      continue;
+    }
     on_stream(W, W.stream2, [&] { fold_planes(W, pl, 1, false); });
   }
   HIP_CHECK(hipEventRecord(W.ev_sw[1], W.stream));
@@ -1254,7 +1306,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
       fd.planes = np;
       fd.t = (int)p.t_gsw;
       fd.bits = (int)p.bits_per(p.t_gsw);
-      fd.nt_store = (int)tunable("fold_nt", 0);
+      fd.nt_store = (tunable("diag_fold_no_store", 0) & 2) ? 2 : (int)tunable("fold_nt", 0);
       launch_fold_fused(D.T, fd, s);
       std::swap(X, Y);
       cur = half;

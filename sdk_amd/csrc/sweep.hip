@@ -198,7 +198,11 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
   const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;  // one chunk-parity class or all chunks
-  for (int unit = wave0; unit < units; unit += nwaves) {
+  u32* const ticket = d.ticket;
+  for (int unit = wave0; unit < units;) {
+    // the next stream's number is asked for now and looked at when this stream is done (one atomic per ~0.3 ms of work)
+    u32 drawn = 0;
+    if (ticket && lane == 0) drawn = atomicAdd(ticket, 1u);
     const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
     // zmul (sweep_zmul, odd; 1 = identity): the z-rows are visited in the order z * zmul mod N, so that the units in flight
     // at one time are spread over the whole plane instead of one contiguous window of it (the chunks of a z stay together)
@@ -252,7 +256,116 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
     }
     sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
                      (u32)a03, (u32)a13);
+    unit = ticket ? nwaves + (int)__builtin_amdgcn_readfirstlane(drawn) : unit + nwaves;
   }
+  if (ticket && lane == 0) {
+    // every wave has drawn its last (failing) ticket before it counts itself out: the last one out resets the counters
+    if (atomicAdd(ticket + 1, 1u) == (u32)nwaves - 1) {
+      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+// Ring form of k_sweep_packed_persist (switch pipe_ring): two buffers of U row pairs per wave, the loads of one in flight
+// while the other is multiplied, and the first buffer of a wave's NEXT (z, chunk) stream requested before the sums of this
+// one are reduced and stored.  A wave of the plain form has nothing in flight while it multiplies and relies on the
+// other 15 waves of its CU; when fold kernels share the CU the multiplies take longer and the HBM queue runs dry (sweep
+// alone 2.23 ms, beside the folds 2.37 ms per plane at C2).  ~96 VGPRs: meant for 2 workgroups per CU (pipe_wgs = 2),
+// which leaves a fold wave's 256 registers free on every SIMD.  Needs npairs % (2 U) == 0.
+typedef __attribute__((address_space(4))) const u32x4_t sweep_const_uint4;
+template <int U>
+__global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDesc d, int units, int hi_prio) {
+  if (hi_prio) __builtin_amdgcn_s_setprio(3);
+  const int lane = threadIdx.x & 63;
+  const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+  const int nwaves = gridDim.x * 4;
+  const int chunks = d.num_per >> 7;
+  const int npairs = d.nj >> 1;
+  const size_t ustride = 448;
+  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
+  const u32 M = 0x0FFFFFFFu;
+  const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;
+  if (wave0 >= units) return;
+  u32x4_t va[U], na[U];
+  u32x3_t vb[U], nb[U];
+#define SPR_BASE(UNIT) \
+  (reinterpret_cast<const u32*>(d.db) + \
+   packed_unit_offset((size_t)((UNIT) / chunks_l), 0, ((UNIT) % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0), npairs, chunks))
+#define SPR_LOAD(VA, VB, BASE, JP0)                                                                       \
+  _Pragma("unroll") for (int uu = 0; uu < U; uu++) {                                                      \
+    const u32* u = (BASE) + (size_t)((JP0) + uu) * ustride;                                               \
+    VA[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(u + lane * 4));                  \
+    VB[uu] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(u + 256 + lane * 3));            \
+  }
+#define SPR_MAC(VA, VB, JP0)                                                                                              \
+  _Pragma("unroll") for (int uu = 0; uu < U; uu++) {                                                                      \
+    const int jp = (JP0) + uu;                                                                                            \
+    const u32 d0 = VA[uu].x, d1 = VA[uu].y, d2 = VA[uu].z, d3 = VA[uu].w, d4 = VB[uu].x, d5 = VB[uu].y, d6 = VB[uu].z;    \
+    const u32x4_t qa = qrow[2 * jp];                                                                                      \
+    const u32x4_t qb = qrow[2 * jp + 1];                                                                                  \
+    const u32 f0 = d0 & M;                                                                                                \
+    const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;                                                             \
+    const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;                                                             \
+    const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;                                                             \
+    const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;                                                             \
+    const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;                                                             \
+    const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;                                                              \
+    const u32 f7 = d6 >> 4;                                                                                               \
+    a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;                           \
+    a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;                           \
+    a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;                           \
+    a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;                           \
+  }
+#define SPR_FOLD                                                                                          \
+  a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);     \
+  a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
+  const u32* base = SPR_BASE(wave0);
+  SPR_LOAD(va, vb, base, 0)
+  for (int unit = wave0; unit < units; unit += nwaves) {
+    const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
+    const int zp = unit / chunks_l;
+    const int z = zp & (N - 1);
+    const int plane = zp >> POLY_LEN_LOG2;
+    // the query rows through the scalar cache (s_load): as plain loads they are VECTOR loads here (the kernel stores inside
+    // the unit loop, so nothing is known to be unwritten) whose return is ordered behind the database loads in flight --
+    // waiting for a query row would drain the ring
+    const sweep_const_uint4* qrow =
+        (const sweep_const_uint4*)(uintptr_t)(reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0));
+    u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
+    // the wave's next stream (its own again past the end: a harmless re-read of 7 KiB)
+    const u32* next_base = unit + nwaves < units ? SPR_BASE(unit + nwaves) : base;
+    // blocks of at most 128 row pairs = 256 rows of < 2^56 products between Barrett folds.  No conditional code inside a
+    // block (a branch lets the optimiser sink the reload of a buffer below the multiplies of the other one)
+    for (int jb = 0; jb < npairs; jb += 128) {
+      const int len = min(128, npairs - jb);
+      int j = jb;
+      for (; j + 2 * U < jb + len; j += 2 * U) {
+        SPR_LOAD(na, nb, base, j + U)
+        __builtin_amdgcn_sched_barrier(0);  // keep the prefetch ahead of the multiply-accumulates
+        SPR_MAC(va, vb, j)
+        SPR_LOAD(va, vb, base, j + 2 * U)
+        __builtin_amdgcn_sched_barrier(0);
+        SPR_MAC(na, nb, j + U)
+      }
+      SPR_LOAD(na, nb, base, j + U)
+      __builtin_amdgcn_sched_barrier(0);
+      SPR_MAC(va, vb, j)
+      const bool more = jb + 128 < npairs;
+      const u32* nb_base = more ? base : next_base;
+      const int nb_jp = more ? jb + 128 : 0;
+      SPR_LOAD(va, vb, nb_base, nb_jp)
+      __builtin_amdgcn_sched_barrier(0);
+      SPR_MAC(na, nb, j + U)
+      SPR_FOLD
+    }
+    sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
+                     (u32)a03, (u32)a13);
+    base = next_base;
+  }
+#undef SPR_BASE
+#undef SPR_LOAD
+#undef SPR_MAC
+#undef SPR_FOLD
 }
 void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus) {
   const int units = d.planes * N * ((d.num_per >> 7) / (d.chunk_step == 2 ? 2 : 1));
@@ -263,6 +376,23 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
   // every 128-row-pair block (and the ragged last one) must split evenly into the U sub-streams
   const int spread = tunable("sweep_spread", 0) != 0 && (npairs % 128) % u_eff == 0 && (128 % u_eff) == 0 ? 1 : 0;
   const int zmul = (int)(tunable("sweep_zmul", 1) | 1);
+  // Ring form (default): pipe_ring = row pairs per buffer (8, 4 or 2; 0 = the plain form below), the largest that divides
+  // the stream evenly, on pipe_ring_wgs workgroups per CU (default ONE: four waves with two buffers of 8 row pairs each
+  // keep as many bytes in flight as sixteen plain waves with one buffer of 4, alone 2.23 against 2.27 ms per plane at
+  // C2 -- and a second ring workgroup per CU starves the fold kernels beside it: their loads queue behind the ring's)
+  long ring = tunable("pipe_ring", 8);
+  while (ring > 1 && (npairs % (2 * ring) != 0 || (ring != 2 && ring != 4 && ring != 8))) ring >>= 1;
+  if (ring >= 2 && !d.ticket) {
+    const int ring_wgs = (int)std::max(1L, tunable("pipe_ring_wgs", 1));
+    const dim3 rgrid((unsigned)std::min(n_cus * ring_wgs, (units + 3) / 4));
+    switch (ring) {
+      case 2: hipLaunchKernelGGL(k_sweep_packed_ring<2>, rgrid, dim3(256), 0, s, T, d, units, prio); break;
+      case 8: hipLaunchKernelGGL(k_sweep_packed_ring<8>, rgrid, dim3(256), 0, s, T, d, units, prio); break;
+      default: hipLaunchKernelGGL(k_sweep_packed_ring<4>, rgrid, dim3(256), 0, s, T, d, units, prio); break;
+    }
+    launched(PATH_SWEEP_PERSIST | PATH_SWEEP_RING | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_ring");
+    return;
+  }
   switch (unroll) {
     case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
     case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;

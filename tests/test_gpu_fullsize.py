@@ -52,7 +52,8 @@ def _client(oracle_mod, cfg, seed):
     return o, cl, cl.generate_keys(seed)
 
 
-PRODUCTION_C2 = {"sweep_packed_persist", "from_sweep4", "from_sweep4_xcd_order", "fold_fused", "pipelined_fold_overlap"}
+PRODUCTION_C2 = {"sweep_packed_persist", "sweep_ring", "from_sweep4", "from_sweep4_xcd_order", "fold_fused", "pipelined_fold_overlap",
+                 "fold_tail_batched"}
 
 
 def test_synth_word_copies_agree(sp, oracle_mod):

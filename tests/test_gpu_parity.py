@@ -979,6 +979,46 @@ def test_pipelined_class_split_parity(sp, oracle_mod, monkeypatch, nu_2, split):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
+@pytest.mark.parametrize("nu_1,nu_2,t_gsw,ring,wgs,defer,split", [
+    (5, 10, 4, "8", "1", "256", "0"),   # the defaults: two buffers of 8 row pairs, one workgroup per CU, tails batched
+    (5, 10, 4, "4", "2", "256", "0"),
+    (5, 10, 4, "2", "1", "64", "0"),    # two more levels per plane before parking
+    (5, 11, 4, "8", "1", "256", "2"),   # every plane as two chunk-parity classes, then parked
+    (5, 11, 4, "8", "1", "256", "1"),
+    (5, 10, 4, "0", "1", "256", "0"),   # plain persistent sweep, batched tails
+    (5, 10, 4, "8", "1", "0", "0"),     # ring sweep, every plane folded to the end under the next sweep
+    (4, 10, 2, "8", "1", "256", "0"),   # 8 row pairs per stream: the ring falls back to buffers of 4
+    (3, 10, 3, "8", "1", "256", "0"),   # 4 row pairs per stream: buffers of 2
+])
+def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, nu_2, t_gsw, ring, wgs, defer, split):
+    """The pipelined query's persistent sweep in ring form (k_sweep_packed_ring: two buffers of row pairs per wave, the next
+    stream's first buffer requested before this one's sums are stored) and the deferred fold tails (every plane folded to
+    256 / 64 ciphertexts under the next sweep, the remaining levels of all planes as one batch): response bytes equal the
+    oracle's for every buffer size, with and without the class split, and with either piece switched off."""
+    monkeypatch.setenv("SPIRAL_PIPE_RING", ring)
+    monkeypatch.setenv("SPIRAL_PIPE_RING_WGS", wgs)
+    monkeypatch.setenv("SPIRAL_PIPE_TAIL_DEFER", defer)
+    monkeypatch.setenv("SPIRAL_PIPE_SPLIT", split)
+    cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": t_gsw, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 8192}
+    o, cl, pp, q = _session(oracle_mod, cfg, 97, 11)
+    p = sp.Params(cfg)
+    item, db = o.generate_random_db_and_get_item(97)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    sp.paths_taken()
+    resp = sp.process_query(p, gpp, q, gdb)
+    taken = sp.paths_taken()
+    assert "pipelined_fold_overlap" in taken, taken
+    assert ("sweep_ring" in taken) == (ring != "0"), taken
+    # (t_gsw = 2: 29-bit gadget digits, which the fused fold kernels do not take -- nothing is deferred there)
+    assert ("fold_tail_batched" in taken) == (defer != "0" and t_gsw > 2), taken
+    assert ("pipe_class_split" in taken) == (split != "0"), taken
+    assert resp == o.process_query(pp, q, db)
+    if t_gsw >= 4:  # (fewer gadget digits: the noise is too large to decode, the bytes still have to agree)
+        assert cl.decode_response(resp) == o.item_to_vec(item)
+
+
 def test_process_query_batch_lds_staged(sp, oracle_mod):
     """Batched sweep with the queries' rows staged in LDS (groups of >= 5 queries on databases with >= 512 columns):
     14 queries = one group of 8 (two row pairs in flight) + one of 6 (four in flight); byte-identical per query."""
