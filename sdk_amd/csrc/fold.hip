@@ -507,7 +507,6 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
           e = e >= q1 ? e - q1 : e;
           const u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
           const u64 res = val >= T.c.Q ? val - T.c.Q : val;
-          if (d.nt_store == 2 && res != ~0ull) continue;  // timing diagnostic (diag_fold_no_store): results are WRONG
           if (d.nt_store)
             __builtin_nontemporal_store(res, orow + zi);
           else

@@ -312,7 +312,6 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
           u32 e = dd * T.c.q0_inv_q1 - qt * q1;
           e = e >= q1 ? e - q1 : e;
           const u64 val = (u64)x + (u64)q0 * (u64)e;
-          if ((xcd_map & 4) && val != ~0ull) continue;  // timing diagnostic (diag_fold_no_store): results are WRONG
           if (nt)
             __builtin_nontemporal_store(val, out + tau + 256 * k);
           else
@@ -331,8 +330,7 @@ void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes
   const unsigned groups = (unsigned)((np / (cls >= 0 ? 8 : 4)) * 2 * n_planes);
   const int want = (int)tunable("from_sweep_xcd", 1);
   const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
-  const int flags = (xcd_map ? 1 : 0) | (tunable("from_sweep_nt", 0) ? 2 : 0) |   // bit 1: streaming stores
-                    ((tunable("diag_fold_no_store", 0) & 1) ? 4 : 0);
+  const int flags = (xcd_map ? 1 : 0) | (tunable("from_sweep_nt", 0) ? 2 : 0);   // bit 1: streaming stores
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, flags, cls);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }

@@ -198,11 +198,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
   const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;  // one chunk-parity class or all chunks
-  u32* const ticket = d.ticket;
-  for (int unit = wave0; unit < units;) {
-    // the next stream's number is asked for now and looked at when this stream is done (one atomic per ~0.3 ms of work)
-    u32 drawn = 0;
-    if (ticket && lane == 0) drawn = atomicAdd(ticket, 1u);
+  for (int unit = wave0; unit < units; unit += nwaves) {
     const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
     // zmul (sweep_zmul, odd; 1 = identity): the z-rows are visited in the order z * zmul mod N, so that the units in flight
     // at one time are spread over the whole plane instead of one contiguous window of it (the chunks of a z stay together)
@@ -256,14 +252,6 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
     }
     sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
                      (u32)a03, (u32)a13);
-    unit = ticket ? nwaves + (int)__builtin_amdgcn_readfirstlane(drawn) : unit + nwaves;
-  }
-  if (ticket && lane == 0) {
-    // every wave has drawn its last (failing) ticket before it counts itself out: the last one out resets the counters
-    if (atomicAdd(ticket + 1, 1u) == (u32)nwaves - 1) {
-      __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_store(ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
   }
 }
 // Ring form of k_sweep_packed_persist (switch pipe_ring): two buffers of U row pairs per wave, the loads of one in flight
@@ -382,7 +370,7 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
   // C2 -- and a second ring workgroup per CU starves the fold kernels beside it: their loads queue behind the ring's)
   long ring = tunable("pipe_ring", 8);
   while (ring > 1 && (npairs % (2 * ring) != 0 || (ring != 2 && ring != 4 && ring != 8))) ring >>= 1;
-  if (ring >= 2 && !d.ticket) {
+  if (ring >= 2) {
     const int ring_wgs = (int)std::max(1L, tunable("pipe_ring_wgs", 1));
     const dim3 rgrid((unsigned)std::min(n_cus * ring_wgs, (units + 3) / 4));
     switch (ring) {
