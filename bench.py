@@ -87,7 +87,7 @@ def pmc_traffic(cfg_name, world, launches):
     tracked record and `traffic_source` says so.  (None, None) when no matching record exists."""
     if cfg_name != "c2" or world != 1:
         return None, None
-    for name in ("r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
+    for name in ("r03_final_pmc_sweep_c2.json", "r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             rec = json.load(open(path))
@@ -416,13 +416,42 @@ def main():
     ms_per_step = elapsed * 1e3 / args.steps
 
     # dominant kernel: the db sweep.  HIP events on the launch stream around `sweep_iters` launches.
+    # two queries in flight (single-GPU, one query per step): begin + sweep of query k+1 are queued before finish(k) is
+    # waited for, so that its expansion runs under query k's sweeps and k's last fold + pack under k+1's first sweep.
+    # Reported beside the headline, never as it (the headline stays one query at a time, comparable across rounds).
+    in_flight = None
+    if mode == "single" and batch == 1 and world == 1:
+        def two_in_flight(n):
+            prev = None
+            for i in range(n):
+                r = sp.QueryRun(p, pp, queries[i % len(queries)], db=db)
+                r.sweep(db)
+                if prev is not None:
+                    prev.finish()
+                    prev.free()
+                prev = r
+            o = prev.finish()
+            prev.free()
+            return o
+        two_in_flight(max(2, args.warmup))
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        last = two_in_flight(args.steps)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        in_flight = {"queries_in_flight": 2, "value": args.steps / dt, "unit": "queries/s", "ms_per_query": dt * 1e3 / args.steps,
+                     "responses": "identical" if last == sp.process_query(p, pp, queries[(args.steps - 1) % len(queries)], db) else "DIFFER",
+                     "note": "same %d queries through sp_query_begin / sp_query_sweep / sp_query_finish with the next query "
+                             "queued before the previous one is waited for; NOT the headline value" % args.steps}
     run = sp.QueryRun(p, pp, queries[0], db=db)
     per_plane_flow = mode in ("lib",) or (mode == "torch" and overlap)
+    sp.paths_taken()
     if per_plane_flow:                                        # one launch per plane, exchange overlapped
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters, per_plane=1), planes
     else:                                                     # 1, or one per plane when the fold is overlapped
         sweep_ms, launches = run.bench_sweep(db, args.sweep_iters), run.sweep_launches(db)
     run.free()
+    sweep_paths = sp.paths_taken()
     batch_pass = None
     if mode in ("single", "replicas") and batch > 1 and cfg["nu_2"] >= 7 and (1 << cfg["nu_1"]) % 2 == 0:   # PACKED databases only
         runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 8))]
@@ -467,7 +496,11 @@ def main():
         traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches)
         # the roofline block describes the kernel sp_bench_sweep / the stage events time: the single-query sweep; batched
         # steps add roofline.batched_pass (the pass kernel of the group, timed by sp_bench_sweep_batch)
-        kernel = "k_sweep_packed_persist<4>" if cfg["nu_2"] >= 7 else "k_sweep_narrow2"
+        npairs_local = (1 << cfg["nu_1"]) // (2 * (world if sharded and mode != "columns" else 1))
+        ring_u = next((u for u in (8, 4, 2) if npairs_local % (2 * u) == 0), 0)
+        kernel = ("k_sweep_packed_ring<%d>" % ring_u if "sweep_ring" in sweep_paths else
+                  "k_sweep_packed_persist<4>" if "sweep_packed_persist" in sweep_paths else
+                  "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow2")
         workload_how = {
             "single": "unsharded, one query per step" if batch == 1 else "unsharded, %d queries per step (<= 8 per database pass)" % batch,
             "replicas": "whole database on each of the %d GPUs, %d queries per GPU per step (one database pass), no collective in the timed region (BASELINE configs[4])" % (world, batch),
@@ -523,6 +556,8 @@ def main():
         }
         if batch_pass is not None:
             line["roofline"]["batched_pass"] = batch_pass
+        if in_flight is not None:
+            line["two_in_flight"] = in_flight
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         else:

@@ -15,7 +15,7 @@ def mean_counter(db, counter, kernel_substr):
     return sum(vals) / len(vals), len(vals)
 
 
-def main(fetch_db, write_db, out, kernel="k_sweep_packed_persist", launches_per_query=4, alg_bytes_per_query=69323456512):
+def main(fetch_db, write_db, out, kernel="k_sweep_packed_", launches_per_query=4, alg_bytes_per_query=69323456512):
     f, nf = mean_counter(fetch_db, "FETCH_SIZE", kernel)
     w, nw = mean_counter(write_db, "WRITE_SIZE", kernel)
     rec = {
