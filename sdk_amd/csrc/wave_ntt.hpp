@@ -50,7 +50,7 @@ __device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, 
   for (int k = 0; k < 8; k++) {
     const int idx = tau + 256 * k;
     const int ph = wtw_phys(idx);
-    ltw[ph] = tw[idx];
+    ltw[ph] = 0u - tw[idx];   // negated (ct_bfly_batch)
     ltw[N + ph] = tw[N + idx];
   }
 }
@@ -71,22 +71,38 @@ __device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, 
 // 16q.  Both outputs are < x + 2q: values grow by 2q per stage.  Instead of the reference's conditional subtraction of
 // 2q in every butterfly (ntt.rs:92-103; two of nine instructions) x is reduced by 8q in two of the eleven stages only
 // (CORR; see wntt_fwd for the bounds).  The residues mod q are the same, so every canonical result is too.
+// Five instructions per butterfly instead of seven: with NEGATED twiddles nw = -w (mod 2^32; the LDS copy and the scalar
+// entries are negated once, wtw_stage / wntt_scalar_tw) the Shoup product comes out negated,
+//     nl = floor(w' y / 2^32) q - w y   (mod 2^32)   = -(w y mod q, lazily in [0, 2q)),
+// as two chained v_mad_u64_u32 (nw * y, then + qt * q; only the low 32 bits of the sum are used -- the second one is inline
+// assembly because the compiler would narrow it to v_mul_lo + v_add) in place of v_mul_lo, v_mul_lo, v_sub, and the
+// two outputs are
+//     y' = x + 2q + nl  (v_add3_u32)      x' = x - nl
+// in place of add, sub, add.  Same residues as before in every register (all arithmetic is mod 2^32).
 template <int B, bool CORR>
-__device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&w)[B], const u32 (&wp)[B], u32 q, u32 q2) {
-  u32 qt[B], lo[B], t[B];
+__device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&nw)[B], const u32 (&wp)[B], u32 q, u32 q2) {
+  u32 qt[B], t[B];
+  u64 nl[B];
 #pragma unroll
   for (int b = 0; b < B; b++) qt[b] = __umulhi(y[b], wp[b]);
   SP_SB();
 #pragma unroll
-  for (int b = 0; b < B; b++) lo[b] = w[b] * y[b];
+  for (int b = 0; b < B; b++) nl[b] = (u64)nw[b] * y[b];
   SP_SB();
   if (CORR) {
 #pragma unroll
     for (int b = 0; b < B; b++) t[b] = x[b] - 4 * q2;
     SP_SB();
   }
+  // (one assembly statement per four: between separate statements the compiler puts an s_nop each)
+  static_assert(B % 4 == 0, "butterfly batches come in fours");
 #pragma unroll
-  for (int b = 0; b < B; b++) qt[b] = qt[b] * q;
+  for (int b = 0; b < B; b += 4)
+    asm("v_mad_u64_u32 %0, vcc, %4, %8, %0\n\tv_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %8, %2\n\tv_mad_u64_u32 %3, vcc, %7, %8, %3"
+        : "+v"(nl[b]), "+v"(nl[b + 1]), "+v"(nl[b + 2]), "+v"(nl[b + 3])
+        : "v"(qt[b]), "v"(qt[b + 1]), "v"(qt[b + 2]), "v"(qt[b + 3]), "s"(q)
+        : "vcc");
   SP_SB();
   if (CORR) {
 #pragma unroll
@@ -94,16 +110,10 @@ __device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u3
     SP_SB();
   }
 #pragma unroll
-  for (int b = 0; b < B; b++) lo[b] = lo[b] - qt[b];
+  for (int b = 0; b < B; b++) y[b] = x[b] + q2 + (u32)nl[b];
   SP_SB();
 #pragma unroll
-  for (int b = 0; b < B; b++) y[b] = x[b] + q2;
-  SP_SB();
-#pragma unroll
-  for (int b = 0; b < B; b++) {
-    y[b] = y[b] - lo[b];
-    x[b] = x[b] + lo[b];
-  }
+  for (int b = 0; b < B; b++) x[b] = x[b] - (u32)nl[b];
   SP_SB();
 }
 // butterflies (v[ia], v[ib]) with twiddles (w, wp), ia / ib / twiddle index given by the functors, in batches of 8
@@ -128,7 +138,7 @@ __device__ __forceinline__ void wntt_scalar_tw(WaveScalarTw& s, const u32* tw) {
   const cu32_t* sw = (const cu32_t*)tw;
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    s.w[i] = sw[i];
+    s.w[i] = 0u - sw[i];      // negated (ct_bfly_batch)
     s.wp[i] = sw[N + i];
   }
 }
@@ -153,7 +163,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
   u32 w5[16], p5[16];  // stage t = 64: entries 16..31, in flight during the first four stages
 #pragma unroll
   for (int i = 0; i < 16; i++) {
-    w5[i] = sw[16 + i];
+    w5[i] = 0u - sw[16 + i];  // negated (ct_bfly_batch)
     p5[i] = sw[N + 16 + i];
   }
   SP_SB();

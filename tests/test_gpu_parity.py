@@ -731,10 +731,14 @@ def test_column_sharded_single_gpu_emulation(sp, oracle_mod, monkeypatch, cfg, G
     assert runs[0].finish_gathered(gathered.data_ptr(), G) == expect
 
 
-@pytest.mark.parametrize("cfg,B", [(dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 11), (FAST56, 3)], ids=["packed-11", "narrow-3"])
-def test_process_query_batch(sp, oracle_mod, cfg, B):
+@pytest.mark.parametrize("cfg,B,in_flight", [(dict(FAST, nu_1=6, nu_2=7, db_item_size=256), 11, "2"), (FAST56, 3, "2"),
+                                             (FAST56, 6, "2"), (FAST56, 4, "1")],
+                         ids=["packed-11", "narrow-3", "narrow-6", "narrow-4-one-at-a-time"])
+def test_process_query_batch(sp, oracle_mod, monkeypatch, cfg, B, in_flight):
     """BASELINE configs[4]: batched queries share database passes (groups of <= 8 on the PACKED layout; 11 = 8 + 3
-    exercises two group sizes); two different clients' keys in one batch.  Byte-identical per query."""
+    exercises two group sizes); on narrow (8-byte) databases the list runs one pass per query with two queries in flight
+    (SPIRAL_BATCH_IN_FLIGHT=1: one at a time).  Two different clients' keys in one batch.  Byte-identical per query."""
+    monkeypatch.setenv("SPIRAL_BATCH_IN_FLIGHT", in_flight)
     o = oracle_mod.Params(cfg)
     p = sp.Params(cfg)
     cls = [oracle_mod.Client(o), oracle_mod.Client(o)]
