@@ -922,10 +922,10 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
   const Params& p = h->p;
   const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !tunable("no_batch_sweep", 0);
   if (!batched) {
-    // 8-byte / narrow databases: one pass per query, TWO queries in flight -- query i + 1 is deserialised, expanded and
-    // swept (own workspace, own streams) before query i is waited for, so that its expansion, a chain of ~30 small
-    // dependent launches, runs under its predecessors' sweeps and folds instead of after them (C1: 1422 against 994 queries/s, P2:
-    // 1054 against 828 with three in flight, the default; switch batch_in_flight = 1 .. 4, 1 = the one-at-a-time loop).
+    // 8-byte / narrow databases: one pass per query, up to `batch_in_flight` (default 3, at most 4; 1 = one at a time)
+    // queries in flight -- query i + 1 is deserialised, expanded and swept on its own workspace and streams before query
+    // i is waited for, so that its expansion, a chain of ~30 small dependent launches, runs under its predecessors' sweeps
+    // and folds instead of after them.  Lists of 8: C1 994 -> 1422 queries/s, P2 828 -> 1054.
     if (db->num_shards != 1 || db->col_G != 1) {
       g_last_error = "sp_process_query_batch needs an unsharded db";
       return SP_E_ARG;
