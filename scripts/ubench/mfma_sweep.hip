@@ -328,7 +328,7 @@ int main(int argc, char** argv) {
     k_fill_q<<<(unsigned)((qn + 255) / 256), 256>>>(c.qv[b], b, qn);
     CK(hipMalloc(&c.out[b], (size_t)4 * N * c.num_per * 4 * (b == 0 ? 8 : 1)));
   }
-  CK(hipMalloc(&c.rq, (size_t)N * (c.nj / 16) * 128 * 16));
+  CK(hipMalloc(&c.rq, (size_t)N * (c.nj / 16) * 128 * 16 + (size_t)N * 32 * 4));  // digit table + offset terms
   CK(hipDeviceSynchronize());
   printf("database: %d z-rows x %d columns x %d rows = %.2f GB packed\n", nz, c.num_per, c.nj, db_dwords * 4 / 1e9);
 
@@ -396,9 +396,16 @@ int main(int argc, char** argv) {
   float ms;
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("[k_query_digits] %.3f ms for 8 queries\n", ms);
+  CK(hipEventRecord(e0));
+  k_query_offset_terms<<<N, 256>>>(c.T, qd, c.rq + entries * 4);
+  CK(hipEventRecord(e1));
+  CK(hipEventSynchronize(e1));
+  CK(hipEventElapsedTime(&ms, e0, e1));
+  printf("[k_query_offset_terms] %.3f ms for 8 queries\n", ms);
 
   c.d.db = reinterpret_cast<const u64*>(c.db);
   c.d.rq = c.rq;
+  c.d.rq_off = c.rq + entries * 4;
   for (int b = 0; b < 8; b++) c.d.out[b] = c.out[b];
   c.d.batch = 8;
   c.d.planes = 1;

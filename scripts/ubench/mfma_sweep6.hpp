@@ -57,6 +57,8 @@ __global__ __launch_bounds__(384, 3) void k_sweep_mfma_batch6(DevTables T, Sweep
     out_b0 = kb == k2 ? d.out[2 * k2] : out_b0;
     out_b1 = kb == k2 ? d.out[2 * k2 + 1] : out_b1;
   }
+  const mf_u32x4_t off0 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + kb];
+  const mf_u32x4_t off1 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + 4 + kb];
   mf_u32x4_t va[NB][2];
   mf_u32x3_t vb[NB][2];
 
@@ -99,10 +101,10 @@ __global__ __launch_bounds__(384, 3) void k_sweep_mfma_batch6(DevTables T, Sweep
       if (DIAG == 3) {                                                                               \
         A[e][c] = __builtin_bit_cast(v4i_t, (e ^ c) ? va[BUF][0] : va[BUF][1]);                      \
       } else {                                                                                       \
-        A[e][c][0] = (int)signed_digits(f[0][2 * e + c]);                                            \
-        A[e][c][1] = (int)signed_digits(f[0][4 + 2 * e + c]);                                        \
-        A[e][c][2] = (int)signed_digits(f[1][2 * e + c]);                                            \
-        A[e][c][3] = (int)signed_digits(f[1][4 + 2 * e + c]);                                        \
+        A[e][c][0] = (int)offset_digits(f[0][2 * e + c]);                                            \
+        A[e][c][1] = (int)offset_digits(f[0][4 + 2 * e + c]);                                        \
+        A[e][c][2] = (int)offset_digits(f[1][2 * e + c]);                                            \
+        A[e][c][3] = (int)offset_digits(f[1][4 + 2 * e + c]);                                        \
       }                                                                                              \
     }                                                                                                \
     _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                  \
@@ -162,9 +164,9 @@ __global__ __launch_bounds__(384, 3) void k_sweep_mfma_batch6(DevTables T, Sweep
         for (int c = 0; c < 2; c++) {
           const ModConst mc = c ? m1 : m0;
           const u32 v0 = combine_digit_sums(acc[0][c][0][i], acc[0][c][1][i], acc[0][c][2][i], acc[0][c][3][i],
-                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
+                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], c ? off1[i] : off0[i]);
           const u32 v1 = combine_digit_sums(acc[1][c][0][i], acc[1][c][1][i], acc[1][c][2][i], acc[1][c][3][i],
-                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
+                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], c ? off1[i] : off0[i]);
           if (DIAG == 4 && (v0 ^ v1) != 0xDEADBEEFu) continue;  // (practically) no stores
           if (DIAG == 7) {
             u32* o7 = d.out[0] + ((((size_t)zp * chunks + chunk0 + ch) * 4 + g) * 8 + (i * 2 + c)) * 128 + 2 * lane;

@@ -309,7 +309,8 @@ struct SweepBatchDesc {
 };
 // does this shape / group size run on the matrix cores (switch batch_mfma, default on from batch_mfma_min = 4 queries)?
 bool sweep_batch_wants_mfma(const SweepBatchDesc& d);
-inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16) * 128 * 4; }
+// digit table [N][nj / 16][2][64][4] + offset-correction table [N][2][16] (k_query_digits / k_query_offset_terms)
+inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16) * 128 * 4 + (size_t)N * 32; }
 // once per group of queries, before the pass (all planes share the table): builds the digit table when the matrix-core
 // form applies and d.rq is set
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s);

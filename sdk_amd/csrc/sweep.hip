@@ -560,12 +560,15 @@ void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
   const size_t entries = (size_t)N * (d.nj >> 4) * 128;
   hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
   launched(0, "k_query_digits");
+  hipLaunchKernelGGL(k_query_offset_terms, dim3(N), dim3(256), 0, s, T, q, d.rq + entries * 4);
+  launched(0, "k_query_offset_terms");
   d.use_mfma = 1;
 }
 static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
   SweepMfmaDesc m{};
   m.db = d.db;
   m.rq = d.rq;
+  m.rq_off = d.rq + (size_t)N * (d.nj >> 4) * 128 * 4;
   for (int b = 0; b < d.batch; b++) m.out[b] = d.out[b];
   m.batch = d.batch;
   m.planes = d.planes;

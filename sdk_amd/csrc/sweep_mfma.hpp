@@ -4,11 +4,15 @@
 //
 // With B >= 4 queries per pass the first-dimension multiply is, for every (plane, z, modulus), an exact integer GEMM
 // [num_per x dim0] . [dim0 x 2B] whose VALU form (k_sweep_packed_batch, 32 v_mad_u64_u32 per database word at B = 8)
-// is issue-bound at 1.9x the HBM time of the pass.  Here the 28-bit residues are split into four SIGNED base-256
-// digits (x + 0x808080 ^ 0x808080: bytes 0-2 in [-128, 127], byte 3 in [0, 16]) and multiplied on
-// v_mfma_i32_16x16x64_i8:
-//   sum_j x_j y_j = sum_{s=0..6} 256^s D_s,   D_s = sum_j sum_{a+b=s} xdigit_a(j) ydigit_b(j),   |D_s| <= 4 nj 2^14
-// exact in i32 for nj <= 2^15 rows.  One MFMA covers K = 64 = (16 rows) x (4 database digits); its B operand for shift
+// is issue-bound at 1.9x the HBM time of the pass.  Here the 28-bit residues are split into four signed bytes and
+// multiplied on v_mfma_i32_16x16x64_i8.  The QUERY side y uses carry-propagated signed base-256 digits (y + 0x808080 ^
+// 0x808080: bytes 0-2 in [-128, 127], byte 3 in [0, 16], sum digit_b 256^b = y; done once per pass by k_query_digits); the
+// DATABASE side x, converted inside the sweep for every word, uses OFFSET digits x ^ 0x80808080 = bytes u_a - 128 (one
+// instruction, no carries), which leaves a term that does not depend on the database column:
+//   sum_j x_j y_j = sum_{s=0..6} 256^s D_s + 128 (1 + 2^8 + 2^16 + 2^24) sum_j y_j,
+//   D_s = sum_j sum_{a+b=s} (u_a(j) - 128) ydigit_b(j),   |D_s| <= 4 nj 2^14
+// exact in i32 for nj <= 2^15 rows; the second term, mod q, comes from k_query_offset_terms per (z, query column, modulus)
+// and is added when the digit sums are recombined.  One MFMA covers K = 64 = (16 rows) x (4 database digits); its B operand for shift
 // s carries the query digit y_{s-a} in byte a of each row's dword (zero where s - a is outside 0..3), i.e. the
 // byte-reversed digit dword shifted by whole bytes -- so the seven operands of a row block are six VALU shifts of one
 // LDS read.  Seven i32 accumulators per (output, modulus) are recombined and reduced mod q once per 128-column chunk.
@@ -32,10 +36,14 @@ typedef u32 mf_u32x2_t __attribute__((ext_vector_type(2)));
 constexpr u32 DIGIT_BIAS = 0x00808080u;
 // four signed base-256 digits of x < 2^28 in the four bytes of the result (sum digit_i 256^i = x)
 __host__ __device__ __forceinline__ u32 signed_digits(u32 x) { return (x + DIGIT_BIAS) ^ DIGIT_BIAS; }
+// four offset digits: byte a = (byte a of x) - 128 as a signed byte (sum digit_a 256^a = x - DIGIT_OFFSET_SUM)
+constexpr u32 DIGIT_OFFSET = 0x80808080u;  // = 128 (1 + 2^8 + 2^16 + 2^24), also the value the offsets add up to
+__host__ __device__ __forceinline__ u32 offset_digits(u32 x) { return x ^ DIGIT_OFFSET; }
 
 struct SweepMfmaDesc {
   const u64* db;                  // PACKED database: plane 0 of the launch
   const u32* rq;                  // query digit table [N][nj / 16][2][64][4] (k_query_digits)
+  const u32* rq_off;              // offset terms [N][2][16]: DIGIT_OFFSET * sum_j y_j mod q per (z, crt, query column)
   u32* out[SWEEP_BATCH_MAX];      // per query: sweep-native [plane][r][crt][z][ii]
   int batch;                      // 1 .. 8 (unused query columns of the table are zero)
   int planes, num_per, nj;        // nj % 16 == 0, nj <= 512 (LDS-staged table), num_per % 128 == 0
@@ -71,14 +79,38 @@ __global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
   reinterpret_cast<mf_u32x4_t*>(d.rq)[idx] = o;
 }
 
+// Offset terms of the database-side digit form: off[z][crt][n] = DIGIT_OFFSET * (sum_j y_j) mod q over the nj rows of query
+// column n = 2 b + r (zero for b >= batch).  One workgroup per z: 8 threads per (crt, n) add up strided rows, then a
+// shuffle reduction; the row sum (< 2^37) and the product with DIGIT_OFFSET mod q (< 2^28) are exact in 64 bits.
+__global__ __launch_bounds__(256) void k_query_offset_terms(DevTables T, QueryDigitsDesc d, u32* off) {
+  const int z = blockIdx.x, t = threadIdx.x;
+  const int combo = t >> 3, part = t & 7;      // combo = crt * 16 + n
+  const int crt = combo >> 4, n = combo & 15, b = n >> 1, r = n & 1;
+  u64 sum = 0;
+  if (b < d.batch) {
+    const u64* q = d.qv[b] + ((size_t)z * d.dim0 + d.j0) * 2 + r;
+    for (int j = part; j < d.nj; j += 8) {
+      const u64 w = q[2 * (size_t)j];
+      sum += crt ? (u32)(w >> 32) : (u32)w;
+    }
+  }
+#pragma unroll
+  for (int sft = 1; sft < 8; sft <<= 1) sum += __shfl_xor(sum, sft, 8);
+  if (part == 0) {
+    const ModConst m = T.c.mod[crt];
+    const u32 sy = reduce64(sum, m);
+    off[(size_t)z * 32 + combo] = reduce64((u64)sy * (u64)(DIGIT_OFFSET % m.q), m);
+  }
+}
+
 // sum_s 256^s D[s] mod q for |D[s]| < 2^26 (exact: the sum is the non-negative integer sum_j x_j y_j).  The three high
 // digit sums are multiplied by 256^s mod q (c4 = 2^32, c5 = 2^40, c6 = 2^48 mod q, each < 2^28: |products| < 2^54) and added
 // to the low part as signed 64-bit integers; q 2^29 makes the total positive, one Barrett fold finishes.
 __device__ __forceinline__ u32 combine_digit_sums(int d0, int d1, int d2, int d3, int d4, int d5, int d6, const ModConst m,
-                                                  u32 c4, u32 c5, u32 c6) {
+                                                  u32 c4, u32 c5, u32 c6, u32 off) {
   long long v = (long long)d0 + ((long long)d1 << 8) + ((long long)d2 << 16) + ((long long)d3 << 24);  // |.| < 2^51
   v += (long long)d4 * (long long)c4 + (long long)d5 * (long long)c5 + (long long)d6 * (long long)c6;   // |.| < 2^56
-  return reduce64((u64)(v + ((long long)m.q << 29)), m);
+  return reduce64((u64)(v + ((long long)m.q << 29) + (long long)off), m);  // off < q: the offset term (k_query_offset_terms)
 }
 
 // DIAG (microbenchmark only, scripts/ubench/mfma_sweep.hip; 0 in the library): 1 = no database loads after the
@@ -134,6 +166,9 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
     out_b0 = kb == k2 ? d.out[2 * k2] : out_b0;
     out_b1 = kb == k2 ? d.out[2 * k2 + 1] : out_b1;
   }
+  // offset terms of this lane's four query columns n = 4 kb + i, both moduli (the same for every chunk of the workgroup)
+  const mf_u32x4_t off0 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + kb];
+  const mf_u32x4_t off1 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + 4 + kb];
   mf_u32x4_t va[NB][2];
   mf_u32x3_t vb[NB][2];
 
@@ -174,10 +209,10 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
       if (DIAG == 3) {                                                                               \
         A[e][c] = __builtin_bit_cast(v4i_t, (e ^ c) ? va[BUF][0] : va[BUF][1]);                      \
       } else {                                                                                       \
-        A[e][c][0] = (int)signed_digits(f[0][2 * e + c]);                                            \
-        A[e][c][1] = (int)signed_digits(f[0][4 + 2 * e + c]);                                        \
-        A[e][c][2] = (int)signed_digits(f[1][2 * e + c]);                                            \
-        A[e][c][3] = (int)signed_digits(f[1][4 + 2 * e + c]);                                        \
+        A[e][c][0] = (int)offset_digits(f[0][2 * e + c]);                                            \
+        A[e][c][1] = (int)offset_digits(f[0][4 + 2 * e + c]);                                        \
+        A[e][c][2] = (int)offset_digits(f[1][2 * e + c]);                                            \
+        A[e][c][3] = (int)offset_digits(f[1][4 + 2 * e + c]);                                        \
       }                                                                                              \
     }                                                                                                \
     _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                  \
@@ -232,10 +267,11 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const ModConst mc = c ? m1 : m0;
+          const u32 oc = c ? off1[i] : off0[i];
           const u32 v0 = combine_digit_sums(acc[0][c][0][i], acc[0][c][1][i], acc[0][c][2][i], acc[0][c][3][i],
-                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
+                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
           const u32 v1 = combine_digit_sums(acc[1][c][0][i], acc[1][c][1][i], acc[1][c][2][i], acc[1][c][3][i],
-                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c]);
+                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
           if (DIAG == 4 && (v0 ^ v1) != 0xDEADBEEFu) continue;  // (practically) no stores
           if (DIAG == 7) {
             u32* o7 = d.out[0] + ((((size_t)zp * chunks + chunk0 + ch) * 4 + g) * 8 + (i * 2 + c)) * 128 + 2 * lane;
