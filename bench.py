@@ -245,6 +245,9 @@ def main():
                          "queries split over the GPUs, no collective; BASELINE configs[4])")
     ap.add_argument("--sweep-iters", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--two-in-flight", action="store_true",
+                    help="also time the same queries with two in flight (extra object `two_in_flight` in the line; off by "
+                         "default so that the kernel statistics of the default command hold the timed steps only)")
     ap.add_argument("--batch", type=int, default=0,
                     help="queries per step per GPU (single-GPU and replicas modes): groups of <= 8 queries share one "
                          "database pass (sp_process_query_batch).  Default 1 (single) / 8 (replicas).")
@@ -420,7 +423,7 @@ def main():
     # waited for, so that its expansion runs under query k's sweeps and k's last fold + pack under k+1's first sweep.
     # Reported beside the headline, never as it (the headline stays one query at a time, comparable across rounds).
     in_flight = None
-    if mode == "single" and batch == 1 and world == 1:
+    if mode == "single" and batch == 1 and world == 1 and args.two_in_flight:
         def two_in_flight(n):
             prev = None
             for i in range(n):

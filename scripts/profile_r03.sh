@@ -26,6 +26,8 @@ timeout 600 python bench.py --batch 8 --steps 5 --warmup 2 --no-cpu-baseline > $
 timeout 600 python bench.py --mode replicas --steps 5 --warmup 2 --no-cpu-baseline > $O/${T}_bench_c2_replicas1.json 2>/dev/null
 timeout 600 python bench.py --config c1 --no-cpu-baseline > $O/${T}_bench_c1.json 2>/dev/null
 timeout 600 python bench.py --config p2 --no-cpu-baseline > $O/${T}_bench_p2.json 2>/dev/null
+timeout 600 python bench.py --config c1 --batch 8 --steps 8 --warmup 2 --no-cpu-baseline > $O/${T}_bench_c1_list8.json 2>/dev/null
+timeout 600 python bench.py --config p2 --batch 8 --steps 8 --warmup 2 --no-cpu-baseline > $O/${T}_bench_p2_list8.json 2>/dev/null
 SPIRAL_FORCE_DIST=1 MASTER_PORT=29655 timeout 600 python bench.py --no-cpu-baseline > $O/${T}_bench_c2_dist1.json 2>/dev/null
 timeout 900 python bench.py --config c4 --steps 5 --warmup 1 --no-cpu-baseline > $O/${T}_bench_c4.json 2>/dev/null
 timeout 900 python bench.py --config c3 --steps 5 --warmup 1 --no-cpu-baseline > $O/${T}_bench_c3.json 2>/dev/null
