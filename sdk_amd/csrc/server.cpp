@@ -653,6 +653,8 @@ void Workspace::ensure_finish() {
   pack_ct2.ensure(nb * 2 * POLY_LEN);
   pack_res.ensure(p.instances * (p.n + 1) * p.n * 2 * POLY_LEN);
   pack_raw.ensure(p.instances * (p.n + 1) * p.n * POLY_LEN);
+  // parking buffer of the pipelined query's batched fold tails (pipe_tail_defer, default 256 ciphertexts per plane)
+  if (p.planes() > 1 && p.num_per() >= 1024 && fused_ok) fold_tail.ensure(2 * p.planes() * 256 * 2 * POLY_LEN);
 }
 
 // ---------------------------------------------------------------------------------- pipeline stages
