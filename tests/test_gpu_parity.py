@@ -369,6 +369,41 @@ def test_concurrent_host_threads(sp, oracle_mod):
     assert got == exp
 
 
+def test_query_list_in_flight_errors_and_threads(sp, oracle_mod):
+    """Lists on a narrow database keep up to three queries in flight (sp_process_query_batch): a malformed query in the
+    middle of a list fails the call without wedging the workspaces of the queries around it (the next list is answered
+    correctly), and two host threads may submit lists against one database at the same time."""
+    import threading
+    cfg = FAST56
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(4)
+    item, db = o.generate_random_db_and_get_item(9)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    qs = [cl.generate_query((29 * i + 1) % o.num_items, 70 + i) for i in range(7)]
+    exp = [o.process_query(pp, q, db) for q in qs]
+    bad = list(qs)
+    bad[3] = qs[3][:-8]  # wrong length: rejected when the list reaches it, three good queries already in flight
+    with pytest.raises(sp.SpiralError):
+        sp.process_query_batch(p, gpp, bad, gdb)
+    assert sp.process_query_batch(p, gpp, qs, gdb) == exp
+    got, errs = [None, None], []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = sp.process_query_batch(p, gpp, qs[t:] + qs[:t], gdb)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs
+    assert got[0] == exp and got[1] == exp[1:] + exp[:1]
+
+
 def test_process_query_c1(sp, oracle_mod):
     """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
     idx = 12345
