@@ -52,7 +52,8 @@ def main():
               (v or "baseline", alone, steps / dt, *(stage / steps), "ok" if sha == ref else "RESPONSE CHANGED"), flush=True)
 
 
-DEFAULTS = {"pipe_wgs": 4, "pipe_unroll": 4, "sweep_prio": 1, "fold_variant": 5, "fused_min_pairs": 256, "expand_split": -1}
+DEFAULTS = {"pipe_wgs": 4, "pipe_unroll": 4, "sweep_prio": 1, "fold_variant": 5, "fused_min_pairs": 256, "expand_split": -1,
+            "pipe_ring": 8, "pipe_ring_wgs": 1, "pipe_tail_defer": 256, "batch_in_flight": 3, "pipeline": 1, "sweep_nt_store": 1}
 
 if __name__ == "__main__":
     main()
