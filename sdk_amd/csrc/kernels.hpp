@@ -280,6 +280,11 @@ struct SweepDesc {
   // non-temporal (streaming) output stores: HBM writes mixed into the read stream cost 3-4x a read byte on this part, a
   // quarter less as streaming stores (scripts/ubench/rw_mix.hip); switch sweep_nt_store
   int nt_store;
+  // ring-form persistent sweep: two zeroed words (streams handed out, waves done) or null.  Non-null: a wave's streams
+  // after its first are handed out by an atomic counter instead of a fixed stride, so that waves on CUs that also run fold
+  // workgroups, or whose memory channels are busier, take fewer streams instead of holding the launch back (switch
+  // sweep_tickets).  The last wave to leave zeroes both words again.
+  u32* ticket;
 };
 // Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
 // i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.

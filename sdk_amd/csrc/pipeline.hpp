@@ -47,6 +47,7 @@ struct Workspace {
   DevBuf<u32> gsw_dig;
   // sweep
   DevBuf<u32> sweep_out;  // [plane][r][crt][z][ii]
+  DevBuf<u32> sweep_ticket;  // SweepDesc::ticket (zeroed once; the ring sweep leaves it zeroed)
   DevBuf<u64> fold_tail;     // pipe_tail_defer: [2][plane][cts parked per plane][2][N]
   DevBuf<u32> batch_rq;   // query digit table of a batched pass on the matrix cores (first workspace of a group; on first use)
   // fold / pack

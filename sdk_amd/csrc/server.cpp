@@ -634,6 +634,10 @@ size_t Workspace::plane_group() const {
 void Workspace::ensure_sweep() {
   const Params& p = *P;
   sweep_out.ensure(p.planes() * 4 * POLY_LEN * p.num_per());
+  if (!sweep_ticket.p) {  // SweepDesc::ticket: zero once, the kernel leaves it zeroed
+    sweep_ticket.ensure(64);
+    HIP_CHECK(hipMemset(sweep_ticket.p, 0, 64 * sizeof(u32)));
+  }
 }
 
 void Workspace::ensure_finish() {
@@ -1163,6 +1167,7 @@ void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl, int cls) {
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
               (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G, cls >= 0 ? 2 : 1, cls >= 0 ? cls : 0};
   d.nt_store = (int)tunable("sweep_nt_store", 1);
+  d.ticket = tunable("sweep_tickets", 0) != 0 ? W.sweep_ticket.p : nullptr;
   const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
   if (db.packed && wgs > 0)
     launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);

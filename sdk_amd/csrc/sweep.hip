@@ -273,7 +273,18 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
   const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;
-  if (wave0 >= units) return;
+  // (tickets) every wave of the grid counts itself out when it leaves; the last one zeroes the two words for the next launch
+#define SPR_COUNT_OUT                                                                                 \
+  if (d.ticket && lane == 0) {                                                                        \
+    if (atomicAdd(d.ticket + 1, 1u) == (u32)nwaves - 1) {                                             \
+      __hip_atomic_store(d.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   \
+      __hip_atomic_store(d.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
+    }                                                                                                 \
+  }
+  if (wave0 >= units) {
+    SPR_COUNT_OUT
+    return;
+  }
   u32x4_t va[U], na[U];
   u32x3_t vb[U], nb[U];
 #define SPR_BASE(UNIT) \
@@ -309,7 +320,12 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
   a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
   const u32* base = SPR_BASE(wave0);
   SPR_LOAD(va, vb, base, 0)
-  for (int unit = wave0; unit < units; unit += nwaves) {
+  u32* const ticket = d.ticket;
+  for (int unit = wave0; unit < units;) {
+    // (tickets) the number of the stream after this one is asked for now and looked at when this stream's last buffer is
+    // requested: one atomic per ~70 us of work, its latency hidden behind the whole stream
+    u32 drawn = 0;
+    if (ticket && lane == 0) drawn = atomicAdd(ticket, 1u);
     const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
     const int zp = unit / chunks_l;
     const int z = zp & (N - 1);
@@ -320,8 +336,8 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
     const sweep_const_uint4* qrow =
         (const sweep_const_uint4*)(uintptr_t)(reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0));
     u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
-    // the wave's next stream (its own again past the end: a harmless re-read of 7 KiB)
-    const u32* next_base = unit + nwaves < units ? SPR_BASE(unit + nwaves) : base;
+    int next_unit = units;
+    const u32* next_base = base;
     // blocks of at most 128 row pairs = 256 rows of < 2^56 products between Barrett folds.  No conditional code inside a
     // block (a branch lets the optimiser sink the reload of a buffer below the multiplies of the other one)
     for (int jb = 0; jb < npairs; jb += 128) {
@@ -339,6 +355,9 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
       __builtin_amdgcn_sched_barrier(0);
       SPR_MAC(va, vb, j)
       const bool more = jb + 128 < npairs;
+      // the wave's next stream (its own again past the end: a harmless re-read of 7 KiB)
+      next_unit = ticket ? nwaves + (int)__builtin_amdgcn_readfirstlane(drawn) : unit + nwaves;
+      next_base = next_unit < units ? SPR_BASE(next_unit) : base;
       const u32* nb_base = more ? base : next_base;
       const int nb_jp = more ? jb + 128 : 0;
       SPR_LOAD(va, vb, nb_base, nb_jp)
@@ -349,7 +368,11 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
     sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
                      (u32)a03, (u32)a13);
     base = next_base;
+    unit = next_unit;
   }
+  // every wave has drawn its last (failing) ticket before it counts itself out
+  SPR_COUNT_OUT
+#undef SPR_COUNT_OUT
 #undef SPR_BASE
 #undef SPR_LOAD
 #undef SPR_MAC

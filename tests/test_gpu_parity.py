@@ -1028,12 +1028,17 @@ def test_pipelined_class_split_parity(sp, oracle_mod, monkeypatch, nu_2, split):
     (5, 10, 4, "8", "1", "0", "0"),     # ring sweep, every plane folded to the end under the next sweep
     (4, 10, 2, "8", "1", "256", "0"),   # 8 row pairs per stream: the ring falls back to buffers of 4
     (3, 10, 3, "8", "1", "256", "0"),   # 4 row pairs per stream: buffers of 2
+    (5, 10, 4, "8t", "1", "256", "0"),  # streams handed out by tickets (sweep_tickets), twice in a row: the counters reset
+    (5, 11, 4, "4t", "2", "256", "2"),
 ])
 def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, nu_2, t_gsw, ring, wgs, defer, split):
     """The pipelined query's persistent sweep in ring form (k_sweep_packed_ring: two buffers of row pairs per wave, the next
     stream's first buffer requested before this one's sums are stored) and the deferred fold tails (every plane folded to
     256 / 64 ciphertexts under the next sweep, the remaining levels of all planes as one batch): response bytes equal the
     oracle's for every buffer size, with and without the class split, and with either piece switched off."""
+    tickets = ring.endswith("t")
+    ring = ring.rstrip("t")
+    monkeypatch.setenv("SPIRAL_SWEEP_TICKETS", "1" if tickets else "0")
     monkeypatch.setenv("SPIRAL_PIPE_RING", ring)
     monkeypatch.setenv("SPIRAL_PIPE_RING_WGS", wgs)
     monkeypatch.setenv("SPIRAL_PIPE_TAIL_DEFER", defer)
@@ -1054,6 +1059,8 @@ def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, 
     assert ("fold_tail_batched" in taken) == (defer != "0" and t_gsw > 2), taken
     assert ("pipe_class_split" in taken) == (split != "0"), taken
     assert resp == o.process_query(pp, q, db)
+    if tickets:
+        assert sp.process_query(p, gpp, q, gdb) == resp
     if t_gsw >= 4:  # (fewer gadget digits: the noise is too large to decode, the bytes still have to agree)
         assert cl.decode_response(resp) == o.item_to_vec(item)
 
