@@ -99,6 +99,32 @@ def pmc_traffic(cfg_name, world, launches):
     return None, None
 
 
+def torchrun_command(n_gpus, argv, port=None):
+    """The command `python bench.py --gpus N ...` turns itself into when no launcher has set WORLD_SIZE: one rank per
+    GPU on this node under torch.distributed.run, rendezvous on 127.0.0.1 (the container hostname may not resolve)."""
+    if port is None:
+        port = int(os.environ.get("MASTER_PORT", "0")) or (29500 + os.getpid() % 2000)
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus),
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def gpu_telemetry():
+    """Clocks / temperatures / power of GPU 0 from rocm-smi (outside every timed region); {} when the tool is missing."""
+    import subprocess
+    try:
+        out = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--showtemp", "--showpower", "--json"],
+                             capture_output=True, text=True, timeout=20).stdout
+        card = next(iter(json.loads(out).values()))
+        keep = {}
+        for k, v in card.items():
+            kl = k.lower()
+            if any(s in kl for s in ("sclk", "mclk", "fclk", "temperature", "power")):
+                keep[k] = v
+        return keep
+    except Exception as e:   # telemetry only
+        return {"error": repr(e)[:120]}
+
+
 def cpu_model():
     try:
         for line in open("/proc/cpuinfo"):
@@ -113,26 +139,31 @@ def cpu_baseline(cfg_name, cfg):
     """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample, two modes:
     faithful = spiral-rs's own threading (server.rs:682-694: the sweep and the fold of an instance run on ONE thread,
                expansion uses the rayon loops); all_core = lib/server's shape (AVX2 u64-lane sweep,
-               lib/server/src/compute/dot_product.rs:59-95, every core busy: z-rows of the sweep and subtrees of the
-               fold spread over the threads, lib/server/src/server.rs:53-55).  C1 (configs[0]) is also timed in full."""
+               lib/server/src/compute/dot_product.rs:59-95, every core offered: z-rows of the sweep and subtrees of the
+               fold spread over the threads, lib/server/src/server.rs:53-55).  C1 (configs[0]) is also timed in full.
+    EVERY STAGE is timed with its own best team out of {all logical CPUs, 1/2, 1/4, 1/8} (`team_per_stage`; r03 chose
+    one team by the sweep alone and ran the expansion and the fold 2x slower than r02 with it): the all_core value is the
+    sum of the per-stage minima, `cores` the largest team any stage used."""
     import oracle
     max_threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
     N = 2048
-    # "every core" is not automatically the fastest team on an SMT host: the all-core mode is timed with the team size
-    # that a short scan over {all logical CPUs, half, a quarter} finds best for the sweep, and `cores` reports that size
-    scan = {}
-    threads = max_threads
+    cands = sorted({max(1, max_threads // d) for d in (8, 4, 2, 1)}) if max_threads >= 8 else [max_threads]
     rng = np.random.default_rng(5)
 
-    def rand_words(n):   # residues < 2^28 in both limbs (the MAC loops are data independent)
-        blk = min(n, 1 << 25)
-        block = rng.integers(0, 1 << 28, blk, dtype=np.uint64) * np.uint64((1 << 32) + 1) % np.uint64(1 << 60)
-        if blk == n:
-            return block
-        out = np.empty(n, dtype=np.uint64)   # a 256 MiB random block repeated: real memory traffic, quick to build
-        for i in range(0, n, blk):
-            out[i:i + blk] = block[:min(blk, n - i)]
-        return out
+    def scan(fn):
+        """fn(team) timed under every candidate team, ascending; stops once a larger team is 1.5x slower than the best
+        so far (256 threads are 40x slower than 128 on the sweep of a 2 x 64-core SMT host).  -> (best team, {team: s})"""
+        times, best = {}, None
+        for t in cands:
+            oracle.set_threads(t)
+            t0 = time.time()
+            fn(t)
+            times[t] = time.time() - t0
+            if best is None or times[t] < times[best]:
+                best = t
+            elif times[t] > 1.5 * times[best]:
+                break
+        return best, times
 
     def mem_available_gib():
         try:
@@ -144,19 +175,22 @@ def cpu_baseline(cfg_name, cfg):
         return 0.0
 
     def one(name, c, full):
-        nonlocal threads
         o = oracle.Params(c)
         cl = oracle.Client(o)
         pp = cl.generate_keys(11)
         q = cl.generate_query(12345 % o.num_items, 12)
         dim0, num_per, planes = o.dim0, o.num_per, o.instances * o.n * o.n
-        if max_threads >= 8:
-            oracle.set_threads(threads if scan else max(1, max_threads // 2))   # before the scan: one thread per physical core
-        v_reg, v_fold = o.expand_query(pp, q)       # (untimed: the inputs of the sweep; timed below with the chosen team)
-        # full: every z-row of every plane and the whole fold tree of every plane are executed (no scaling);
-        # sampled: nz rows of one plane / a subtree, scaled by row count, step count and planes
-        # sampled configurations: ONE WHOLE PLANE of the sweep is executed un-sampled in both modes when the host has the
-        # memory for it (16 GiB of words at C2), else 2^25 words' worth of z-rows
+        # ---- expansion (+ get_v_folding_neg), in full, per team
+        box = {}
+
+        def expand(_t):
+            box["v_reg"], box["v_fold"] = o.expand_query(pp, q)
+            box["v_neg"] = o.get_v_folding_neg(box["v_fold"])
+        team_e, scan_e = scan(expand)
+        t_expand = scan_e[team_e]
+        v_reg, v_fold, v_neg = box["v_reg"], box["v_fold"], box["v_neg"]
+        # ---- sweep.  full: every z-row of every plane (no scaling); sampled: ONE WHOLE PLANE un-sampled in both modes
+        # when the host has the memory for it (16 GiB of words at C2), else 2^25 words' worth of z-rows
         plane_gib = N * num_per * dim0 * 8 / 2**30
         whole_plane = (not full) and mem_available_gib() > 2.5 * plane_gib + 8
         nz = N if (full or whole_plane) else max(1, min(N, (1 << 25) // (num_per * dim0)))
@@ -169,69 +203,180 @@ def cpu_baseline(cfg_name, cfg):
             oracle.sweep_rows(dbs[:nz1 * num_per * dim0], v_reg[:nz1 * dim0 * 2], nz1, dim0, num_per)
         t_sweep_1 = (time.time() - t0) * (1 if full else (N / nz1) * planes)
         oracle.sweep_rows_avx2(dbs[:num_per * dim0], v_reg[:dim0 * 2], 1, dim0, num_per)   # thread-pool warm-up
-        if not scan and max_threads >= 8:
-            nzs = min(nz, max(8, (1 << 27) // (num_per * dim0)))   # ~1 GiB of words per trial
-            for t in sorted({max_threads, max(1, max_threads // 2), max(1, max_threads // 4)}):
-                oracle.set_threads(t)
-                oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
-                t0 = time.time()
-                oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
-                scan[t] = time.time() - t0
-            threads = min(scan, key=scan.get)
-            if threads != max_threads:      # re-place the pages for the team that will actually run
-                oracle.set_threads(threads)
-                dbs = oracle.words_first_touch(nz, num_per * dim0)
-        oracle.set_threads(threads)
+        nzs = min(nz, max(8, (1 << 27) // (num_per * dim0)))   # ~1 GiB of words per trial of the team scan
+
+        def sweep_trial(_t):
+            oracle.sweep_rows_avx2(dbs[:nzs * num_per * dim0], v_reg[:nzs * dim0 * 2], nzs, dim0, num_per)
+        sweep_trial(0)
+        team_s, scan_s = scan(sweep_trial)
+        oracle.set_threads(team_s)
+        if team_s != max_threads:      # re-place the pages for the team that will actually run
+            dbs = oracle.words_first_touch(nz, num_per * dim0)
         t0 = time.time()
         for _ in range(reps):
             oracle.sweep_rows_avx2(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
         t_sweep_all = (time.time() - t0) * (1 if full else (N / nz) * planes)
-        t0 = time.time()
-        v_reg, v_fold = o.expand_query(pp, q)
-        v_neg = o.get_v_folding_neg(v_fold)
-        t_expand = time.time() - t0
-        # fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
+        del dbs
+        # ---- fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
         k1 = o.db_dim_2 if full else min(o.db_dim_2, 5)
         ka = o.db_dim_2 if full else min(o.db_dim_2, 11)   # all-core: the whole tree of a plane (its serial top included)
         w = 2 * 2 * o.t_gsw * 2 * N
-        cts = np.concatenate([rng.integers(0, 249561089, (1 << ka) * 2 * 2 * N, dtype=np.uint64)])
+        cts = rng.integers(0, 249561089, (1 << ka) * 2 * 2 * N, dtype=np.uint64)
+        oracle.set_threads(1)
         t0 = time.time()
         for _ in range(reps):
             o.from_ntt_fold_parallel(cts[:(1 << k1) * 4 * N], v_fold[:k1 * w], v_neg[:k1 * w], nu=k1, classes=1)
         t_fold_1 = (time.time() - t0) * (1 if full else (num_per / (1 << k1)) * planes)
-        t0 = time.time()
-        for _ in range(reps):
-            o.from_ntt_fold_parallel(cts, v_fold[:ka * w], v_neg[:ka * w], nu=ka, classes=threads)
-        t_fold_all = (time.time() - t0) * (1 if full else (num_per / (1 << ka)) * planes)
+
+        def fold_all(t):
+            for _ in range(reps):
+                o.from_ntt_fold_parallel(cts, v_fold[:ka * w], v_neg[:ka * w], nu=ka, classes=t)
+        team_f, scan_f = scan(fold_all)
+        t_fold_all = scan_f[team_f] * (1 if full else (num_per / (1 << ka)) * planes)
+        oracle.set_threads(max_threads)
         if full:
             how = ("every z-row of all %d planes and the whole fold tree of every plane executed (random residues as "
                    "database words), nothing scaled; pack/encode omitted (<1%%)" % planes)
         else:
             how = ("sweep: %d of %d z-rows of one plane (AVX2, %d threads) / %d of them (scalar u128, 1 thread), x%d planes; "
                    "fold: %d-leaf subtree over %d threads / %d-leaf subtree on 1 thread, scaled to %d leaves x %d planes; "
-                   "expand_query + get_v_folding_neg in full; pack/encode omitted (<1%%)" %
-                   (nz, N, threads, nz1, planes, 1 << ka, threads, 1 << k1, num_per, planes))
+                   "expand_query + get_v_folding_neg in full (%d threads); pack/encode omitted (<1%%)" %
+                   (nz, N, team_s, nz1, planes, 1 << ka, team_f, 1 << k1, num_per, planes, team_e))
         return {"config": name, "sampled": not full,
                 "faithful_qps": 1.0 / (t_expand + t_sweep_1 + t_fold_1),
                 "all_core_qps": 1.0 / (t_expand + t_sweep_all + t_fold_all),
                 "seconds": {"expand": t_expand, "sweep_1thread": t_sweep_1, "fold_1thread": t_fold_1,
                             "sweep_all_core": t_sweep_all, "fold_all_core": t_fold_all},
+                "team_per_stage": {"expand": team_e, "sweep": team_s, "fold": team_f},
+                "team_scan_seconds": {"expand": {str(k): v for k, v in sorted(scan_e.items())},
+                                      "sweep_1GiB_trial": {str(k): v for k, v in sorted(scan_s.items())},
+                                      "fold": {str(k): v for k, v in sorted(scan_f.items())}},
                 "sample": how}
 
     main = one(cfg_name, cfg, full=False)
     extra = [one(k, CONFIGS[k], full=True) for k in ("c1", "p2")] if cfg_name not in ("c1", "p2", "fast") else []
     return {
-        "value": main["all_core_qps"], "unit": "queries/s", "cores": threads, "kind": "port",
+        "value": main["all_core_qps"], "unit": "queries/s", "cores": max(main["team_per_stage"].values()), "kind": "port",
         "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
-        "thread_scan_seconds": {str(k): v for k, v in sorted(scan.items())},
+        "team_per_stage": main["team_per_stage"], "team_scan_seconds": main["team_scan_seconds"],
         "modes": {"all_core": main["all_core_qps"], "faithful": main["faithful_qps"]},
         "seconds_per_query": main["seconds"],
-        "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = all_core mode (every core busy: AVX2 "
-                  "u64-lane sweep over z-rows as lib/server's dot_product.rs:59-95, fold subtrees in parallel); "
-                  "faithful mode = spiral-rs threading (sweep + fold on one thread per instance, server.rs:682-694). "
-                  "%s" % (cfg_name, main["sample"]),
+        "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = all_core mode (AVX2 u64-lane sweep over "
+                  "z-rows as lib/server's dot_product.rs:59-95, fold subtrees in parallel; each stage with the team size "
+                  "that is fastest for it, team_per_stage); faithful mode = spiral-rs threading (sweep + fold on one thread "
+                  "per instance, server.rs:682-694). %s" % (cfg_name, main["sample"]),
         "unsampled": extra,
     }
+
+
+def secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step):
+    """Measurements the driver's default run also records, on the database the headline just used (BASELINE configs[1]
+    resident): `sustained` (a long run of consecutive single queries: q/s of the first and of the last 100, GPU
+    telemetry before and after) and `batch8` (BASELINE configs[4] at one GPU: 8 queries per database pass)."""
+    out = {}
+    if args.sustained > 0:
+        n = args.sustained
+        tel0 = gpu_telemetry()
+        stamps = np.zeros(n + 1)
+        torch.cuda.synchronize()
+        stamps[0] = time.perf_counter()
+        for i in range(n):
+            step(i)                       # synchronous: returns the response bytes
+            stamps[i + 1] = time.perf_counter()
+        tel1 = gpu_telemetry()
+        k = max(1, min(100, n // 3))
+        dt = np.diff(stamps)
+        out["sustained"] = {
+            "queries": n, "value": n / (stamps[-1] - stamps[0]), "unit": "queries/s",
+            "first_%d_qps" % k: k / (stamps[k] - stamps[0]), "last_%d_qps" % k: k / (stamps[-1] - stamps[-1 - k]),
+            "ms_per_query_p50": float(np.median(dt) * 1e3), "ms_per_query_max": float(dt.max() * 1e3),
+            "seconds": float(stamps[-1] - stamps[0]),
+            "telemetry_before": tel0, "telemetry_after": tel1,
+            "note": "the headline's step repeated back to back, one query at a time, no pause; rocm-smi sampled outside "
+                    "the loop"}
+    if cfg["nu_2"] >= 7:
+        B, bsteps = 8, 5
+        qs8 = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(B)]
+        outs = sp.process_query_batch(p, pp, qs8, db)
+        single = [sp.process_query(p, pp, q, db) for q in qs8]
+        check = "ok" if outs == single else "MISMATCH"
+        if check != "ok":
+            print("bench: batched responses DIFFER from the single-query path", file=sys.stderr, flush=True)
+        for _ in range(2):
+            sp.process_query_batch(p, pp, qs8, db)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(bsteps):
+            sp.process_query_batch(p, pp, qs8, db)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        runs = [sp.QueryRun(p, pp, q, db=db) for q in qs8]
+        sp.paths_taken()
+        pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
+        taken = sp.paths_taken()
+        for r in runs:
+            r.free()
+        N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
+        pass_bytes = db.device_bytes() + B * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
+        out["batch8"] = {
+            "workload": "BASELINE configs[4] at one GPU: 8 queries per step sharing ONE database pass (sp_process_query_batch)",
+            "value": (B * bsteps / dt) if check == "ok" else None, "unit": "queries/s", "steps": bsteps,
+            "queries_per_step": B, "ms_per_step": dt * 1e3 / bsteps, "batch_selfcheck": check,
+            "batched_pass": {"kernel": "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<8>",
+                             "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
+                             "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+    return out
+
+
+def secondary_c4(sp, torch, args):
+    """BASELINE configs[3] (2^20 items x 32 KiB, 16 planes, 224 GiB resident) on a fresh synthetic fill: the caller has
+    released the headline's database.  5 timed single queries after 2 warm-up queries."""
+    cfg = CONFIGS["c4"]
+    free = torch.cuda.mem_get_info()[0]
+    if free < 236 * 2**30:
+        return {"skipped": "needs 236 GiB of free HBM, %.1f available" % (free / 2**30)}
+    p = sp.Params(cfg)
+    pp = sp.PublicParameters.deserialize(p, synthetic_wire_bytes(p.setup_bytes(), 1))
+    t0 = time.perf_counter()
+    db = sp.Database(p).fill_synthetic(SEED)
+    torch.cuda.synchronize()
+    fill_s = time.perf_counter() - t0
+    queries = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(4)]
+    steps, warm = 5, 2
+    planes = cfg["instances"] * cfg["n"] ** 2
+
+    def one(i):
+        run = sp.QueryRun(p, pp, queries[i % len(queries)], db=db)
+        run.sweep(db)
+        o = run.finish()
+        t = run.timings()
+        run.free()
+        return o, t
+    for i in range(warm):
+        one(i)
+    torch.cuda.synchronize()
+    stage = np.zeros(4)
+    t0 = time.perf_counter()
+    for i in range(steps):
+        _, t = one(i)
+        stage += np.array(t)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    launches = sp.lib().sp_sweep_launches(C.c_void_p(p.h), C.c_void_p(db.h))
+    moved = sweep_moved_bytes(cfg, 1, db.device_bytes()) / launches
+    in_situ_ms = stage[1] / steps / launches
+    res = {"workload": "BASELINE configs[3]: spiral-rs process_query on 2^20 items x 32 KiB (%d planes), %.1f GiB resident, "
+                       "one query per step" % (planes, db.device_bytes() / 2**30),
+           "value": steps / dt, "unit": "queries/s", "steps": steps, "warmup": warm, "ms_per_step": dt * 1e3 / steps,
+           "stage_ms": {"expand": stage[0] / steps, "sweep": stage[1] / steps, "fold": stage[2] / steps,
+                        "pack_encode": stage[3] / steps},
+           "roofline": {"bound": "hbm", "launches_per_query": launches, "bytes_per_launch": moved, "ms_per_launch": in_situ_ms,
+                        "achieved": moved / (in_situ_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                        "frac": moved / (in_situ_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+           "fill_seconds": fill_s}
+    del db, pp, p
+    return res
 
 
 def main():
@@ -251,9 +396,21 @@ def main():
     ap.add_argument("--batch", type=int, default=0,
                     help="queries per step per GPU (single-GPU and replicas modes): groups of <= 8 queries share one "
                          "database pass (sp_process_query_batch).  Default 1 (single) / 8 (replicas).")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the headline timed region + roofline (no `secondary` objects: batch8 / sustained / c4); "
+                         "what the profiling scripts use so that kernel statistics hold the headline's launches only")
+    ap.add_argument("--sustained", type=int, default=300, help="queries of the `secondary.sustained` run (0 = skip)")
+    ap.add_argument("--via-torchrun", action="store_true",
+                    help="re-exec under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does on its own when "
+                         "no launcher set WORLD_SIZE)")
     args = ap.parse_args()
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on these hosts (RCCL needs it)
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or args.via_torchrun):
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU) instead of exiting
+        cmd = torchrun_command(args.gpus, [a for a in sys.argv[1:] if a != "--via-torchrun"])
+        print("bench: no WORLD_SIZE in the environment, re-executing as: %s" % " ".join(cmd), file=sys.stderr, flush=True)
+        os.execv(cmd[0], cmd)
     try:   # cpu_baseline: every CPU this process may run on
         n_cpus = len(os.sched_getaffinity(0))
     except (AttributeError, OSError):
@@ -269,8 +426,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     if sp.lib().sp_set_device(local_rank) != 0:
         raise SystemExit("sp_set_device failed")
@@ -561,6 +717,25 @@ def main():
             line["roofline"]["batched_pass"] = batch_pass
         if in_flight is not None:
             line["two_in_flight"] = in_flight
+        if mode == "single" and batch == 1 and world == 1 and not args.headline_only:
+            # after the headline (whose timed region and roofline are complete above): the BASELINE configs only the
+            # builder had timed so far, now in the line the driver records.  A failure here never takes the headline down.
+            secondary = {}
+            try:
+                secondary.update(secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step))
+            except Exception as e:
+                secondary["error_same_db"] = repr(e)[:300]
+            if args.config == "c2":
+                try:
+                    import gc
+                    run = None                 # (a freed QueryRun still references its Params / PublicParameters)
+                    del db, pp, p
+                    gc.collect()
+                    torch.cuda.synchronize()
+                    secondary["c4"] = secondary_c4(sp, torch, args)
+                except Exception as e:
+                    secondary["c4"] = {"error": repr(e)[:300]}
+            line["secondary"] = secondary
         if mode == "single" and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.config, cfg)
         else:

@@ -102,6 +102,33 @@ def test_c2_full_size_response_bytes(sp, oracle_mod):
     # is checked on the planted-item database (test_c2_full_size_decodes_planted_items in test_gpu_parity.py)
 
 
+def test_c2_batch8_matrix_core_pass_at_full_size(sp, oracle_mod):
+    """BASELINE.json configs[4] at one GPU, full size: EIGHT queries share one database pass, which from four queries
+    on runs on the matrix cores (k_sweep_mfma_batch, v_mfma_i32_16x16x64_i8) -- the batch of two in the test above is below
+    batch_mfma_min and takes the vector kernel.  First and last response of the group byte for byte against the oracle
+    (lib/server/src/bin/server.rs:152-158: the per-request loop over process_query), the six in between against the
+    one-at-a-time path that the test above ties to the oracle."""
+    _need_hbm(96)
+    o, cl, pp = _client(oracle_mod, C2, 501)
+    p = sp.Params(C2)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    db = sp.Database(p).fill_synthetic(SEED)
+    idxs = (5, 1 << 19, 777777, 123456, o.num_items - 1, 0, 999999, 31337)
+    queries = [cl.generate_query(idx, 950 + k) for k, idx in enumerate(idxs)]
+    sp.paths_taken()
+    outs = sp.process_query_batch(p, gpp, queries, db)
+    taken = sp.paths_taken()
+    assert {"sweep_batch", "sweep_batch_mfma"} <= taken, taken
+    for k in (0, 7):
+        want = o.process_query_synth(pp, queries[k], SEED)
+        assert outs[k] == want, "query %d of the batched pass differs from the oracle (sha %s vs %s)" % (
+            k, hashlib.sha256(outs[k]).hexdigest()[:16], hashlib.sha256(want).hexdigest()[:16])
+    for k in range(1, 7):
+        assert outs[k] == sp.process_query(p, gpp, queries[k], db), k
+    del db
+    gc.collect()
+
+
 def test_c2_fold_thresholds_agree_at_full_size(sp, oracle_mod, monkeypatch):
     """The two extremes of the fold dispatch produce the oracle's bytes at full size as well: every level through the
     fused kernel (threshold 1), and no level through it (threshold 2048 > the 1024 pairs of a plane's first level:
