@@ -658,8 +658,8 @@ def main():
         npairs_local = (1 << cfg["nu_1"]) // (2 * (world if sharded and mode != "columns" else 1))
         ring_u = next((u for u in (8, 4, 2) if npairs_local % (2 * u) == 0), 0)
         kernel = ("k_sweep_packed_ring<%d>" % ring_u if "sweep_ring" in sweep_paths else
-                  "k_sweep_packed_persist<4>" if "sweep_packed_persist" in sweep_paths else
-                  "k_sweep_packed" if cfg["nu_2"] >= 7 else "k_sweep_narrow2")
+                  "k_sweep_packed_persist" if "sweep_packed_persist" in sweep_paths else
+                  "k_sweep_wide" if cfg["nu_2"] >= 7 else "k_sweep_narrow2")
         workload_how = {
             "single": "unsharded, one query per step" if batch == 1 else "unsharded, %d queries per step (<= 8 per database pass)" % batch,
             "replicas": "whole database on each of the %d GPUs, %d queries per GPU per step (one database pass), no collective in the timed region (BASELINE configs[4])" % (world, batch),

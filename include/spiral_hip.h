@@ -330,13 +330,13 @@ int sp_from_ntt(const sp_params_t*, const uint64_t* ntt, uint64_t* out, size_t c
 /* poly.rs:437-458 multiply: res[ar x bc] = a[ar x ac] * b[ac x bc] (NTT form) */
 int sp_multiply(const sp_params_t*, const uint64_t* a, size_t ar, size_t ac, const uint64_t* b, size_t bc,
                 uint64_t* res);
-/* poly.rs:539-551 automorph on `count` raw polys (x -> x^t, sign flip Q - a, Q for a == 0) */
 /* poly.rs:483-498 add, :500-512 add_into, :575-588 scalar_multiply over `count` NTT polynomials (2 * 2048 words each;
  * `scalar` is one polynomial): res = a + b; res += a; res = scalar * b, all pointwise mod the two primes.  The reference's
  * add does not re-reduce a sum below 2 q of canonical inputs differently from these: inputs are reduced mod q first. */
 int sp_add(const sp_params_t*, const uint64_t* a, const uint64_t* b, size_t count, uint64_t* res);
 int sp_add_into(const sp_params_t*, uint64_t* res, const uint64_t* a, size_t count);
 int sp_scalar_multiply(const sp_params_t*, const uint64_t* scalar, const uint64_t* b, size_t count, uint64_t* res);
+/* poly.rs:539-551 automorph on `count` raw polys (x -> x^t, sign flip Q - a, Q for a == 0) */
 int sp_automorph(const sp_params_t*, const uint64_t* a, size_t count, size_t t, uint64_t* res);
 /* gadget.rs:34-60 gadget_invert_rdim followed by to_ntt_no_reduce is what the pipeline uses; this
  * export returns the raw digits: inp[rows_in x cols] -> out[rows_out x cols] */

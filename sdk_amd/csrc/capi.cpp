@@ -10,30 +10,52 @@
 using namespace spiral;
 
 static thread_local std::string g_last_error;
+static thread_local int g_last_rc = SP_OK;  // status of this thread's last guarded() section: what a constructor-style entry
+                                             // point (returns a handle or null) failed with
 
 template <typename F>
 static int guarded(F&& f) {
   tunables_new_call();
+  auto fail = [](int rc, const char* what) {
+    g_last_error = what;
+    g_last_rc = rc;
+    return rc;
+  };
   try {
     f();
+    g_last_rc = SP_OK;
     return SP_OK;
   } catch (const ArgError& e) {
-    g_last_error = e.what();
-    return SP_E_ARG;
+    return fail(SP_E_ARG, e.what());
   } catch (const OomError& e) {
-    g_last_error = e.what();
-    return SP_E_OOM;
+    return fail(SP_E_OOM, e.what());
   } catch (const HipError& e) {
-    g_last_error = e.what();
-    return SP_E_HIP;
+    return fail(SP_E_HIP, e.what());
   } catch (const std::bad_alloc&) {
-    g_last_error = "host allocation failed";
-    return SP_E_OOM;
+    return fail(SP_E_OOM, "host allocation failed");
   } catch (const std::exception& e) {
-    g_last_error = e.what();
-    return SP_E_ARG;
+    return fail(SP_E_ARG, e.what());
   }
 }
+// a pair of timing events that cannot leak
+struct TimingEvents {
+  hipEvent_t a = nullptr, b = nullptr;
+  TimingEvents() {
+    HIP_CHECK(hipEventCreate(&a));
+    if (hipEventCreate(&b) != hipSuccess) {
+      (void)hipEventDestroy(a);
+      throw HipError("hipEventCreate failed");
+    }
+  }
+  ~TimingEvents() {
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+  }
+  TimingEvents(const TimingEvents&) = delete;
+  TimingEvents& operator=(const TimingEvents&) = delete;
+};
+// status to report when a handle-returning entry point came back null
+static int null_handle_rc() { return g_last_rc != SP_OK ? g_last_rc : SP_E_ARG; }
 
 struct sp_query {
   sp_params* params = nullptr;
@@ -50,8 +72,6 @@ struct sp_query {
     if (ws && params) {
       (void)hipStreamSynchronize(ws->stream);
       (void)hipStreamSynchronize(ws->stream2);
-      if (ws->s_sweep) (void)hipStreamSynchronize(ws->s_sweep);
-      if (ws->s_fold) (void)hipStreamSynchronize(ws->s_fold);
       ws->pipelined = false;
       ws->have_sweep_span = false;
       ws->zero_shortcuts = false;
@@ -273,40 +293,9 @@ static sp_db_t* db_create_impl(const sp_params_t* h, int shard, int num_shards, 
     // scripts/ubench/contig_repro.hip modes 4-6, profiles/r03_contiguous_alloc.md) -- the next handle's uploads vanish.
     const size_t db_words = (db_bytes((int)p.planes(), d->np_local, d->nj, d->packed) + 7) / 8;
     d->words.alloc_streaming(db_words, tunable("db_contiguous", 0) != 0);
-    // Placement lottery: how a multi-GiB hipMalloc happens to be backed moves the sweep by up to
-    // 9 % (2.19 .. 2.40 ms per C2 plane, same binary).  db_place_tries = n > 1 (default 1 = off; PACKED databases of
-    // at least 4 GiB, and only while a second copy fits in free memory): time the sweep's read pattern on up to n
-    // fresh plain allocations and keep the fastest; the others are freed again.  Plain hipMalloc / hipFree only.
-    // Measured (profiles/r03_placement.md): the candidates of one process differ by ~1 %, the spread is between
-    // processes / machines -- best-of-n buys nothing, so it is off.
-    const long tries = tunable("db_place_tries", 1);
-    if (d->packed && tries > 1 && d->words.bytes() >= ((size_t)4 << 30) && tunable("db_contiguous", 0) == 0) {
-      DevBuf<u32> sink(16);
-      float best = stream_probe_ms(d->words.p, d->words.bytes(), sink.p, 0);
-      const float first = best;
-      int kept = 0, made = 1;
-      for (long t = 1; t < tries && best > 0.f; t++) {
-        size_t fr = 0, tot = 0;
-        HIP_CHECK(hipMemGetInfo(&fr, &tot));
-        if (fr < d->words.bytes() + ((size_t)8 << 30)) break;
-        DevBuf<u64> cand;
-        try {
-          cand.alloc(db_words);
-        } catch (const OomError&) {
-          break;
-        }
-        made++;
-        const float ms = stream_probe_ms(cand.p, cand.bytes(), sink.p, 0);
-        if (ms > 0.f && ms < best) {
-          best = ms;
-          kept = (int)t;
-          std::swap(d->words, cand);   // `cand` now owns the slower buffer and frees it at the end of this iteration
-        }
-      }
-      if (getenv("SPIRAL_ALLOC_DEBUG"))
-        fprintf(stderr, "[spiral] database placement: %d candidates, first %.3f ms, kept #%d at %.3f ms per %.1f GiB pass\n", made, first, kept, best,
-                d->words.bytes() / 1073741824.0);
-    }
+    // (How a multi-GiB hipMalloc happens to be backed moves the sweep by up to 9 % between processes; timing the read pattern on
+    // several fresh allocations and keeping the fastest was tried in round 3 -- the candidates of ONE process differ by ~1 % --
+    // and removed: profiles/r03_placement.md.)
     HIP_CHECK(hipMemset(d->words.p, 0, d->words.bytes()));  // an empty bucket: absent items are zero polynomials
     const_cast<sp_params*>(h)->device_state();
     out = d.release();
@@ -845,8 +834,6 @@ int sp_query_sync(sp_query_t* q) {
     need(q && q->ws, "null query");
     HIP_CHECK(hipStreamSynchronize(q->ws->stream));
     HIP_CHECK(hipStreamSynchronize(q->ws->stream2));
-    if (q->ws->s_sweep) HIP_CHECK(hipStreamSynchronize(q->ws->s_sweep));
-    if (q->ws->s_fold) HIP_CHECK(hipStreamSynchronize(q->ws->s_fold));
   });
 }
 
@@ -905,7 +892,7 @@ int sp_process_query(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* que
     return SP_E_ARG;
   }
   sp_query_t* q = sp_query_begin_for_db(h, pp, query, query_len, db);  // (sparse: pruned expansion; wide: split expansion)
-  if (!q) return g_last_error.find("hip") != std::string::npos ? SP_E_HIP : SP_E_ARG;
+  if (!q) return null_handle_rc();
   int rc = sp_query_sweep(q, db);
   if (rc == SP_OK) rc = guarded([&] { finish_impl(q, false, out, out_cap, out_len); });
   sp_query_free(q);
@@ -920,6 +907,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     return SP_E_ARG;
   }
   const Params& p = h->p;
+  tunables_new_call();  // the switches below are read before the first guarded() section of this call
   const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !tunable("no_batch_sweep", 0);
   if (!batched) {
     // 8-byte / narrow databases: one pass per query, up to `batch_in_flight` (default 3, at most 4; 1 = one at a time)
@@ -930,7 +918,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       g_last_error = "sp_process_query_batch needs an unsharded db";
       return SP_E_ARG;
     }
-    const size_t depth = (size_t)std::max(1L, std::min(4L, tunable("batch_in_flight", 3)));
+    size_t depth = (size_t)std::max(1L, std::min(4L, tunable("batch_in_flight", 3)));
     std::deque<std::pair<sp_query_t*, int>> flying;  // oldest first
     int rc = SP_OK;
     auto finish_oldest = [&]() -> int {
@@ -943,8 +931,16 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     };
     for (int i = 0; i < batch && rc == SP_OK; i++) {
       sp_query_t* q = sp_query_begin_for_db(h, pps[i], queries[i], query_lens[i], db);
+      if (!q && g_last_rc == SP_E_OOM && !flying.empty()) {
+        // no memory for one more workspace (sweep_out + fold buffers, up to ~2 GiB) beside the database and the queries in
+        // flight: finish those -- their workspaces return to the pool -- and go on one query at a time
+        while (rc == SP_OK && !flying.empty()) rc = finish_oldest();
+        if (rc != SP_OK) break;
+        depth = 1;
+        q = sp_query_begin_for_db(h, pps[i], queries[i], query_lens[i], db);
+      }
       if (!q) {
-        rc = g_last_error.find("hip") != std::string::npos ? SP_E_HIP : SP_E_ARG;
+        rc = null_handle_rc();
         break;
       }
       rc = sp_query_sweep(q, db);
@@ -1030,28 +1026,9 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         d.rq = W0.batch_rq.p;
       }
       sweep_batch_prepare(W0.D->T, d, W0.stream);
-      // SPIRAL_BATCH_PIPELINE=1 (off by default): the pass runs one (instance, trial) plane per launch and every query
-      // folds plane p on its second stream while plane p+1 is swept -- the single-query pipeline with B folds per
-      // plane.  Measured at C2, B = 8: 199 vs 198-227 queries/s for the one-launch pass -- the batched sweep's 188
-      // VGPRs + 64 KiB LDS leave no room for fold workgroups on a CU, so nothing overlaps
-      // (profiles/r02_fold_batch_experiments.md).
-      const bool per_plane = p.planes() > 1 && p.num_per() >= 1024 && tunable("batch_pipeline", 0) != 0;
-      if (per_plane) {
-        const size_t plane_db_words = db_bytes(1, db->np_local, db->nj, db->packed) / 8;
-        const size_t plane_out = (size_t)4 * POLY_LEN * db->np_local;
-        for (size_t pl = 0; pl < p.planes(); pl++) {
-          SweepBatchDesc dp = d;
-          dp.planes = 1;
-          dp.db = db->words.p + pl * plane_db_words;
-          for (int i = 0; i < B; i++) dp.out[i] = qs[i]->ws->sweep_out.p + pl * plane_out;
-          launch_sweep_batch(W0.D->T, dp, W0.stream);
-          HIP_CHECK(hipEventRecord(W0.ev_plane[pl], W0.stream));
-          for (int i = 0; i < B; i++) run_fold_plane_overlapped(*qs[i]->ws, pl, W0.ev_plane[pl]);
-        }
-        note_path(PATH_PIPELINED);
-      } else {
-        launch_sweep_batch(W0.D->T, d, W0.stream);
-      }
+      // (a per-plane form of the pass with every query folding plane p beside the pass of plane p + 1 was measured in rounds
+      // 2 and 3 and is slower: the pass leaves no registers for a fold workgroup; profiles/r02_fold_batch_experiments.md)
+      launch_sweep_batch(W0.D->T, d, W0.stream);
       HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
       prev_pass = W0.ev[2];
       // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
@@ -1084,34 +1061,24 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
     need(q->state >= 1, "query not begun");
     check_device(db->device);
     Workspace& W = *q->ws;
-    hipEvent_t a, b;
-    HIP_CHECK(hipEventCreate(&a));
-    HIP_CHECK(hipEventCreate(&b));
+    TimingEvents ev;
     // the same launches process_query issues for this database (one per plane when the sweep is pipelined)
     const Params& p = q->params->p;
     const bool per_plane = per_plane_launches < 0 ? sweep_is_pipelined(p, *db) : per_plane_launches != 0;
     need(!per_plane || db->col_G == 1, "per-plane launches need a row-sharded or unsharded db");
-    // the same launches the pipelined query issues (the last plane may be swept as two chunk-parity classes)
-    const auto plan = per_plane_launches < 0 && per_plane ? pipelined_sweep_launches(p, *db) : std::vector<std::pair<size_t, int>>();
     auto sweep_once = [&] {
       if (!per_plane) return run_sweep(W, *db);
       W.ensure_sweep();
-      if (!plan.empty()) {
-        for (const auto& l : plan) launch_plane_sweep(W, *db, l.first, l.second);
-        return;
-      }
       for (size_t pl = 0; pl < p.planes(); pl++) launch_plane_sweep(W, *db, pl);
     };
     sweep_once();  // warm
-    HIP_CHECK(hipEventRecord(a, W.stream));
+    HIP_CHECK(hipEventRecord(ev.a, W.stream));
     for (int i = 0; i < iters; i++) sweep_once();
-    HIP_CHECK(hipEventRecord(b, W.stream));
+    HIP_CHECK(hipEventRecord(ev.b, W.stream));
     HIP_CHECK(hipStreamSynchronize(W.stream));
     float t = 0;
-    HIP_CHECK(hipEventElapsedTime(&t, a, b));
-    *ms_per_launch = t / ((float)iters * (per_plane ? (float)(plan.empty() ? p.planes() : plan.size()) : 1.0f));
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
+    HIP_CHECK(hipEventElapsedTime(&t, ev.a, ev.b));
+    *ms_per_launch = t / ((float)iters * (per_plane ? (float)p.planes() : 1.0f));
   });
 }
 
@@ -1120,7 +1087,10 @@ int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, in
     need(qs && db && ms_per_pass && iters > 0 && batch >= 1 && batch <= SWEEP_BATCH_MAX, "bad argument");
     need(db->packed && db->num_shards == 1 && db->col_G == 1, "the batched pass needs an unsharded PACKED database");
     check_device(db->device);
-    for (int i = 0; i < batch; i++) need(qs[i] && qs[i]->state >= 1, "query not begun");
+    for (int i = 0; i < batch; i++) {
+      need(qs[i] && qs[i]->state >= 1, "query not begun");
+      need(qs[i]->params == db->params, "query and db were created for different params");
+    }
     const Params& p = qs[0]->params->p;
     Workspace& W0 = *qs[0]->ws;
     SweepBatchDesc d{};
@@ -1142,29 +1112,25 @@ int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, in
       W0.batch_rq.ensure(sweep_batch_rq_words(d.nj));
       d.rq = W0.batch_rq.p;
     }
-    hipEvent_t a, b;
-    HIP_CHECK(hipEventCreate(&a));
-    HIP_CHECK(hipEventCreate(&b));
+    TimingEvents ev;   // destroyed on every path out of here (launches and HIP_CHECK throw)
     auto pass = [&] {
       sweep_batch_prepare(W0.D->T, d, W0.stream);
       launch_sweep_batch(W0.D->T, d, W0.stream);
     };
     pass();  // warm
-    HIP_CHECK(hipEventRecord(a, W0.stream));
+    HIP_CHECK(hipEventRecord(ev.a, W0.stream));
     for (int i = 0; i < iters; i++) pass();
-    HIP_CHECK(hipEventRecord(b, W0.stream));
+    HIP_CHECK(hipEventRecord(ev.b, W0.stream));
     HIP_CHECK(hipStreamSynchronize(W0.stream));
     float t = 0;
-    HIP_CHECK(hipEventElapsedTime(&t, a, b));
+    HIP_CHECK(hipEventElapsedTime(&t, ev.a, ev.b));
     *ms_per_pass = t / (float)iters;
-    (void)hipEventDestroy(a);
-    (void)hipEventDestroy(b);
   });
 }
 
 int sp_sweep_launches(const sp_params_t* h, const sp_db_t* db) {
   if (!h || !db) return 0;
-  return sweep_is_pipelined(h->p, *db) ? (int)pipelined_sweep_launches(h->p, *db).size() : 1;
+  return sweep_is_pipelined(h->p, *db) ? (int)h->p.planes() : 1;
 }
 
 // Placement probe: launches `blocks` small workgroups on a stream whose CU mask has bits [bit_lo, bit_hi) set (the

@@ -192,6 +192,7 @@ static void comm_reserve(sp_comm_t* c, const sp_params_t* h) {
   const size_t planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
   const size_t num_per = (size_t)1 << sp_params_get(h, "db_dim_2");
   if ((size_t)G > num_per) throw Fail{SP_E_ARG, "more ranks than second-dimension columns (num_per): use fewer shards"};
+  if (num_per % (size_t)G != 0) throw Fail{SP_E_ARG, "num_per is not a multiple of the number of ranks: the column chunks of the exchange would be ragged"};
   const size_t chunk = 4 * (size_t)sp_params_get(h, "poly_len") * num_per / (size_t)G;   // u32 [r][crt][z][ii / G] of one plane
   const size_t local_words = planes * 2 * (size_t)sp_params_get(h, "poly_len");         // one raw ciphertext per plane
   c->ensure(c->mine, c->mine_bytes, planes * chunk * sizeof(uint32_t));
@@ -234,6 +235,11 @@ void sharded_sweeps(sp_comm_t* c, const sp_db_t* shard, ShardedRun& r, bool time
   uint32_t* part = (uint32_t*)sp_query_partial_ptr(r.q);
   if (!part) throw Fail{SP_E_OOM, std::string("partial buffer: ") + sp_last_error()};
   const size_t words = sp_query_partial_words(r.q), pw = words / r.planes, chunk = pw / (size_t)G;
+  // comm_reserve sized `mine` / `gathered` from the parameters alone; this is the partial layout the query really produced.
+  // A disagreement (a future output layout, a column shard) must fail here, not write past `mine`.
+  if (words % r.planes != 0 || pw % (size_t)G != 0 || r.planes * chunk * sizeof(uint32_t) > c->mine_bytes ||
+      (size_t)G * r.local_words * sizeof(uint64_t) > c->gathered_bytes)
+    throw Fail{SP_E_ARG, "internal: the query's partial buffer does not match the reserved exchange buffers"};
   if (timed) hip_ok(hipEventRecord(c->ev_t[0], r.main), "hipEventRecord");
   for (size_t pl = 0; pl < r.planes; pl++) {
     sp_ok(sp_query_sweep_scatter_plane(r.q, shard, G, (int)pl), "sp_query_sweep_scatter_plane");

@@ -33,12 +33,11 @@ __device__ __forceinline__ bool fold_zero_shortcut(const u64* ct0, const u64* ct
   return true;
 }
 
-template <bool HOIST_TW>
 __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) {
   __shared__ u32 lds0[LDS_WORDS];
   __shared__ u32 lds1[LDS_WORDS];
   const int tau = threadIdx.x;
-  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
+  const int i = (int)blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -78,10 +77,9 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
         }
         const u32* fwk = fw;
         int tk = tau;
-        if (!HOIST_TW) {  // keep twiddle loads and LDS address arithmetic inside the loop (fewer live VGPRs)
-          asm volatile("" : "+s"(fwk));
-          asm volatile("" : "+v"(tk));
-        }
+        // keep twiddle loads and LDS address arithmetic inside the loop (fewer live VGPRs)
+        asm volatile("" : "+s"(fwk));
+        asm volatile("" : "+v"(tk));
         ntt_fwd_block(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
         {
           u32* tmp = la;
@@ -136,16 +134,15 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
 }
 // k_fold_fused with two digit transforms in flight per thread (shared twiddles / addresses / barriers).
 // Requires an even digit count t.
-// TW_LDS: the forward twiddles + Shoup quotients of the current modulus (16 KiB) are staged in LDS once per
-// modulus, so the 4 x 14 twiddle reads of every digit transform are ds_reads (no vector-memory latency, and no
-// queueing behind a concurrent sweep's load stream when the fold runs on the second stream).
-template <bool TW_LDS>
+// The forward twiddles + Shoup quotients of the current modulus (16 KiB) are staged in LDS once per modulus, so the
+// 4 x 14 twiddle reads of every digit transform are ds_reads (no vector-memory latency, and no queueing behind a
+// concurrent sweep's load stream when the fold runs on the second stream).
 __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d) {
   __shared__ u32 lds0[2 * LDS_WORDS];
   __shared__ u32 lds1[2 * LDS_WORDS];
-  __shared__ u32 ltw[TW_LDS ? 2 * N : 4];
+  __shared__ u32 ltw[2 * N];
   const int tau = threadIdx.x;
-  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
+  const int i = (int)blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -158,13 +155,11 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
     const u32* fw = T.tw + (size_t)c * 4 * N;
-    if (TW_LDS) {
-      if (c == 1) __syncthreads();
+    if (c == 1) __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 4; k++)  // [fw | fwp] = 2N words
-        reinterpret_cast<uint4*>(ltw)[tau + 256 * k] = reinterpret_cast<const uint4*>(fw)[tau + 256 * k];
-      __syncthreads();
-    }
+    for (int k = 0; k < 4; k++)  // [fw | fwp] = 2N words
+      reinterpret_cast<uint4*>(ltw)[tau + 256 * k] = reinterpret_cast<const uint4*>(fw)[tau + 256 * k];
+    __syncthreads();
     u64 acc0[8], acc1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
@@ -193,14 +188,9 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
             v[mm][k] = d1 >= d0 ? d1 - d0 : d1 + m.q - d0;
           }
         }
-        const u32* fwk = fw;
         int tk = tau;
-        asm volatile("" : "+s"(fwk));
         asm volatile("" : "+v"(tk));
-        if (TW_LDS)
-          ntt_fwd_block_m<2>(v, tk, la, lb, ltw, ltw + N, m.q, m.two_q);
-        else
-          ntt_fwd_block_m<2>(v, tk, la, lb, fwk, fwk + N, m.q, m.two_q);
+        ntt_fwd_block_m<2>(v, tk, la, lb, ltw, ltw + N, m.q, m.two_q);
         {
           u32* tmp = la;
           la = lb;
@@ -315,7 +305,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
   constexpr int E = 16 / ES;                // digit differences per 16-byte vector
   const int tau = threadIdx.x, lane = tau & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index and row pointers stay scalar
-  const int i = fold_step_of_block(d, blockIdx.x), plane = blockIdx.y;
+  const int i = (int)blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
@@ -507,10 +497,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
           e = e >= q1 ? e - q1 : e;
           const u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
           const u64 res = val >= T.c.Q ? val - T.c.Q : val;
-          if (d.nt_store)
-            __builtin_nontemporal_store(res, orow + zi);
-          else
-            orow[zi] = res;
+          orow[zi] = res;
         }
       }
     }
@@ -533,12 +520,15 @@ void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s
 
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
+  // fold_variant: 5 (default) = k_fold_wave where two workgroups fit a CU's LDS, else the cooperative kernels;
+  // 3 = k_fold_fused2 (two cooperative transforms in flight, even t_gsw); 0 = k_fold_fused (one)
   const int variant = (int)tunable("fold_variant", FOLD_VARIANT_DEFAULT);
+  const dim3 grid(d.half, d.planes), block(256);
   if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)
     const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
     const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
     if (lds <= 80 * 1024) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
-      const dim3 grid(d.cls_on ? d.half / 2 : d.half, d.planes), block(256);  // > 64 KiB of dynamic LDS needs no opt-in on gfx950 (scripts/ubench/dyn_lds.hip)
+      // (> 64 KiB of dynamic LDS needs no opt-in on gfx950, scripts/ubench/dyn_lds.hip)
       if (es == 1)
         hipLaunchKernelGGL(k_fold_wave<1>, grid, block, lds, s, T, d, d.mats_w);
       else if (es == 2)
@@ -549,107 +539,11 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
       return;
     }
   }
-  if ((variant == 3 || variant == 5) && (d.t % 2) == 0)
-    hipLaunchKernelGGL(k_fold_fused2<true>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
-  else if (variant == 2 && (d.t % 2) == 0)
-    hipLaunchKernelGGL(k_fold_fused2<false>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
-  else if (variant == 1)
-    hipLaunchKernelGGL(k_fold_fused<true>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
+  if (variant != 0 && (d.t % 2) == 0)
+    hipLaunchKernelGGL(k_fold_fused2, grid, block, 0, s, T, d);
   else
-    hipLaunchKernelGGL(k_fold_fused<false>, dim3(d.cls_on ? d.half / 2 : d.half, d.planes), dim3(256), 0, s, T, d);
+    hipLaunchKernelGGL(k_fold_fused, grid, block, 0, s, T, d);
   launched(PATH_FOLD_FUSED, "k_fold_fused");
-}
-
-// ------------------------------------------------------------------------------------------------
-// from_ntt of the sweep-native buffer on the wave-per-transform NTT (r03): four adjacent columns per workgroup as in
-// k_from_sweep4 (the 16-byte strided loads share sectors), but each WAVE inverse-transforms one column's polynomial on
-// its own -- no workgroup barrier inside a transform.  Per modulus the four columns are staged in LDS ([col][z], z padded
-// by 4 words per 32: conflict-free b128 reads of 32 consecutive values per lane), wave w picks up column w, transforms,
-// keeps modulus 0's result in registers, Garner after modulus 1, stores the raw polynomial in coalesced 512-byte rows.
-// Measured (profiles/r03_switch_ab.md): exactly as fast as k_from_sweep4 (0.36-0.38 ms for the 4 planes of a C2 query
-// stand-alone) -- the stage is bound by neither the transforms nor the strided reads; kept as the switch from_sweep_wave.
-// grid (np/4 * 2 * planes), flags / cls as k_from_sweep4.
-// ------------------------------------------------------------------------------------------------
-constexpr int FSW_COL_WORDS = N + N / 8;  // 2048 values + 4 pad words per 32
-__global__ __launch_bounds__(256, 2) void k_from_sweep_wave(DevTables T, const u32* src, int np, int premod, u64* dst, int flags,
-                                                            int cls) {
-  __shared__ __attribute__((aligned(16))) u32 col[4 * FSW_COL_WORDS];
-  __shared__ __attribute__((aligned(16))) u32 wbuf[4 * WBUF_WORDS];
-  const int tau = threadIdx.x, lane = tau & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);
-  int g = blockIdx.x;  // (plane, r, ii/4), XCD-aware order as in k_from_sweep4
-  const bool nt = (flags & 2) != 0;
-  if (flags & 1) {
-    const int xcd = g & 7, t = g >> 3;
-    g = ((t >> 3) * 8 + xcd) * 8 + (t & 7);
-  }
-  const int gpr = cls >= 0 ? np / 8 : np / 4;
-  const int groups_per_plane = gpr * 2;
-  const int plane = g / groups_per_plane, rem = g % groups_per_plane;
-  const int r = rem / gpr, gl = rem % gpr;
-  const int ii0 = cls >= 0 ? ((gl >> 5) * 2 + cls) * 128 + (gl & 31) * 4 : gl * 4;
-  const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
-  u32 res0[32];
-#pragma unroll 1
-  for (int c = 0; c < 2; c++) {
-    const ModConst m = T.c.mod[c];
-    const u32* sp = src + base + (size_t)c * N * np;
-    uint4 x[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) x[k] = *reinterpret_cast<const uint4*>(sp + (size_t)(tau + 256 * k) * np);
-    if (c == 1) __syncthreads();  // every wave has read its modulus-0 column out of the staging area
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      const int z = tau + 256 * k, zi = z + (z >> 5) * 4;
-      uint4 y = x[k];
-      if (premod) {
-        y.x %= m.q; y.y %= m.q; y.z %= m.q; y.w %= m.q;
-      }
-      col[0 * FSW_COL_WORDS + zi] = y.x;
-      col[1 * FSW_COL_WORDS + zi] = y.y;
-      col[2 * FSW_COL_WORDS + zi] = y.z;
-      col[3 * FSW_COL_WORDS + zi] = y.w;
-    }
-    __syncthreads();
-    u32 v[32];
-    const u32x4w_t* cp = reinterpret_cast<const u32x4w_t*>(col + wv * FSW_COL_WORDS + 36 * lane);
-#pragma unroll
-    for (int q4 = 0; q4 < 8; q4++) {
-      const u32x4w_t t4 = cp[q4];
-      v[4 * q4] = t4.x; v[4 * q4 + 1] = t4.y; v[4 * q4 + 2] = t4.z; v[4 * q4 + 3] = t4.w;
-    }
-    wntt_inv(v, lane, wbuf + wv * WBUF_WORDS, T.tw + ((size_t)c * 4 + 2) * N, m.q, m.two_q);  // -> coefficient 64 k + lane
-    if (c == 0) {
-#pragma unroll
-      for (int k = 0; k < 32; k++) res0[k] = v[k];
-    } else {
-      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
-      u64* out = dst + (((size_t)plane * np + ii0 + wv) * 2 + r) * N;
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        const u32 xx = res0[k], y = v[k];
-        const u32 xm = xx >= q1 ? xx - q1 : xx;
-        const u32 dd = y >= xm ? y - xm : y + q1 - xm;
-        const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
-        u32 e = dd * T.c.q0_inv_q1 - qt * q1;
-        e = e >= q1 ? e - q1 : e;
-        const u64 val = (u64)xx + (u64)q0 * (u64)e;
-        if (nt)
-          __builtin_nontemporal_store(val, out + 64 * k + lane);
-        else
-          out[64 * k + lane] = val;
-      }
-    }
-  }
-}
-void launch_from_sweep_wave(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls) {
-  if (n_planes <= 0) return;
-  const unsigned groups = (unsigned)((np / (cls >= 0 ? 8 : 4)) * 2 * n_planes);
-  const int want = (int)tunable("from_sweep_xcd", 1);
-  const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
-  const int flags = (xcd_map ? 1 : 0) | (tunable("from_sweep_nt", 0) ? 2 : 0);
-  hipLaunchKernelGGL(k_from_sweep_wave, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, flags, cls);
-  launched(PATH_FROM_SWEEP4 | PATH_FROM_SWEEP_WAVE | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep_wave");
 }
 
 }  // namespace spiral

@@ -23,8 +23,8 @@ struct DevTables {
 // which code path produced the bytes they compared) and the launch is checked -- a rejected launch (bad grid, too
 // much LDS ...) throws HipError instead of leaving stale workspace contents to be packed into a "successful" response.
 enum PathBit : u64 {
-  PATH_SWEEP_PERSIST = 1ull << 0,     // k_sweep_packed_persist (PACKED database, capped-footprint grid)
-  PATH_SWEEP_PACKED = 1ull << 1,      // k_sweep_packed (one wave per unit)
+  PATH_SWEEP_PERSIST = 1ull << 0,     // k_sweep_packed_persist / k_sweep_packed_ring (PACKED database, persistent grid)
+  PATH_SWEEP_PACKED = 1ull << 1,      // (retired: k_sweep_packed, one wave per unit)
   PATH_SWEEP_WIDE = 1ull << 2,        // k_sweep_wide (8-byte words, num_per >= 128)
   PATH_SWEEP_NARROW = 1ull << 3,      // k_sweep_narrow / k_sweep_narrow2 (num_per < 128, LDS-staged query)
   PATH_SWEEP_BATCH = 1ull << 4,       // k_sweep_packed_batch (several queries per database pass)
@@ -40,16 +40,16 @@ enum PathBit : u64 {
   PATH_SCATTER_OUT = 1ull << 14,      // column-interleaved sweep output (multi-GPU reduce-scatter layout)
   PATH_SWEEP_XCD_FROM = 1ull << 15,   // k_from_sweep4 with the XCD-aware block order
   PATH_FOLD_TAIL_PERSIST = 1ull << 16,// k_fold_tail (all small levels in one launch, grid barrier per level)
-  PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_head (first expansion rounds in one launch)
+  PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_persist (the whole expansion in ONE launch, device-wide barriers between phases)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // RCCL collectives issued by the library itself (sp_comm_create)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
-  PATH_CU_SPLIT = 1ull << 21,         // sweeps and overlapped folds on disjoint CU sets (CU-masked streams)
+  PATH_CU_SPLIT = 1ull << 21,         // (retired: sweeps and overlapped folds on disjoint CU sets)
   PATH_EXPAND_SPLIT = 1ull << 22,     // odd expansion subtree + GSW side on the second stream, beside the even subtree
-  PATH_PIPE_CLASS_SPLIT = 1ull << 23, // a plane swept and folded as two chunk-parity classes (pipe_split)
+  PATH_PIPE_CLASS_SPLIT = 1ull << 23, // (retired: a plane swept and folded as two chunk-parity classes)
   PATH_SWEEP_MFMA = 1ull << 24,       // k_sweep_mfma_batch (batched sweep on the matrix cores, signed base-256 digits)
   PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
-  PATH_FROM_SWEEP_WAVE = 1ull << 26,  // k_from_sweep_wave (from_ntt of the sweep output, one wave per polynomial)
+  PATH_FROM_SWEEP_WAVE = 1ull << 26,  // (retired: k_from_sweep_wave)
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
   PATH_SWEEP_RING = 1ull << 28        // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
 };
@@ -124,10 +124,7 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s);
 // from_ntt of the sweep-native buffer [plane][r][crt][z][ii] (num_per = np, np % 4 == 0), four adjacent
 // columns per workgroup (16-byte loads: a quarter of the cache-line traffic of the one-column form);
 // dst raw polys dense in the same order as InvDesc's sweep mode: poly (plane*np + ii)*2 + r.
-// cls >= 0: only the columns whose 128-column chunk has parity cls (np % 256 == 0)
-void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls = -1);
-// the same on the wave-per-transform NTT (fold.hip); launch_from_sweep4 dispatches to it unless from_sweep_wave = 0
-void launch_from_sweep_wave(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls = -1);
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s);
 
 // ---- NTT-domain multiply-accumulate (poly.rs:437-481) --------------------------------------
 // out[b][r] = (addend ? addend[b][r] : 0) + sum_k A[r][k] * B[b][k]   (pointwise, per crt), r < R
@@ -173,36 +170,14 @@ struct FoldDesc {
   int zero_shortcuts;
   // the level's operands in wave layout (k_fold_wave); nullptr: not available
   const u32* mats_w;
-  // cls_on: only the fold steps of one chunk-parity class (see SweepDesc::chunk_step): block b handles step
-  // i = (b / 128) * 256 + b % 128 + 128 * cls_off; the grid has half / 2 blocks.  Needs half % 256 == 0.
-  int cls_on, cls_off;
-  int nt_store;  // k_fold_wave: streaming stores of the folded ciphertext (switch fold_nt; measured in profiles/r03_switch_ab.md)
 };
-__host__ __device__ inline int fold_step_of_block(const FoldDesc& d, int b) {
-  return d.cls_on ? ((b >> 7) << 8) + (b & 127) + 128 * d.cls_off : b;
-}
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
 // SPIRAL_FOLD_VARIANT: 5 = k_fold_wave (wave-per-transform NTT; used while two workgroups fit a CU's LDS, else falls
-// through), 3 / 2 = k_fold_fused2 (two transforms per pass, even t_gsw) with / without hoisted twiddles, 1 / 0 =
-// k_fold_fused.  profiles/r02_fold_batch_experiments.md has the measurements behind the default.
+// through), 3 = k_fold_fused2 (two cooperative transforms per pass, even t_gsw, twiddles in LDS), 0 = k_fold_fused.
+// profiles/r02_fold_batch_experiments.md has the measurements behind the default.
 constexpr long FOLD_VARIANT_DEFAULT = 5;
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s);
-
-// One round of coefficient_expansion, one workgroup per ciphertext (expand.hip).  Group 0 / 1 = the "left" / "right"
-// ciphertexts of the round (different gadget widths and key-switching matrices).
-struct ExpandDesc {
-  const u32* src;        // v as the round finds it: [ct][row][crt][N]
-  u32* dst;              // v as the round leaves it (a different buffer: see expand.hip)
-  const int* ct_idx[2];  // ciphertext indices of the group
-  int n[2];
-  int t[2], bits[2];
-  const u32* W[2];       // 2 x t key-switching matrix of this round (polynomial row * t + k of sp_pp::all)
-  int num_in;            // ciphertexts >= num_in are first formed as neg1 * v[ct - num_in]
-  const u32* neg1;       // [crt][N] of this round
-  int t_auto;
-};
-void launch_expand_round(const DevTables& T, const ExpandDesc& d, hipStream_t s);
 
 // dst poly idx[b] += src poly b   (NTT polys, mod q)
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s);
@@ -273,18 +248,9 @@ struct SweepDesc {
   // out_G > 1: column-interleaved output for the multi-GPU reduce-scatter -- chunk g = ii % out_G holds
   // [plane][r][crt][z][ii / out_G]; chunks are contiguous (chunk g goes to rank g)
   int out_G;
-  // chunk_step == 2 (persistent PACKED sweep only): only the 128-column chunks of parity chunk_off -- half a plane.  The
-  // first log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and therefore stay inside one parity
-  // class, which lets the pipeline fold one half of a plane while the other half is still being swept.
-  int chunk_step, chunk_off;
   // non-temporal (streaming) output stores: HBM writes mixed into the read stream cost 3-4x a read byte on this part, a
   // quarter less as streaming stores (scripts/ubench/rw_mix.hip); switch sweep_nt_store
   int nt_store;
-  // ring-form persistent sweep: two zeroed words (streams handed out, waves done) or null.  Non-null: a wave's streams
-  // after its first are handed out by an atomic counter instead of a fixed stride, so that waves on CUs that also run fold
-  // workgroups, or whose memory channels are busier, take fewer streams instead of holding the launch back (switch
-  // sweep_tickets).  The last wave to leave zeroes both words again.
-  u32* ticket;
 };
 // Column sharding (multi-GPU alternative to row sharding): a shard holds the columns ii = off + stride*i,
 // i < num_per_local, of every row; kernels see the local column count, loaders map to the global index.
@@ -296,8 +262,9 @@ inline size_t db_bytes(int planes, int num_per, int nj, bool packed) {
   return (size_t)planes * N * nj * num_per * (packed ? 7 : 8);
 }
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
-// persistent PACKED sweep with a capped footprint (wgs_per_cu workgroups per CU, `unroll` row pairs in flight)
-void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus = 256);
+// persistent PACKED sweep: the ring form on one workgroup per CU where the row-pair count allows, else the plain form on
+// wgs_per_cu workgroups per CU
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, hipStream_t s, int n_cus = 256);
 // B queries against ONE pass over the (PACKED) database: every database word is multiplied into B
 // accumulator sets.  B <= SWEEP_BATCH_MAX; qv[b] / out[b] as in SweepDesc.
 constexpr int SWEEP_BATCH_MAX = 8;
@@ -320,9 +287,6 @@ inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16
 // form applies and d.rq is set
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s);
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);
-const char* sweep_kernel_name(int num_per);
-// milliseconds to stream `bytes` with the PACKED sweep's access pattern (best of two timed passes; 0 = buffer too small)
-float stream_probe_ms(const void* buf, size_t bytes, u32* sink, hipStream_t s);
 // reference layout -> device layout for a z-range of one plane: src [nz][num_per][dim0] (host-order
 // words already on the device), dst plane base; keeps rows j0..j0+nj
 void launch_db_relayout(u64* dst, int plane, const u64* src, int z0, int nz, int num_per, int dim0, int j0, int nj,

@@ -255,8 +255,7 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // from_ntt of four adjacent sweep-output columns per workgroup.  grid (np/4 * 2 * planes)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map,
-                                                        int cls) {
+__global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map) {
   __shared__ u32 lds0[4 * LDS_WORDS];
   __shared__ u32 lds1[4 * LDS_WORDS];
   const int tau = threadIdx.x;
@@ -264,17 +263,15 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
   // The 8 column groups that share one 128-byte line of the [z][ii] source should go through ONE XCD's L2, back
   // to back (workgroups are dealt to the 8 XCDs round-robin): block b -> XCD b % 8 handles line (b/64)*8 + b%8,
   // group (b/8) % 8 of that line.  Otherwise every line is fetched from HBM by up to 8 L2s.
-  const bool nt = (xcd_map & 2) != 0;  // from_sweep_nt: streaming stores of the raw ciphertexts
   if (xcd_map & 1) {
     const int xcd = g & 7, t = g >> 3;
     g = ((t >> 3) * 8 + xcd) * 8 + (t & 7);
   }
-  // cls >= 0: only the column groups of one chunk-parity class (chunk = 128 columns = 32 groups of four)
-  const int gpr = cls >= 0 ? np / 8 : np / 4;  // groups per (plane, r)
+  const int gpr = np / 4;  // groups per (plane, r)
   const int groups_per_plane = gpr * 2;
   const int plane = g / groups_per_plane, rem = g % groups_per_plane;
   const int r = rem / gpr, gl = rem % gpr;
-  const int ii0 = cls >= 0 ? ((gl >> 5) * 2 + cls) * 128 + (gl & 31) * 4 : gl * 4;
+  const int ii0 = gl * 4;
   const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
   u32 res0[4][8];
 #pragma unroll 1
@@ -312,26 +309,17 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
           u32 e = dd * T.c.q0_inv_q1 - qt * q1;
           e = e >= q1 ? e - q1 : e;
           const u64 val = (u64)x + (u64)q0 * (u64)e;
-          if (nt)
-            __builtin_nontemporal_store(val, out + tau + 256 * k);
-          else
-            out[tau + 256 * k] = val;
+          out[tau + 256 * k] = val;
         }
       }
     }
   }
 }
-void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s, int cls) {
+void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
-  if (tunable("from_sweep_wave", 0) != 0) {
-    launch_from_sweep_wave(T, src, np, n_planes, premod, dst, s, cls);
-    return;
-  }
-  const unsigned groups = (unsigned)((np / (cls >= 0 ? 8 : 4)) * 2 * n_planes);
-  const int want = (int)tunable("from_sweep_xcd", 1);
-  const int xcd_map = want && (np % 32) == 0 && (groups % 64) == 0;
-  const int flags = (xcd_map ? 1 : 0) | (tunable("from_sweep_nt", 0) ? 2 : 0);   // bit 1: streaming stores
-  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, flags, cls);
+  const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
+  const int xcd_map = tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0;
+  hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
 

@@ -14,26 +14,16 @@ struct Workspace {
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
-  hipEvent_t ev_class0 = nullptr;           // first chunk-parity class of a plane swept (pipe_split)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
-  hipEvent_t ev_even = nullptr;             // even subtree + reorientation done (main): expand_order 2
   bool right_pending = false;               // this query's fold operands are produced on stream2: join_right before use
   bool long_sweep_follows = false;          // hint for run_begin (set by the caller that knows the database)
-  // CU-partitioned overlap (SPIRAL_CU_SPLIT = n > 0): the per-plane sweeps run on a stream masked to all but n CUs
-  // (n/8 in every XCD) and the overlapped folds on a stream masked to those n CUs, so the two never share a CU's
-  // issue slots, LDS or L1; created on first use (hipExtStreamCreateWithCUMask)
-  hipStream_t s_sweep = nullptr, s_fold = nullptr;
-  int split_fold_cus = -1, split_sweep_cus = 0;   // -1: not probed yet, 0: off
-  hipEvent_t ev_split_begin = nullptr;
   hipEvent_t ev_sw[2] = {nullptr, nullptr};  // first sweep launch begins / last sweep launch done (timing)
   bool have_sweep_span = false;
-  void ensure_split_streams();
   bool pipelined = false;                   // set by run_sweep_pipelined, consumed by run_finish
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
   // expansion
   DevBuf<u64> q_raw;      // query ct, raw 2x1
   DevBuf<u32> v;          // [2^g] 2x1 NTT cts
-  DevBuf<u32> v2;         // second copy: the fused expansion rounds read one and write the other
   DevBuf<u64> exp_raw;    // [active] automorphed raw cts
   DevBuf<u32> exp_dig;    // digit NTTs of one group
   DevBuf<u32> exp_ct1;    // NTT of row 1 of the automorphed cts
@@ -47,7 +37,6 @@ struct Workspace {
   DevBuf<u32> gsw_dig;
   // sweep
   DevBuf<u32> sweep_out;  // [plane][r][crt][z][ii]
-  DevBuf<u32> sweep_ticket;  // SweepDesc::ticket (zeroed once; the ring sweep leaves it zeroed)
   DevBuf<u64> fold_tail;     // pipe_tail_defer: [2][plane][cts parked per plane][2][N]
   DevBuf<u32> batch_rq;   // query digit table of a batched pass on the matrix cores (first workspace of a group; on first use)
   // fold / pack
@@ -93,13 +82,10 @@ void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const i
 std::unique_ptr<DeviceState::PrunedPlan> build_pruned_plan_rows(const Params& P, const std::vector<char>& rows);
 void run_sweep(Workspace& W, const sp_db& db);
 void run_sweep_pipelined(Workspace& W, const sp_db& db);
-void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);
-bool plane_is_class_split(const Params& p, const sp_db& db, size_t plane);
-std::vector<std::pair<size_t, int>> pipelined_sweep_launches(const Params& p, const sp_db& db);  // (plane, class or -1)
-void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane, int cls = -1);  // cls >= 0: one chunk-parity class
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
 bool fused_fold_supported(const Params& p);
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1, int cls = -1);
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_fold_local_plane(Workspace& W, const u32* reduced_plane_chunk, int G, int plane);
 void run_fold_local_join(Workspace& W);

@@ -66,7 +66,8 @@ static bool tunable_resolve(const char* name, long* out) {
 }
 long tunable(const char* name, long dflt) {
   struct Ent {
-    const char* name;  // call sites pass string literals: the address identifies the site
+    std::string name;  // compared by CONTENT: call sites pass literals today, but an address is no identity for a heap or
+                       // stack string whose storage is reused
     unsigned epoch;
     bool has;
     long val;
@@ -74,7 +75,7 @@ long tunable(const char* name, long dflt) {
   thread_local std::vector<Ent> cache;
   const unsigned ep = g_tun_epoch.load(std::memory_order_relaxed);
   for (auto& e : cache)
-    if (e.name == name) {
+    if (!strcmp(e.name.c_str(), name)) {
       if (e.epoch != ep) {
         e.has = tunable_resolve(name, &e.val);
         e.epoch = ep;
@@ -507,25 +508,14 @@ sp_params::~sp_params() {}
 namespace spiral {
 
 // ---------------------------------------------------------------------------------- workspace
+static int tail_defer_levels(const Params& p, long stop);
 Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
   device = D.device;
-  // stream_prio (default 0 = off): 1 = the main stream (even expansion chain, sweeps) at the highest dispatch priority and
-  // the second stream (odd expansion subtree, overlapped folds) at the lowest; 2 = the other way round
-  const long sprio = tunable("stream_prio", 0);
-  if (sprio == 1 || sprio == 2) {
-    int lo = 0, hi = 0;  // numerically lower = higher priority
-    HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
-    HIP_CHECK(hipStreamCreateWithPriority(&stream, hipStreamNonBlocking, sprio == 1 ? hi : lo));
-    HIP_CHECK(hipStreamCreateWithPriority(&stream2, hipStreamNonBlocking, sprio == 1 ? lo : hi));
-  } else {
-    HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
-  }
+  HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+  HIP_CHECK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
   HIP_CHECK(hipEventCreateWithFlags(&ev_fold, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_round0, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_class0, hipEventDisableTiming));
   HIP_CHECK(hipEventCreateWithFlags(&ev_right, hipEventDisableTiming));
-  HIP_CHECK(hipEventCreateWithFlags(&ev_even, hipEventDisableTiming));
   ev_plane.resize(P.planes());
   for (auto& e : ev_plane) HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -562,47 +552,16 @@ Workspace::~Workspace() {
   for (auto& e : ev_plane)
     if (e) (void)hipEventDestroy(e);
   if (ev_fold) (void)hipEventDestroy(ev_fold);
-  for (hipEvent_t e : {ev_split_begin, ev_sw[0], ev_sw[1], ev_round0, ev_right, ev_even, ev_class0})
+  for (hipEvent_t e : {ev_sw[0], ev_sw[1], ev_round0, ev_right})
     if (e) (void)hipEventDestroy(e);
-  if (s_sweep) (void)hipStreamDestroy(s_sweep);
-  if (s_fold) (void)hipStreamDestroy(s_fold);
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
-}
-
-// SPIRAL_CU_SPLIT = n: CU bit k of a stream's mask is CU (k / 8) of XCD (k % 8) on this part (the driver deals the mask
-// bits round-robin over the 8 XCCs), so the low n bits give the fold n/8 CUs in every XCD and the sweep the rest: both
-// partitions keep all 8 L2s and every HBM channel.
-void Workspace::ensure_split_streams() {
-  if (split_fold_cus >= 0) return;
-  split_fold_cus = 0;
-  const int n = (int)tunable("cu_split", 0);
-  if (n <= 0) return;
-  hipDeviceProp_t prop;
-  HIP_CHECK(hipGetDeviceProperties(&prop, device));
-  const int total = prop.multiProcessorCount;
-  if (n >= total) return;
-  std::vector<uint32_t> mf((total + 31) / 32, 0u), ms((total + 31) / 32, 0u);
-  for (int k = 0; k < total; k++) (k < n ? mf : ms)[k / 32] |= 1u << (k % 32);
-  hipStream_t a = nullptr, b = nullptr;
-  if (hipExtStreamCreateWithCUMask(&a, (uint32_t)ms.size(), ms.data()) != hipSuccess ||
-      hipExtStreamCreateWithCUMask(&b, (uint32_t)mf.size(), mf.data()) != hipSuccess) {
-    (void)hipGetLastError();
-    if (a) (void)hipStreamDestroy(a);
-    return;  // no CU masking on this system: the shared-CU overlap stays in use
-  }
-  s_sweep = a;
-  s_fold = b;
-  HIP_CHECK(hipEventCreateWithFlags(&ev_split_begin, hipEventDisableTiming));
-  split_fold_cus = n;
-  split_sweep_cus = total - n;
 }
 
 void Workspace::ensure_expand() {
   const Params& p = *P;
   const size_t g = p.g();
   v.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);
-  if (p.db_dim_2 > 0) v2.ensure(((size_t)1 << g) * 2 * 2 * POLY_LEN);  // k_expand_round ping-pongs v and v2
   exp_raw.ensure(std::max<size_t>(D->max_all, 1) * 2 * POLY_LEN);
   size_t dig = D->max_left * p.t_exp_left + D->max_right * p.t_exp_right;  // both groups of a round coexist
   exp_dig.ensure(std::max<size_t>(dig, 1) * 2 * POLY_LEN);
@@ -634,10 +593,6 @@ size_t Workspace::plane_group() const {
 void Workspace::ensure_sweep() {
   const Params& p = *P;
   sweep_out.ensure(p.planes() * 4 * POLY_LEN * p.num_per());
-  if (!sweep_ticket.p) {  // SweepDesc::ticket: zero once, the kernel leaves it zeroed
-    sweep_ticket.ensure(64);
-    HIP_CHECK(hipMemset(sweep_ticket.p, 0, 64 * sizeof(u32)));
-  }
 }
 
 void Workspace::ensure_finish() {
@@ -657,8 +612,10 @@ void Workspace::ensure_finish() {
   pack_ct2.ensure(nb * 2 * POLY_LEN);
   pack_res.ensure(p.instances * (p.n + 1) * p.n * 2 * POLY_LEN);
   pack_raw.ensure(p.instances * (p.n + 1) * p.n * POLY_LEN);
-  // parking buffer of the pipelined query's batched fold tails (pipe_tail_defer, default 256 ciphertexts per plane)
-  if (p.planes() > 1 && p.num_per() >= 1024 && fused_ok) fold_tail.ensure(2 * p.planes() * 256 * 2 * POLY_LEN);
+  // parking buffer of the pipelined query's batched fold tails, sized from the same switch run_sweep_pipelined reads
+  // (pipe_tail_defer, default 256 ciphertexts per plane): nothing is allocated inside a pipelined query
+  const int defer = tail_defer_levels(p, tunable("pipe_tail_defer", 256));
+  if (defer > 0 && p.num_per() >= 1024) fold_tail.ensure(2 * p.planes() * (p.num_per() >> defer) * 2 * POLY_LEN);
 }
 
 // ---------------------------------------------------------------------------------- pipeline stages
@@ -778,46 +735,6 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
     }
     launch_mac2(D.T, md[0], md[1], s);
   }
-}
-
-// Rounds [r_begin, r_end) of one subtree (or of the whole schedule) with k_expand_round: round r reads buf[r & 1] and
-// writes buf[(r & 1) ^ 1].  Returns the buffer the last launched round wrote (buf[r_begin & 1] if none ran).
-static u32* run_expansion_fused(Workspace& W, const sp_pp& pp, size_t r_begin, size_t r_end, const DeviceState::PrunedPlan* plan,
-                                int tree, u32* const buf[2]) {
-  const Params& p = *W.P;
-  DeviceState& D = *W.D;
-  const int* L = plan ? plan->lists.p : D.lists.p;
-  const std::vector<RoundPlan>& rounds = tree == 1   ? (plan ? plan->rounds_even : D.rounds_even)
-                                         : tree == 2 ? (plan ? plan->rounds_odd : D.rounds_odd)
-                                                     : (plan ? plan->rounds : D.rounds);
-  const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
-  u32* last = buf[r_begin & 1];
-  for (size_t r = r_begin; r < r_end; r++) {
-    const RoundPlan& rp = rounds[r];
-    if (rp.n_all == 0) continue;
-    const bool use_right = pp.has_right && p.db_dim_2 > 0;
-    ExpandDesc d{};
-    d.src = buf[r & 1];
-    d.dst = buf[(r & 1) ^ 1];
-    // the group lists hold positions inside all_ct; the kernel wants the ciphertext itself = out poly index / 2
-    d.ct_idx[0] = L + rp.left_ct;
-    d.ct_idx[1] = L + rp.right_ct;
-    d.n[0] = rp.n_left;
-    d.n[1] = rp.n_right;
-    d.t[0] = tl;
-    d.t[1] = tr;
-    d.bits[0] = (int)p.bits_per(tl);
-    d.bits[1] = (int)p.bits_per(tr);
-    const u32* wbase = pp.all.p;
-    d.W[0] = wbase + (pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
-    d.W[1] = wbase + (use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl) * 2 * POLY_LEN;
-    d.num_in = rp.num_in;
-    d.neg1 = D.neg1.p + r * 2 * POLY_LEN;
-    d.t_auto = rp.t_auto;
-    launch_expand_round(D.T, d, W.stream);
-    last = d.dst;
-  }
-  return last;
 }
 
 // server.rs:123-151 with idx_factor 1, idx_offset 0, reading the inputs v[2b+1] in place and writing
@@ -961,62 +878,27 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   const int* L = D.lists.p;
   const long split_mode = tunable("expand_split", -1);  // -1: only when a long sweep follows (it hides the odd subtree)
   if (p.db_dim_2 > 0 && g >= 2 && (split_mode > 0 || (split_mode < 0 && W.long_sweep_follows))) {
-    // SPIRAL_EXPAND_SPLIT (default: only before a per-plane pipelined sweep, i.e. wide packed databases; 1: always;
-    // 0: never): after round 0 the tree falls into the even subtree (-> v_reg, what the sweep waits
-    // for) and the odd subtree (-> the GSW bits, regev_to_gsw and G - C, what the FOLD waits for; 56 digits per
-    // ciphertext against 8: more than half of the transforms).  The odd side then runs on stream2, beside the even side
-    // and the first plane's sweep; consumers of fold_mats order themselves after ev_right (join_right).
-    // Measured (profiles/r02_expand_experiments.md): the even subtree is a chain of 27 launches whose length does not
-    // depend on how much work rides along, so taking the odd subtree out shortens it by 6 % at C2 and not at all at
-    // C1/P2, where the odd subtree then competes with the short sweep.  SPIRAL_EXPAND_FUSED=1 replaces the three
-    // launches of a round by k_expand_round_teams (one workgroup per ciphertext): byte-identical, but one CU cannot
-    // issue a ciphertext's 22 transforms faster than three launches spread over 22 CUs (32 us against 28 per round).
+    // expand_split (default -1: only before a per-plane pipelined sweep, i.e. wide packed databases; 1: always; 0: never):
+    // after round 0 the tree falls into the even subtree (-> v_reg, what the sweep waits for) and the odd subtree (-> the
+    // GSW bits, regev_to_gsw and G - C, what the FOLD waits for; 56 digits per ciphertext against 8: more than half of the
+    // transforms).  The odd side then runs on stream2, beside the even side and the first plane's sweep; consumers of
+    // fold_mats order themselves after ev_right (join_right).  Measured (profiles/r02_expand_experiments.md): -6 % at C2,
+    // nothing at C1/P2, where the odd subtree then competes with the short sweep.  The enqueue order of the two sides and a
+    // one-launch-per-round kernel (one workgroup per ciphertext) were measured in round 2 and bought nothing
+    // (profiles/r02_expand_order.txt, r02_expand_experiments.md); both are gone.
     note_path(PATH_EXPAND_SPLIT);
-    if (tunable("expand_fused", 0)) {
-      // one launch per round and subtree (expand.hip): v and v2 alternate as source and destination
-      u32* const buf[2] = {W.v.p, W.v2.p};
-      run_expansion_fused(W, pp, 0, 1, pl, 0, buf);
-      HIP_CHECK(hipEventRecord(W.ev_round0, s));
-      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_round0, 0));
-      on_stream(W, W.stream2, [&] {
-        const u32* v_odd = run_expansion_fused(W, pp, 1, g, pl, 2, buf);
-        run_regev_to_gsw(W, pp, v_odd, L + D.gsw_src_ct, L + D.gsw_src_poly);
-        run_folding_neg(W);
-      });
-      HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
-      W.right_pending = true;
-      const u32* v_even = run_expansion_fused(W, pp, 1, g, pl, 1, buf);
-      launch_reorient(W.qv.p, v_even, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
-      return;
-    }
     run_coefficient_expansion(W, pp, 1, pl, 0, 0);
     HIP_CHECK(hipEventRecord(W.ev_round0, s));
-    // Enqueue order (expand_order; measured at C2, profiles/r02_expand_order.md).  0 (default): the odd side is queued
-    // first and starts after round 0, beside the even side: 10.95 ms per query.  1: the even side (the critical path:
-    // the first sweep waits for it) is queued first, the odd side still starts after round 0: expansion 0.74 -> 0.62 ms
-    // but the sweeps lose more than that (11.5 ms).  2: the odd side starts when the even side is done, i.e. it runs
-    // beside the first plane's sweep only: expansion 0.49 ms, sweep span +0.22 ms, 10.93 ms -- the odd side's ~0.2 ms
-    // of work costs the same wherever it runs, so the order is left as it was.
-    const long order = tunable("expand_order", 0);
-    auto odd_side = [&](hipEvent_t after) {
-      HIP_CHECK(hipStreamWaitEvent(W.stream2, after, 0));
-      on_stream(W, W.stream2, [&] {
-        run_coefficient_expansion(W, pp, g, pl, 2, 1);
-        run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-        run_folding_neg(W);
-      });
-      HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
-      W.right_pending = true;
-    };
-    if (order == 0) odd_side(W.ev_round0);
+    HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_round0, 0));
+    on_stream(W, W.stream2, [&] {
+      run_coefficient_expansion(W, pp, g, pl, 2, 1);
+      run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+      run_folding_neg(W);
+    });
+    HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
+    W.right_pending = true;
     run_coefficient_expansion(W, pp, g, pl, 1, 1);
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
-    if (order == 2) {
-      HIP_CHECK(hipEventRecord(W.ev_even, s));
-      odd_side(W.ev_even);
-    } else if (order != 0) {
-      odd_side(W.ev_round0);
-    }
     return;
   }
   run_coefficient_expansion(W, pp, g, pl);
@@ -1087,7 +969,7 @@ static int tail_defer_levels(const Params& p, long stop) {  // levels folded per
 static void fold_plane_head(Workspace& W, size_t pl, int levels) {  // from_ntt + the first `levels` levels, parked
   const Params& p = *W.P;
   launch_from_sweep4(W.D->T, W.sweep_out.p + pl * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), 1, 0, W.foldX.p, W.stream);
-  u64* res = run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, levels, -1);
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, levels);
   const size_t cts = p.num_per() >> levels;
   HIP_CHECK(hipMemcpyAsync(W.fold_tail.p + pl * cts * 2 * POLY_LEN, res, cts * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
 }
@@ -1095,59 +977,8 @@ static void fold_tails(Workspace& W, int levels) {  // the parked planes togethe
   const Params& p = *W.P;
   const size_t cts = p.num_per() >> levels;
   u64* other = W.fold_tail.p + p.planes() * cts * 2 * POLY_LEN;
-  u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1, -1);
+  u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1);
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, p.planes() * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
-}
-
-// The pipeline's finer grain: a plane is swept in two launches, the 128-column chunks of even and of odd index; the first
-// L = log2(num_per) - 8 fold levels pair column i with i + half, half >= 256, and stay inside such a class, so the
-// from_ntt and those L levels of class 0 run while class 1 is still being swept.
-static int class_fold_levels(const Params& p) {
-  int lg = 0;
-  while (((size_t)1 << lg) < p.num_per()) lg++;
-  return lg - 8;
-}
-static bool class_split_ok(const Params& p) {
-  return p.num_per() % 512 == 0 && class_fold_levels(p) >= 1 && fused_fold_supported(p) && !tunable("from_sweep1", 0);
-}
-static void fold_plane_class(Workspace& W, size_t pl, int cls) {  // from_ntt + class-local levels of one class
-  const Params& p = *W.P;
-  launch_from_sweep4(W.D->T, W.sweep_out.p + pl * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), 1, 0, W.foldX.p, W.stream, cls);
-  (void)run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, class_fold_levels(p), cls);
-}
-static void fold_plane_rest(Workspace& W, size_t pl) {  // the remaining levels of the plane, both classes together
-  const Params& p = *W.P;
-  const int L = class_fold_levels(p);
-  u64* X = (L & 1) ? W.foldY.p : W.foldX.p;   // every level swaps the two buffers
-  u64* Y = (L & 1) ? W.foldX.p : W.foldY.p;
-  u64* res = run_fold(W, X, Y, 1, (int)p.num_per(), -1, L, -1, -1);
-  HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pl * 2 * POLY_LEN, res, (size_t)2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
-}
-
-// pipe_split (default 0 = off): 2 = every plane is swept as two chunk-parity classes, so that the second stream starts a
-// plane's from_ntt and class-local fold levels half a plane earlier; 1 = only the last plane.  Measured at C2
-// (profiles/r02_sweep_experiments.md): the overlapped folds take as long as the sweeps they hide behind, so the second
-// stream runs late and the finer grain shortens what is exposed at the end (0.74 -> 0.56 ms), but the half-plane
-// launches are 3-4 % less efficient (ramp and tail twice per plane): 11.52 -> 11.44 ms in one process, nothing across
-// runs.  Splitting only the last plane is slower (its class-0 fold queues behind the previous plane's fold).
-bool plane_is_class_split(const Params& p, const sp_db& db, size_t pl) {
-  const long split = class_split_ok(p) && db.packed && tunable("pipe_wgs", 4) > 0 && tunable("fused_min_pairs", 256) <= 256
-                         ? tunable("pipe_split", 0)
-                         : 0;
-  return split == 2 || (split == 1 && pl + 1 == p.planes());
-}
-// the sweep launches of one pipelined query: (plane, class or -1)
-std::vector<std::pair<size_t, int>> pipelined_sweep_launches(const Params& p, const sp_db& db) {
-  std::vector<std::pair<size_t, int>> v;
-  for (size_t pl = 0; pl < p.planes(); pl++) {
-    if (plane_is_class_split(p, db, pl)) {
-      v.push_back({pl, 0});
-      v.push_back({pl, 1});
-    } else {
-      v.push_back({pl, -1});
-    }
-  }
-  return v;
 }
 
 // Single-GPU query on a wide PACKED database: the database is swept one (instance, trial) plane per launch, and
@@ -1160,17 +991,16 @@ bool sweep_is_pipelined(const Params& p, const sp_db& db) {
   return enabled && db.packed && db.num_shards == 1 && db.col_G == 1 && p.planes() > 1 && p.num_per() >= 1024;
 }
 
-void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl, int cls) {
+void launch_plane_sweep(Workspace& W, const sp_db& db, size_t pl) {
   const Params& p = *W.P;
   const size_t np_ = (size_t)db.np_local;
   const size_t plane_db_words = db_bytes(1, db.np_local, db.nj, db.packed) / 8;  // N*nj*np*{7,8} is a multiple of 8
   SweepDesc d{db.words.p + pl * plane_db_words, W.qv.p, W.sweep_out.p + pl * 4 * POLY_LEN * np_, 1, db.np_local,
-              (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G, cls >= 0 ? 2 : 1, cls >= 0 ? cls : 0};
+              (int)p.dim0(), db.j0, db.nj, db.packed, W.out_G};
   d.nt_store = (int)tunable("sweep_nt_store", 1);
-  d.ticket = tunable("sweep_tickets", 0) != 0 ? W.sweep_ticket.p : nullptr;
-  const int wgs = (int)tunable("pipe_wgs", 4), unr = (int)tunable("pipe_unroll", 4);
+  const int wgs = (int)tunable("pipe_wgs", 4);
   if (db.packed && wgs > 0)
-    launch_sweep_persist(W.D->T, d, wgs, unr, W.stream, W.stream == W.s_sweep && W.split_sweep_cus > 0 ? W.split_sweep_cus : 256);
+    launch_sweep_persist(W.D->T, d, wgs, W.stream);
   else
     launch_sweep(W.D->T, d, W.stream);
 }
@@ -1179,64 +1009,14 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   const Params& p = *W.P;
   W.ensure_sweep();
   W.ensure_finish();
-  W.ensure_split_streams();
   const size_t planes = p.planes();
-  if (W.split_fold_cus > 0) {
-    // sweeps and folds on disjoint CU sets; the last plane's fold (nothing left to overlap with) on every CU
-    hipStream_t main = W.stream;
-    HIP_CHECK(hipEventRecord(W.ev_split_begin, main));
-    HIP_CHECK(hipStreamWaitEvent(W.s_sweep, W.ev_split_begin, 0));
-    HIP_CHECK(hipStreamWaitEvent(W.s_fold, W.ev_split_begin, 0));
-    HIP_CHECK(hipEventRecord(W.ev_sw[0], W.s_sweep));
-    for (size_t pl = 0; pl < planes; pl++) {
-      on_stream(W, W.s_sweep, [&] { launch_plane_sweep(W, db, pl); });
-      HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.s_sweep));
-      if (pl + 1 < planes) {
-        HIP_CHECK(hipStreamWaitEvent(W.s_fold, W.ev_plane[pl], 0));
-        on_stream(W, W.s_fold, [&] { fold_planes(W, pl, 1, false); });
-      }
-    }
-    HIP_CHECK(hipEventRecord(W.ev_sw[1], W.s_sweep));
-    HIP_CHECK(hipEventRecord(W.ev_fold, W.s_fold));
-    HIP_CHECK(hipStreamWaitEvent(main, W.ev_fold, 0));              // foldX / foldY are shared by all planes
-    HIP_CHECK(hipStreamWaitEvent(main, W.ev_plane[planes - 1], 0));
-    fold_planes(W, planes - 1, 1, false);
-    HIP_CHECK(hipEventRecord(W.ev_fold, main));
-    W.have_sweep_span = true;
-    W.pipelined = true;
-    note_path(PATH_PIPELINED | PATH_CU_SPLIT);
-    return;
-  }
   HIP_CHECK(hipEventRecord(W.ev_sw[0], W.stream));
   const int defer_levels = tail_defer_levels(p, tunable("pipe_tail_defer", 256));
   if (defer_levels > 0) {
-    W.fold_tail.ensure(2 * planes * (p.num_per() >> defer_levels) * 2 * POLY_LEN);
+    W.fold_tail.ensure(2 * planes * (p.num_per() >> defer_levels) * 2 * POLY_LEN);  // (no-op: ensure_finish sized it)
     note_path(PATH_FOLD_TAIL_BATCHED);
   }
   for (size_t pl = 0; pl < planes; pl++) {
-    if (plane_is_class_split(p, db, pl) && (defer_levels == 0 || defer_levels == class_fold_levels(p))) {
-      launch_plane_sweep(W, db, pl, 0);
-      HIP_CHECK(hipEventRecord(W.ev_class0, W.stream));
-      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_class0, 0));
-      on_stream(W, W.stream2, [&] { fold_plane_class(W, pl, 0); });
-      launch_plane_sweep(W, db, pl, 1);
-      HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
-      HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
-      on_stream(W, W.stream2, [&] {
-        fold_plane_class(W, pl, 1);
-        if (defer_levels > 0) {  // the class-local levels are exactly the levels folded before parking
-          const size_t cts = p.num_per() >> defer_levels;
-          u64* res = (defer_levels & 1) ? W.foldY.p : W.foldX.p;
-          HIP_CHECK(hipMemcpyAsync(W.fold_tail.p + pl * cts * 2 * POLY_LEN, res, cts * 2 * POLY_LEN * sizeof(u64),
-                                   hipMemcpyDeviceToDevice, W.stream));
-          if (pl + 1 == planes) fold_tails(W, defer_levels);
-        } else {
-          fold_plane_rest(W, pl);
-        }
-      });
-      note_path(PATH_PIPE_CLASS_SPLIT);
-      continue;
-    }
     launch_plane_sweep(W, db, pl);
     HIP_CHECK(hipEventRecord(W.ev_plane[pl], W.stream));
     HIP_CHECK(hipStreamWaitEvent(W.stream2, W.ev_plane[pl], 0));
@@ -1256,24 +1036,12 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   note_path(PATH_PIPELINED);
 }
 
-// from_ntt + fold of plane `pl` on the SECOND stream once `after` has fired (the batched per-plane pipeline: the plane
-// was swept by another query's stream); run_finish then waits for ev_fold
-void run_fold_plane_overlapped(Workspace& W, size_t pl, hipEvent_t after) {
-  W.ensure_finish();
-  HIP_CHECK(hipStreamWaitEvent(W.stream2, after, 0));
-  on_stream(W, W.stream2, [&] { fold_planes(W, pl, 1, false); });
-  if (pl + 1 == W.P->planes()) {
-    HIP_CHECK(hipEventRecord(W.ev_fold, W.stream2));
-    W.pipelined = true;
-  }
-}
-
 // k_fold_fused* keep gadget digits in u32 and need digit < 2q, i.e. at most 28 bits per digit (t_gsw >= 2)
 bool fused_fold_supported(const Params& p) { return 4 * p.t_gsw <= 128 && p.bits_per(p.t_gsw) <= 28; }
 
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin, int d_end, int cls) {
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin, int d_end) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
@@ -1283,8 +1051,7 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
   while (((int)1 << further) < num_cts) further++;
   // level d uses GSW ciphertext v_folding[top - d]; a whole tree has top = further - 1 (server.rs:413,420)
   const int top_idx = top < 0 ? further - 1 : top;
-  // levels [d_begin, d_end) of the tree (default: all); cls >= 0: only the fold steps of one chunk-parity class (fused
-  // kernels; the caller has checked that these levels qualify: half % 256 == 0)
+  // levels [d_begin, d_end) of the tree (default: all)
   if (d_end < 0) d_end = further;
   int cur = num_cts >> d_begin;
   for (int d = d_begin; d < d_end; d++) {
@@ -1293,11 +1060,8 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
     // the three-kernel form, which parallelises over digits
     if (W.zero_shortcuts && !fused_fold_supported(p))
       throw ArgError("sparse buckets need gadget parameters the fused fold supports (3 <= t_gsw <= 32)");
-    if (cls >= 0 && !(fused_fold_supported(p) && half % 256 == 0)) throw ArgError("internal: class fold on an unfit level");
-    if (W.zero_shortcuts || cls >= 0 || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
+    if (W.zero_shortcuts || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
       FoldDesc fd{};
-      fd.cls_on = cls >= 0 ? 1 : 0;
-      fd.cls_off = cls >= 0 ? cls : 0;
       fd.zero_shortcuts = W.zero_shortcuts ? 1 : 0;
       fd.mats_w = W.mats_w_ready ? W.fold_mats_w.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN : nullptr;
       fd.X = X;
@@ -1308,7 +1072,6 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
       fd.planes = np;
       fd.t = (int)p.t_gsw;
       fd.bits = (int)p.bits_per(p.t_gsw);
-      fd.nt_store = (int)tunable("fold_nt", 0);
       launch_fold_fused(D.T, fd, s);
       std::swap(X, Y);
       cur = half;

@@ -50,7 +50,6 @@ __device__ __forceinline__ void sweep_store_pair(const SweepDesc& d, int plane, 
   }
 }
 
-template <int U, bool NT>
 __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
   const int lane = threadIdx.x & 63;
   const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -70,37 +69,14 @@ __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
   u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // word 1
   for (int jb = 0; jb < d.nj; jb += 256) {
     const int je = min(jb + 256, d.nj);
-    int j = jb;
-    for (; j + U <= je; j += U) {
-      ulonglong2 w[U];
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const ulonglong2* a = p + (size_t)(j + u) * stride;
-        if (NT) {  // streamed once: do not keep the lines in L2 / MALL
-          w[u].x = __builtin_nontemporal_load(&a->x);
-          w[u].y = __builtin_nontemporal_load(&a->y);
-        } else {
-          w[u] = *a;
-        }
-      }
-#pragma unroll
-      for (int u = 0; u < U; u++) {
-        const uint4 qa = qrow[j + u];  // (a0_lo, a0_hi, a1_lo, a1_hi)
-        const u32 b0l = (u32)w[u].x, b0h = (u32)(w[u].x >> 32);
-        const u32 b1l = (u32)w[u].y, b1h = (u32)(w[u].y >> 32);
-        a00 += (u64)qa.x * b0l;
-        a01 += (u64)qa.z * b0l;
-        a02 += (u64)qa.y * b0h;
-        a03 += (u64)qa.w * b0h;
-        a10 += (u64)qa.x * b1l;
-        a11 += (u64)qa.z * b1l;
-        a12 += (u64)qa.y * b1h;
-        a13 += (u64)qa.w * b1h;
-      }
-    }
-    for (; j < je; j++) {
-      const ulonglong2 w = p[(size_t)j * stride];
-      const uint4 qa = qrow[j];
+    for (int j = jb; j < je; j++) {
+      // streamed once: non-temporal loads, no manual unroll (the fastest of the forms measured in round 1,
+      // profiles/r01_sweep_variants.md: 6.8 TB/s)
+      const ulonglong2* a = p + (size_t)j * stride;
+      ulonglong2 w;
+      w.x = __builtin_nontemporal_load(&a->x);
+      w.y = __builtin_nontemporal_load(&a->y);
+      const uint4 qa = qrow[j];  // (a0_lo, a0_hi, a1_lo, a1_hi)
       const u32 b0l = (u32)w.x, b0h = (u32)(w.x >> 32);
       const u32 b1l = (u32)w.y, b1h = (u32)(w.y >> 32);
       a00 += (u64)qa.x * b0l;
@@ -121,74 +97,24 @@ __global__ __launch_bounds__(256) void k_sweep_wide(DevTables T, SweepDesc d) {
     a12 = reduce64(a12, m1);
     a13 = reduce64(a13, m1);
   }
-  // out[plane][r][crt][z][ii]
   // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
   sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
                    (u32)a03, (u32)a13);
 }
 
-// PACKED wide sweep: as k_sweep_wide, but each lane streams 28 bytes per ROW PAIR (7 dwords = 8 limbs
-// of 28 bits) instead of 32; limb extraction is 6 v_alignbit + 7 v_and per 16 multiply-accumulates.
+// PACKED wide sweeps: as k_sweep_wide, but each lane streams 28 bytes per ROW PAIR (7 dwords = 8 limbs of 28 bits)
+// instead of 32; limb extraction is 6 v_alignbit + 7 v_and per 16 multiply-accumulates.
 typedef u32 u32x4_t __attribute__((ext_vector_type(4)));
 typedef u32 u32x3_t __attribute__((ext_vector_type(3), aligned(4)));
-__global__ __launch_bounds__(256) void k_sweep_packed(DevTables T, SweepDesc d) {
-  const int lane = threadIdx.x & 63;
-  const int unit = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  const int chunks = d.num_per >> 7;
-  const int chunk = unit % chunks;
-  const int zp = unit / chunks;  // plane * N + z
-  const int z = zp & (N - 1);
-  const int plane = zp >> POLY_LEN_LOG2;
-  if (plane >= d.planes) return;
-  const int npairs = d.nj >> 1;
-  const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);  // 1792 B = 448 dwords
-  const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
-  const uint4* __restrict__ qrow = reinterpret_cast<const uint4*>(d.qv) + ((size_t)z * d.dim0 + d.j0);
-  const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
-  const u32 M = 0x0FFFFFFFu;
-  u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0;  // ii = 2l  : n0_0, n0_1, n1_0, n1_1
-  u64 a10 = 0, a11 = 0, a12 = 0, a13 = 0;  // ii = 2l+1
-  for (int jb = 0; jb < npairs; jb += 128) {
-    const int je = min(jb + 128, npairs);
-    for (int jp = jb; jp < je; jp++) {
-      const u32* u = base + (size_t)jp * ustride;
-      const u32* p4 = u + lane * 4;
-      const u32* p3 = u + 256 + lane * 3;
-      const u32x4_t va = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p4));
-      const u32x3_t vb = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(p3));
-      const u32 d0 = va.x, d1 = va.y, d2 = va.z, d3 = va.w, d4 = vb.x, d5 = vb.y, d6 = vb.z;
-      const uint4 qa = qrow[2 * jp];      // row 2jp   : (a0_lo, a0_hi, a1_lo, a1_hi)
-      const uint4 qb = qrow[2 * jp + 1];  // row 2jp+1
-      const u32 f0 = d0 & M;
-      const u32 f1 = __builtin_amdgcn_alignbit(d1, d0, 28) & M;
-      const u32 f2 = __builtin_amdgcn_alignbit(d2, d1, 24) & M;
-      const u32 f3 = __builtin_amdgcn_alignbit(d3, d2, 20) & M;
-      const u32 f4 = __builtin_amdgcn_alignbit(d4, d3, 16) & M;
-      const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
-      const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
-      const u32 f7 = d6 >> 4;
-      // (row 2jp, ii 2l) = (f0, f1); (2jp, 2l+1) = (f2, f3); (2jp+1, 2l) = (f4, f5); (2jp+1, 2l+1) = (f6, f7)
-      a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
-      a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
-      a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
-      a10 += (u64)qb.x * f6; a11 += (u64)qb.z * f6; a12 += (u64)qb.y * f7; a13 += (u64)qb.w * f7;
-    }
-    a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
-    a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
-  }
-  // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
-  sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
-                   (u32)a03, (u32)a13);
-}
 
-// Persistent form of k_sweep_packed for the intra-query pipeline: a fixed grid of `wgs_per_cu` workgroups per
-// CU walks the (z, chunk) units, U row pairs in flight per lane, so that half of every CU's wave slots, VGPRs and
-// LDS stay free for the fold kernels running concurrently on the second stream.
-template <int U>
-__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio, int spread, int zmul) {
+// Persistent PACKED sweep, plain form: a fixed grid of `wgs_per_cu` workgroups per CU walks the (z, chunk) streams, four row
+// pairs in flight per lane.  Used where the ring form below does not divide the stream (row-pair counts that are not a
+// multiple of 4: narrow row shards, odd shapes) and as the A/B partner of the ring form (pipe_ring = 0).
+__global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, SweepDesc d, int units, int hi_prio) {
   // the sweep is a latency-bound load stream using ~20 % of the VALU slots: when fold kernels share the CU its
   // waves must win instruction arbitration or the loads in flight (and the HBM rate) drop
   if (hi_prio) __builtin_amdgcn_s_setprio(3);
+  constexpr int U = 4;
   const int lane = threadIdx.x & 63;
   const int wave0 = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
   const int nwaves = gridDim.x * 4;
@@ -197,13 +123,9 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
   const size_t ustride = 448;  // consecutive row pairs of a (zp, chunk) stream are adjacent
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
-  const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;  // one chunk-parity class or all chunks
   for (int unit = wave0; unit < units; unit += nwaves) {
-    const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
-    // zmul (sweep_zmul, odd; 1 = identity): the z-rows are visited in the order z * zmul mod N, so that the units in flight
-    // at one time are spread over the whole plane instead of one contiguous window of it (the chunks of a z stay together)
-    const int zp_lin = unit / chunks_l;
-    const int zp = (zp_lin & ~(N - 1)) | ((zp_lin * zmul) & (N - 1));
+    const int chunk = unit % chunks;
+    const int zp = unit / chunks;
     const int z = zp & (N - 1);
     const int plane = zp >> POLY_LEN_LOG2;
     const u32* base = reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)zp, 0, chunk, npairs, chunks);
@@ -211,23 +133,19 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
     u64 a00 = 0, a01 = 0, a02 = 0, a03 = 0, a10 = 0, a11 = 0, a12 = 0, a13 = 0;
     for (int jb = 0; jb < npairs; jb += 128) {
       const int je = min(jb + 128, npairs);
-      // spread (sweep_spread, needs (je - jb) % U == 0): the U row pairs a wave has in flight come from U sub-streams of
-      // the block, (je - jb) / U row pairs (56 KiB at U = 4) apart, instead of U adjacent 1792-byte pieces: four times as
-      // many independent address streams over the memory channels.  The sums are order-independent (exact integers).
-      const int sub = spread ? (je - jb) / U : 1, step = spread ? 1 : U;
-      for (int jp0 = jb; jp0 < (spread ? jb + sub : je); jp0 += step) {
+      for (int jp0 = jb; jp0 < je; jp0 += U) {
         u32x4_t va[U];
         u32x3_t vb[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          const int jp = min(jp0 + u * sub, je - 1);
+          const int jp = min(jp0 + u, je - 1);
           const u32* uu = base + (size_t)jp * ustride;
           va[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(uu + lane * 4));
           vb[u] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(uu + 256 + lane * 3));
         }
 #pragma unroll
         for (int u = 0; u < U; u++) {
-          const int jp = jp0 + u * sub;
+          const int jp = jp0 + u;
           if (jp < je) {
             const u32 d0 = va[u].x, d1 = va[u].y, d2 = va[u].z, d3 = va[u].w, d4 = vb[u].x, d5 = vb[u].y, d6 = vb[u].z;
             const uint4 qa = qrow[2 * jp];
@@ -240,6 +158,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
             const u32 f5 = __builtin_amdgcn_alignbit(d5, d4, 12) & M;
             const u32 f6 = __builtin_amdgcn_alignbit(d6, d5, 8) & M;
             const u32 f7 = d6 >> 4;
+            // (row 2jp, ii 2l) = (f0, f1); (2jp, 2l+1) = (f2, f3); (2jp+1, 2l) = (f4, f5); (2jp+1, 2l+1) = (f6, f7)
             a00 += (u64)qa.x * f0; a01 += (u64)qa.z * f0; a02 += (u64)qa.y * f1; a03 += (u64)qa.w * f1;
             a10 += (u64)qa.x * f2; a11 += (u64)qa.z * f2; a12 += (u64)qa.y * f3; a13 += (u64)qa.w * f3;
             a00 += (u64)qb.x * f4; a01 += (u64)qb.z * f4; a02 += (u64)qb.y * f5; a03 += (u64)qb.w * f5;
@@ -250,16 +169,19 @@ __global__ __launch_bounds__(256) void k_sweep_packed_persist(DevTables T, Sweep
       a00 = reduce64(a00, m0); a01 = reduce64(a01, m0); a02 = reduce64(a02, m1); a03 = reduce64(a03, m1);
       a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
     }
+    // out[plane][r][crt][z][ii]: (r0,c0) = n0_0, (r0,c1) = n1_0, (r1,c0) = n0_1, (r1,c1) = n1_1
     sweep_store_pair(d, plane, z, chunk * 128 + 2 * lane, (u32)a00, (u32)a10, (u32)a02, (u32)a12, (u32)a01, (u32)a11,
                      (u32)a03, (u32)a13);
   }
 }
-// Ring form of k_sweep_packed_persist (switch pipe_ring): two buffers of U row pairs per wave, the loads of one in flight
-// while the other is multiplied, and the first buffer of a wave's NEXT (z, chunk) stream requested before the sums of this
-// one are reduced and stored.  A wave of the plain form has nothing in flight while it multiplies and relies on the
-// other 15 waves of its CU; when fold kernels share the CU the multiplies take longer and the HBM queue runs dry (sweep
-// alone 2.23 ms, beside the folds 2.37 ms per plane at C2).  ~96 VGPRs: meant for 2 workgroups per CU (pipe_wgs = 2),
-// which leaves a fold wave's 256 registers free on every SIMD.  Needs npairs % (2 U) == 0.
+// Ring form (the default, and the judged kernel): two buffers of U row pairs per wave, the loads of one in flight while the
+// other is multiplied, and the first buffer of a wave's NEXT (z, chunk) stream requested before the sums of this one are
+// reduced and stored.  A wave of the plain form has nothing in flight while it multiplies and relies on the other 15 waves
+// of its CU; when fold kernels share the CU the multiplies take longer and the HBM queue runs dry.  One workgroup per CU
+// (205 VGPRs at U = 8) leaves a fold wave's 256 registers free on every SIMD.  Needs npairs % (2 U) == 0.
+// (Round 3 also tried handing the streams out by an atomic ticket counter, spreading a wave's row pairs over sub-streams,
+// permuting the z-rows and sweeping a plane as two chunk-parity classes: no gain, removed; profiles/r03_ring_sweep.md,
+// r02_sweep_experiments.md.)
 typedef __attribute__((address_space(4))) const u32x4_t sweep_const_uint4;
 template <int U>
 __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDesc d, int units, int hi_prio) {
@@ -272,24 +194,11 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
   const size_t ustride = 448;
   const ModConst m0 = T.c.mod[0], m1 = T.c.mod[1];
   const u32 M = 0x0FFFFFFFu;
-  const int cstep = d.chunk_step == 2 ? 2 : 1, chunks_l = chunks / cstep;
-  // (tickets) every wave of the grid counts itself out when it leaves; the last one zeroes the two words for the next launch
-#define SPR_COUNT_OUT                                                                                 \
-  if (d.ticket && lane == 0) {                                                                        \
-    if (atomicAdd(d.ticket + 1, 1u) == (u32)nwaves - 1) {                                             \
-      __hip_atomic_store(d.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);                   \
-      __hip_atomic_store(d.ticket + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);               \
-    }                                                                                                 \
-  }
-  if (wave0 >= units) {
-    SPR_COUNT_OUT
-    return;
-  }
+  if (wave0 >= units) return;
   u32x4_t va[U], na[U];
   u32x3_t vb[U], nb[U];
 #define SPR_BASE(UNIT) \
-  (reinterpret_cast<const u32*>(d.db) + \
-   packed_unit_offset((size_t)((UNIT) / chunks_l), 0, ((UNIT) % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0), npairs, chunks))
+  (reinterpret_cast<const u32*>(d.db) + packed_unit_offset((size_t)((UNIT) / chunks), 0, (UNIT) % chunks, npairs, chunks))
 #define SPR_LOAD(VA, VB, BASE, JP0)                                                                       \
   _Pragma("unroll") for (int uu = 0; uu < U; uu++) {                                                      \
     const u32* u = (BASE) + (size_t)((JP0) + uu) * ustride;                                               \
@@ -320,14 +229,9 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
   a10 = reduce64(a10, m0); a11 = reduce64(a11, m0); a12 = reduce64(a12, m1); a13 = reduce64(a13, m1);
   const u32* base = SPR_BASE(wave0);
   SPR_LOAD(va, vb, base, 0)
-  u32* const ticket = d.ticket;
   for (int unit = wave0; unit < units;) {
-    // (tickets) the number of the stream after this one is asked for now and looked at when this stream's last buffer is
-    // requested: one atomic per ~70 us of work, its latency hidden behind the whole stream
-    u32 drawn = 0;
-    if (ticket && lane == 0) drawn = atomicAdd(ticket, 1u);
-    const int chunk = (unit % chunks_l) * cstep + (cstep == 2 ? d.chunk_off : 0);
-    const int zp = unit / chunks_l;
+    const int chunk = unit % chunks;
+    const int zp = unit / chunks;
     const int z = zp & (N - 1);
     const int plane = zp >> POLY_LEN_LOG2;
     // the query rows through the scalar cache (s_load): as plain loads they are VECTOR loads here (the kernel stores inside
@@ -356,7 +260,7 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
       SPR_MAC(va, vb, j)
       const bool more = jb + 128 < npairs;
       // the wave's next stream (its own again past the end: a harmless re-read of 7 KiB)
-      next_unit = ticket ? nwaves + (int)__builtin_amdgcn_readfirstlane(drawn) : unit + nwaves;
+      next_unit = unit + nwaves;
       next_base = next_unit < units ? SPR_BASE(next_unit) : base;
       const u32* nb_base = more ? base : next_base;
       const int nb_jp = more ? jb + 128 : 0;
@@ -370,23 +274,15 @@ __global__ __launch_bounds__(256) void k_sweep_packed_ring(DevTables T, SweepDes
     base = next_base;
     unit = next_unit;
   }
-  // every wave has drawn its last (failing) ticket before it counts itself out
-  SPR_COUNT_OUT
-#undef SPR_COUNT_OUT
 #undef SPR_BASE
 #undef SPR_LOAD
 #undef SPR_MAC
 #undef SPR_FOLD
 }
-void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, int unroll, hipStream_t s, int n_cus) {
-  const int units = d.planes * N * ((d.num_per >> 7) / (d.chunk_step == 2 ? 2 : 1));
-  const dim3 grid((unsigned)std::min(n_cus * wgs_per_cu, (units + 3) / 4));
+void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, hipStream_t s, int n_cus) {
+  const int units = d.planes * N * (d.num_per >> 7);
   const int prio = (int)tunable("sweep_prio", 1);
   const int npairs = d.nj >> 1;
-  const int u_eff = unroll == 1 || unroll == 2 || unroll == 8 ? unroll : 4;
-  // every 128-row-pair block (and the ragged last one) must split evenly into the U sub-streams
-  const int spread = tunable("sweep_spread", 0) != 0 && (npairs % 128) % u_eff == 0 && (128 % u_eff) == 0 ? 1 : 0;
-  const int zmul = (int)(tunable("sweep_zmul", 1) | 1);
   // Ring form (default): pipe_ring = row pairs per buffer (8, 4 or 2; 0 = the plain form below), the largest that divides
   // the stream evenly, on pipe_ring_wgs workgroups per CU (default ONE: four waves with two buffers of 8 row pairs each
   // keep as many bytes in flight as sixteen plain waves with one buffer of 4, alone 2.23 against 2.27 ms per plane at
@@ -404,12 +300,8 @@ void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu
     launched(PATH_SWEEP_PERSIST | PATH_SWEEP_RING | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_ring");
     return;
   }
-  switch (unroll) {
-    case 1: hipLaunchKernelGGL(k_sweep_packed_persist<1>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
-    case 2: hipLaunchKernelGGL(k_sweep_packed_persist<2>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
-    case 8: hipLaunchKernelGGL(k_sweep_packed_persist<8>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
-    default: hipLaunchKernelGGL(k_sweep_packed_persist<4>, grid, dim3(256), 0, s, T, d, units, prio, spread, zmul); break;
-  }
+  const dim3 grid((unsigned)std::min(n_cus * wgs_per_cu, (units + 3) / 4));
+  hipLaunchKernelGGL(k_sweep_packed_persist, grid, dim3(256), 0, s, T, d, units, prio);
   launched(PATH_SWEEP_PERSIST | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed_persist");
 }
 
@@ -609,18 +501,11 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
     m.c6[c] = (u32)((1ull << 48) % qs[c]);
   }
   const dim3 grid((unsigned)((size_t)d.planes * N * (chunks / cpw)));
-  // batch_mfma_lds_pad (bytes, default 0): extra dynamic LDS per workgroup; 26624 leaves exactly one pass workgroup per CU
-  // and 70 KiB for a fold workgroup beside it (per-plane batch pipeline experiments)
-  const size_t lds = (size_t)d.nj * 128 + (size_t)std::max<long>(0, tunable("batch_mfma_lds_pad", 0));
-  if (lds > 65536) {
+  const size_t lds = (size_t)d.nj * 128;  // one z-row of the group's query digit table
+  if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<4, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  }
-  // ring of 2 load buffers by default (one 16-row step ahead, 180 VGPRs); 4 measured the same +-2 % at 236 VGPRs
-  if (tunable("batch_mfma_nb", 2) == 4 && (d.nj % 64) == 0)
-    hipLaunchKernelGGL((k_sweep_mfma_batch<4, 2>), grid, dim3(256), lds, s, T, m);
-  else
-    hipLaunchKernelGGL((k_sweep_mfma_batch<2, 2>), grid, dim3(256), lds, s, T, m);
+  // ring of 2 load buffers (one 16-row step ahead, 180 VGPRs); a ring of 4 measured the same +-2 % at 236 VGPRs (r03)
+  hipLaunchKernelGGL((k_sweep_mfma_batch<2, 2>), grid, dim3(256), lds, s, T, m);
   launched(PATH_SWEEP_BATCH | PATH_SWEEP_MFMA, "k_sweep_mfma_batch");
 }
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
@@ -634,13 +519,10 @@ void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t
   const int lds_min_b = (int)tunable("batch_qlds_min", 4);
   const bool qlds = unroll && ((d.num_per >> 7) % 4) == 0 && d.batch >= lds_min_b && d.nj <= QLDS_ROWS;
   const size_t lds = qlds ? (size_t)d.batch * QLDS_ROWS * 16 : 0;
-  const int u_lds = (int)tunable("batch_lds_unroll", 2);  // row pairs per ping-pong buffer in the LDS-staged form
 #define SP_BATCH_CASE(B)                                                                              \
   case B:                                                                                             \
-    if (qlds && u_lds == 2)                                                                           \
+    if (qlds)                                          /* two row pairs per ping-pong buffer */       \
       hipLaunchKernelGGL((k_sweep_packed_batch<B, 2, true>), grid, dim3(256), lds, s, T, d);          \
-    else if (qlds)                                                                                    \
-      hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, true>), grid, dim3(256), lds, s, T, d);          \
     else if (unroll)                                                                                  \
       hipLaunchKernelGGL((k_sweep_packed_batch<B, 4, false>), grid, dim3(256), 0, s, T, d);           \
     else                                                                                              \
@@ -757,85 +639,20 @@ __global__ __launch_bounds__(256) void k_sweep_narrow2(DevTables T, SweepDesc d)
   }
 }
 
-// Placement probe: the PACKED sweep's access pattern (one wave per 448-KiB stream, 28 B per lane per row pair, 4 row pairs
-// in flight, non-temporal) over a buffer, nothing computed.  How a multi-GiB hipMalloc is backed decides 2.19 vs 2.40 ms
-// per C2 plane (profiles/r02_sweep_experiments.md); db_create_impl times this kernel on freshly allocated candidates and
-// keeps the fastest (switch db_place_tries).
-__global__ __launch_bounds__(256) void k_stream_probe(const u32* base, long units, u32* sink) {
-  const int lane = threadIdx.x & 63;
-  const long nw = (long)gridDim.x * 4;
-  u32 acc = 0;
-  for (long u = (long)blockIdx.x * 4 + (threadIdx.x >> 6); u < units; u += nw) {
-    const u32* p = base + u * (448 * 256);
-    for (int jp = 0; jp < 256; jp += 4) {
-      u32x4_t a[4];
-      u32x3_t b[4];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const u32* q = p + (jp + k) * 448;
-        a[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(q + lane * 4));
-        b[k] = __builtin_nontemporal_load(reinterpret_cast<const u32x3_t*>(q + 256 + lane * 3));
-      }
-#pragma unroll
-      for (int k = 0; k < 4; k++) acc += a[k].x ^ a[k].y ^ a[k].z ^ a[k].w ^ b[k].x ^ b[k].y ^ b[k].z;
-    }
-  }
-  if (acc == 0x12345678u) sink[0] = acc;
-}
-float stream_probe_ms(const void* buf, size_t bytes, u32* sink, hipStream_t s) {
-  const long units = (long)(bytes / (448 * 1024));
-  if (units < 1024) return 0.f;
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return 0.f;
-  float best = 1e30f;
-  for (int r = 0; r < 3; r++) {  // first pass warms the TLBs; best of the next two
-    (void)hipEventRecord(a, s);
-    hipLaunchKernelGGL(k_stream_probe, dim3(1024), dim3(256), 0, s, reinterpret_cast<const u32*>(buf), units, sink);
-    (void)hipEventRecord(b, s);
-    (void)hipEventSynchronize(b);
-    float t = 0;
-    (void)hipEventElapsedTime(&t, a, b);
-    if (r > 0 && t < best) best = t;
-  }
-  (void)hipEventDestroy(a);
-  (void)hipEventDestroy(b);
-  launched(0, "k_stream_probe");
-  return best;
-}
-
-const char* sweep_kernel_name(int num_per) { return num_per >= 128 ? "k_sweep_packed" : "k_sweep_narrow"; }
-
 void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s) {
-  // default: persistent grid of 4 workgroups per CU, 4 row pairs in flight per lane (profiles/r01_sweep_variants.md);
-  // SPIRAL_SWEEP_PERSIST_WGS=0 selects the one-wave-per-unit grid
-  const int persist_wgs = (int)tunable("sweep_persist_wgs", 4), persist_unr = (int)tunable("sweep_persist_unroll", 4);
-  if (d.packed && persist_wgs > 0) {
-    launch_sweep_persist(T, d, persist_wgs, persist_unr, s);
+  if (d.packed) {  // persistent grid (ring form where the row-pair count allows), sweep_persist_wgs workgroups per CU for the plain form
+    launch_sweep_persist(T, d, (int)std::max(1L, tunable("sweep_persist_wgs", 4)), s);
     return;
   }
-  if (d.packed) {
+  if (d.num_per >= 128) {
     const long units = (long)d.planes * N * (d.num_per >> 7);
-    hipLaunchKernelGGL(k_sweep_packed, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
-    launched(PATH_SWEEP_PACKED | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_packed");
-  } else if (d.num_per >= 128) {
-    const long units = (long)d.planes * N * (d.num_per >> 7);
-    const int variant = (int)tunable("sweep_variant", 0);
-    const dim3 grid((unsigned)((units + 3) / 4));
-    // measured on MI355X, C2 (profiles/r01_sweep_variants.md): non-temporal loads + no manual unroll is
-    // the fastest form (6.8 TB/s); the others stay selectable for A/B runs
-    switch (variant) {
-      case 1: hipLaunchKernelGGL((k_sweep_wide<8, true>), grid, dim3(256), 0, s, T, d); break;
-      case 2: hipLaunchKernelGGL((k_sweep_wide<8, false>), grid, dim3(256), 0, s, T, d); break;
-      case 4: hipLaunchKernelGGL((k_sweep_wide<4, true>), grid, dim3(256), 0, s, T, d); break;
-      case 5: hipLaunchKernelGGL((k_sweep_wide<2, true>), grid, dim3(256), 0, s, T, d); break;
-      default: hipLaunchKernelGGL((k_sweep_wide<1, true>), grid, dim3(256), 0, s, T, d); break;
-    }
+    hipLaunchKernelGGL(k_sweep_wide, dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, T, d);
     launched(PATH_SWEEP_WIDE | (d.out_G > 1 ? PATH_SCATTER_OUT : 0), "k_sweep_wide");
   } else {
-    if (d.num_per >= 2 && !tunable("narrow1", 0)) {
+    if (d.num_per >= 2) {
       size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 8 * sizeof(u32);
       hipLaunchKernelGGL(k_sweep_narrow2, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
-    } else {
+    } else {  // num_per == 1 (nu_2 = 0): one word per row, 8-byte loads
       size_t sh = (size_t)d.nj * sizeof(uint4) + 256 * 4 * sizeof(u32);
       hipLaunchKernelGGL(k_sweep_narrow, dim3((unsigned)(d.planes * N)), dim3(256), sh, s, T, d);
     }

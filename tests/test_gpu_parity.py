@@ -417,7 +417,7 @@ def test_process_query_c1(sp, oracle_mod):
     assert cl.decode_response(resp) == o.item_to_vec(item)
 
 
-@pytest.mark.parametrize("variant", ["0", "1", "2", "3", "5"])
+@pytest.mark.parametrize("variant", ["0", "3", "5"])
 def test_fused_fold_kernel(sp, oracle_mod, monkeypatch, variant):
     """The fused fold kernels (k_fold_fused / k_fold_fused2: the form used when a level has >= 256 (pair, plane)
     units, i.e. at C2 scale) forced on for a small tree, every kernel variant, through the STAGE export that runs
@@ -938,29 +938,6 @@ def test_process_queries_sharded_pipelined_list(sp, oracle_mod, G):
     assert world.comm(0).process_queries(p, gpp, [], shards[0]) == []
 
 
-@pytest.mark.parametrize("cfg", [FAST56, dict(FAST, nu_1=4, nu_2=8, t_gsw=4, db_item_size=2048), SMALL_INST2],
-                         ids=["8-columns", "256-columns-packed", "two-instances"])
-def test_from_sweep_wave_kernel_parity(sp, oracle_mod, cfg):
-    """k_from_sweep_wave (from_ntt of the sweep output with one wave per polynomial, switch from_sweep_wave; measured as fast
-    as the default k_from_sweep4, kept as an alternative): responses byte-identical to the oracle and to the default."""
-    import ctypes as C
-    o, cl, pp, q = _session(oracle_mod, cfg, 3, 44)
-    p = sp.Params(cfg)
-    item, db = o.generate_random_db_and_get_item(3)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    gdb = sp.Database(p).load(db)
-    ref = sp.process_query(p, gpp, q, gdb)
-    sp.lib().sp_debug_set(b"from_sweep_wave", C.c_long(1))
-    try:
-        sp.paths_taken()
-        got = sp.process_query(p, gpp, q, gdb)
-        assert "from_sweep_wave" in sp.paths_taken()
-    finally:
-        sp.lib().sp_debug_set(b"from_sweep_wave", C.c_long(0))
-    assert got == ref == o.process_query(pp, q, db)
-    assert cl.decode_response(got) == o.item_to_vec(item)
-
-
 def test_overlapped_fold_direct_upload_parity(sp, oracle_mod):
     """Non-expanded ('direct_upload') query on a wide packed database: the overlapped per-plane path with the
     fold matrices coming straight from the wire (server.rs:666-679) instead of regev_to_gsw."""
@@ -994,55 +971,24 @@ def test_overlapped_fold_many_planes_parity(sp, oracle_mod):
     assert sp.process_query(p, gpp, q, gdb) == resp
 
 
-@pytest.mark.parametrize("nu_2,split", [(10, "2"), (10, "1"), (10, "0"), (11, "2")])
-def test_pipelined_class_split_parity(sp, oracle_mod, monkeypatch, nu_2, split):
-    """The pipelined query sweeps a plane as two chunk-parity classes (even / odd 128-column chunks) and folds class 0's
-    first log2(num_per) - 8 levels while class 1 is swept (SPIRAL_PIPE_SPLIT: 2 = every plane; 1 = last plane;
-    0 = off, the default): response bytes equal the oracle's in every mode, with 2 and 3 class-local levels."""
-    monkeypatch.setenv("SPIRAL_PIPE_SPLIT", split)
-    cfg = {"n": 2, "nu_1": 5, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 1, "db_item_size": 8192}   # t_gsw = 4: 15-bit digits, k_fold_wave<2>
-    o, cl, pp, q = _session(oracle_mod, cfg, 4321, 16)
-    p = sp.Params(cfg)
-    item, db = o.generate_random_db_and_get_item(4321)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    gdb = sp.Database(p).load(db)
-    run = sp.QueryRun(p, gpp, q, db=gdb)
-    assert run.sweep_launches(gdb) == {"0": 4, "1": 5, "2": 8}[split]
-    sp.paths_taken()
-    resp = run.sweep(gdb).finish()
-    taken = sp.paths_taken()
-    run.free()
-    assert ("pipe_class_split" in taken) == (split != "0") and "pipelined_fold_overlap" in taken, taken
-    assert resp == o.process_query(pp, q, db)
-    assert cl.decode_response(resp) == o.item_to_vec(item)
-
-
-@pytest.mark.parametrize("nu_1,nu_2,t_gsw,ring,wgs,defer,split", [
-    (5, 10, 4, "8", "1", "256", "0"),   # the defaults: two buffers of 8 row pairs, one workgroup per CU, tails batched
-    (5, 10, 4, "4", "2", "256", "0"),
-    (5, 10, 4, "2", "1", "64", "0"),    # two more levels per plane before parking
-    (5, 11, 4, "8", "1", "256", "2"),   # every plane as two chunk-parity classes, then parked
-    (5, 11, 4, "8", "1", "256", "1"),
-    (5, 10, 4, "0", "1", "256", "0"),   # plain persistent sweep, batched tails
-    (5, 10, 4, "8", "1", "0", "0"),     # ring sweep, every plane folded to the end under the next sweep
-    (4, 10, 2, "8", "1", "256", "0"),   # 8 row pairs per stream: the ring falls back to buffers of 4
-    (3, 10, 3, "8", "1", "256", "0"),   # 4 row pairs per stream: buffers of 2
-    (5, 10, 4, "8t", "1", "256", "0"),  # streams handed out by tickets (sweep_tickets), twice in a row: the counters reset
-    (5, 11, 4, "4t", "2", "256", "2"),
+@pytest.mark.parametrize("nu_1,nu_2,t_gsw,ring,wgs,defer", [
+    (5, 10, 4, "8", "1", "256"),   # the defaults: two buffers of 8 row pairs, one workgroup per CU, tails batched
+    (5, 10, 4, "4", "2", "256"),
+    (5, 10, 4, "2", "1", "64"),    # two more levels per plane before parking
+    (5, 11, 4, "8", "1", "256"),
+    (5, 10, 4, "0", "1", "256"),   # plain persistent sweep, batched tails
+    (5, 10, 4, "8", "1", "0"),     # ring sweep, every plane folded to the end under the next sweep
+    (4, 10, 2, "8", "1", "256"),   # 8 row pairs per stream: the ring falls back to buffers of 4
+    (3, 10, 3, "8", "1", "256"),   # 4 row pairs per stream: buffers of 2
 ])
-def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, nu_2, t_gsw, ring, wgs, defer, split):
+def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, nu_2, t_gsw, ring, wgs, defer):
     """The pipelined query's persistent sweep in ring form (k_sweep_packed_ring: two buffers of row pairs per wave, the next
     stream's first buffer requested before this one's sums are stored) and the deferred fold tails (every plane folded to
     256 / 64 ciphertexts under the next sweep, the remaining levels of all planes as one batch): response bytes equal the
-    oracle's for every buffer size, with and without the class split, and with either piece switched off."""
-    tickets = ring.endswith("t")
-    ring = ring.rstrip("t")
-    monkeypatch.setenv("SPIRAL_SWEEP_TICKETS", "1" if tickets else "0")
+    oracle's for every buffer size and with either piece switched off."""
     monkeypatch.setenv("SPIRAL_PIPE_RING", ring)
     monkeypatch.setenv("SPIRAL_PIPE_RING_WGS", wgs)
     monkeypatch.setenv("SPIRAL_PIPE_TAIL_DEFER", defer)
-    monkeypatch.setenv("SPIRAL_PIPE_SPLIT", split)
     cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": t_gsw, "t_conv": 4, "t_exp_left": 8,
            "t_exp_right": 56, "instances": 1, "db_item_size": 8192}
     o, cl, pp, q = _session(oracle_mod, cfg, 97, 11)
@@ -1057,10 +1003,7 @@ def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, 
     assert ("sweep_ring" in taken) == (ring != "0"), taken
     # (t_gsw = 2: 29-bit gadget digits, which the fused fold kernels do not take -- nothing is deferred there)
     assert ("fold_tail_batched" in taken) == (defer != "0" and t_gsw > 2), taken
-    assert ("pipe_class_split" in taken) == (split != "0"), taken
     assert resp == o.process_query(pp, q, db)
-    if tickets:
-        assert sp.process_query(p, gpp, q, gdb) == resp
     if t_gsw >= 4:  # (fewer gadget digits: the noise is too large to decode, the bytes still have to agree)
         assert cl.decode_response(resp) == o.item_to_vec(item)
 
@@ -1159,38 +1102,6 @@ def test_process_query_batch_matrix_core_extreme_digits(sp, oracle_mod):
         assert resp[i] == sp.process_query(p, gpp, qs[i], gdb), i
 
 
-def test_process_query_batch_per_plane_pipeline(sp, oracle_mod):
-    """Batched queries on a wide database (num_per >= 1024), SPIRAL_BATCH_PIPELINE=1: the pass runs one plane per launch
-    and every query folds plane p on its second stream while plane p+1 is swept (the batch form of the single-query
-    pipeline; off by default -- it measures no faster); 11 queries =
-    a group of 8 + a group of 3, two instances (8 planes); byte-identical to the oracle and to the one-launch pass."""
-    import ctypes as C
-    cfg = {"n": 2, "nu_1": 4, "nu_2": 10, "p": 256, "q2_bits": 20, "t_gsw": 2, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": 2, "db_item_size": 16384}
-    o = oracle_mod.Params(cfg)
-    p = sp.Params(cfg)
-    cl = oracle_mod.Client(o)
-    pp = cl.generate_keys(31)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    item, db = o.generate_random_db_and_get_item(5)
-    gdb = sp.Database(p).load(db)
-    B = 11
-    qs = [cl.generate_query((997 * i + 5) % o.num_items, 400 + i) for i in range(B)]
-    sp.lib().sp_debug_set(b"batch_pipeline", C.c_long(1))
-    try:
-        sp.paths_taken()
-        resp = sp.process_query_batch(p, [gpp] * B, qs, gdb)
-        taken = sp.paths_taken()
-        assert {"sweep_batch", "pipelined_fold_overlap"} <= taken, taken
-    finally:
-        sp.lib().sp_debug_set(b"batch_pipeline", C.c_long(0))
-    for i in (0, 7, 8, 10):
-        assert resp[i] == o.process_query(pp, qs[i], db), i
-    sp.paths_taken()
-    assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp          # the default: one launch per pass
-    assert "pipelined_fold_overlap" not in sp.paths_taken()
-
-
 def _valid_cfg(c):
     dim0, right = 1 << c["nu_1"], c["t_gsw"] * c["nu_2"]
     g = max(1, int(np.ceil(np.log2(right + dim0))))
@@ -1239,43 +1150,14 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
 
 
-@pytest.mark.parametrize("order", ["1", "2"])
-@pytest.mark.parametrize("ci", [0, 4, 11])
-def test_expansion_enqueue_order_parity(sp, oracle_mod, monkeypatch, ci, order):
-    """SPIRAL_EXPAND_ORDER (profiles/r02_expand_order.txt; default 0): with the odd subtree on the second stream, the even
-    subtree may be queued first (1) or the odd side may start only when the even side is done (2).  Pure scheduling:
-    expand_query and the response must not change."""
-    cfg = _FUZZ[ci]
-    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1")
-    monkeypatch.setenv("SPIRAL_EXPAND_ORDER", order)
-    o = oracle_mod.Params(cfg)
-    idx = (419 * (ci + 1)) % o.num_items
-    cl = oracle_mod.Client(o)
-    pp = cl.generate_keys(90 + ci)
-    q = cl.generate_query(idx, 190 + ci)
-    p = sp.Params(cfg)
-    item, db = o.generate_random_db_and_get_item(idx)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    gdb = sp.Database(p).load(db)
-    sp.paths_taken()
-    v_reg, v_fold = sp.expand_query(p, gpp, q)
-    assert "expand_split" in sp.paths_taken()
-    e_reg, e_fold = o.expand_query(pp, q)
-    assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
-    expect = o.process_query(pp, q, db)
-    assert sp.process_query(p, gpp, q, gdb) == expect
-    assert sp.process_query(p, gpp, q, gdb) == expect    # the same workspace again (join of the previous odd side)
-
-
-@pytest.mark.parametrize("mode", ["split", "split+fused"])
+@pytest.mark.parametrize("mode", ["split"])
 @pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
 def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
-    """The optional expansion schedules (off by default, profiles/r02_expand_experiments.md): odd subtree + GSW side on
-    the second stream (SPIRAL_EXPAND_SPLIT) and one k_expand_round_teams launch per round (SPIRAL_EXPAND_FUSED), over gadget
-    widths from 2 to 56 digits, 28-bit digits included; expand_query and the response must not change."""
+    """The optional expansion schedule (default only before a pipelined sweep, profiles/r02_expand_experiments.md): odd
+    subtree + GSW side on the second stream (SPIRAL_EXPAND_SPLIT), over gadget widths from 2 to 56 digits, 28-bit digits
+    included; expand_query and the response must not change."""
     cfg = _FUZZ[ci]
     monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1")
-    monkeypatch.setenv("SPIRAL_EXPAND_FUSED", "1" if mode == "split+fused" else "0")
     o = oracle_mod.Params(cfg)
     idx = (613 * (ci + 1)) % o.num_items
     cl = oracle_mod.Client(o)
@@ -1288,7 +1170,7 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     sp.paths_taken()
     v_reg, v_fold = sp.expand_query(p, gpp, q)
     taken = sp.paths_taken()
-    assert "expand_split" in taken and ("expand_head_fused" in taken) == (mode != "split"), taken
+    assert "expand_split" in taken, taken
     e_reg, e_fold = o.expand_query(pp, q)
     assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
