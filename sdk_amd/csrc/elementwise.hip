@@ -1,6 +1,7 @@
 // NTT-domain multiply-accumulate and the small elementwise kernels of the answer path (poly.rs:351-663, gadget.rs:34-60,
 // util.rs:323-355, server.rs:470-517).
 #include "device_common.hpp"
+#include "bodies.hpp"
 
 namespace spiral {
 
@@ -8,72 +9,17 @@ namespace spiral {
 // NTT-domain multiply-accumulate.  grid (batch, 2N/256[, outer]), one (crt, z) per thread.  The batch runs along
 // grid.x: it is unbounded (num_per * planes on the unfused fold path), grid.y / grid.z are limited to 65535.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void mac_body(const DevTables& T, const MacDesc& d, int inner, int outer) {
-  const int e = blockIdx.y * 256 + threadIdx.x;  // index into [crt][z]
-  const int c = e >> POLY_LEN_LOG2;
-  const int b = outer * d.batch_inner + inner;
-  const ModConst m = T.c.mod[c];
-  const u32* B = d.B + ((size_t)outer * d.B_outer_stride + (size_t)inner * d.B_inner_stride) * 2 * N + e;
-  const long ob = d.out_idx ? (long)d.out_idx[b] : (long)b * d.out_batch_stride;
-  const size_t PW = 2 * N;
-  for (int r = 0; r < d.R; r++) {
-    const u32* A = d.A + (size_t)r * (d.A_row_stride ? d.A_row_stride : d.K) * PW + e;
-    const long op = (ob + (long)r * d.out_row_stride) * 2 * N + e;
-    u64 acc = d.addend ? (u64)d.addend[op] : 0ULL;
-    if (d.extra && r == d.extra_row) acc += (u64)d.extra[(size_t)(d.extra_idx ? d.extra_idx[b] : b) * PW + e];
-    // two segments of B (k < split_k, k >= split_k), each walked 8 operands at a time with all 16
-    // loads issued before the multiplies: small batches are latency-bound, not bandwidth-bound.
-    // products < 2^56: <= 64 terms between Barrett folds stay < 2^63.
-    for (int seg = 0; seg < 2; seg++) {
-      const int k_lo = seg == 0 ? 0 : d.split_k, k_hi = seg == 0 ? min(d.split_k, d.K) : d.K;
-      const u32* Bs = seg == 0 ? B : B + (size_t)(d.split_off - d.split_k) * PW;
-      int k = k_lo, since = 0;
-      for (; k + 28 <= k_hi; k += 28) {  // 56 loads in flight: the small expansion rounds are pure latency
-        u32 a[28], bb[28];
-#pragma unroll
-        for (int u = 0; u < 28; u++) {
-          a[u] = A[(size_t)(k + u) * PW];
-          bb[u] = Bs[(size_t)(k + u) * PW];
-        }
-#pragma unroll
-        for (int u = 0; u < 28; u++) acc += (u64)a[u] * (u64)bb[u];
-        since += 28;
-        if (since >= 56) {
-          acc = reduce64(acc, m);
-          since = 0;
-        }
-      }
-      for (; k + 8 <= k_hi; k += 8) {
-        u32 a[8], bb[8];
-#pragma unroll
-        for (int u = 0; u < 8; u++) {
-          a[u] = A[(size_t)(k + u) * PW];
-          bb[u] = Bs[(size_t)(k + u) * PW];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; u++) acc += (u64)a[u] * (u64)bb[u];
-        since += 8;
-        if (since >= 64) {
-          acc = reduce64(acc, m);
-          since = 0;
-        }
-      }
-      for (; k < k_hi; k++) acc += (u64)A[(size_t)k * PW] * (u64)Bs[(size_t)k * PW];
-      acc = reduce64(acc, m);
-    }
-    d.out[op] = (u32)acc;
-  }
-}
-__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.x, blockIdx.z); }
+__global__ __launch_bounds__(256) void k_mac(DevTables T, MacDesc d) { mac_body(T, d, blockIdx.x, blockIdx.z, blockIdx.y); }
 __global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d1) {
   const int y = blockIdx.x;
   if (y < d0.batch_inner)
-    mac_body(T, d0, y, 0);
+    mac_body(T, d0, y, 0, blockIdx.y);
   else
-    mac_body(T, d1, y - d0.batch_inner, 0);
+    mac_body(T, d1, y - d0.batch_inner, 0, blockIdx.y);
 }
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
   if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
+  if (program_record(d)) return;
   hipLaunchKernelGGL(k_mac, dim3(d.batch_inner, 2 * N / 256, d.batch_outer), dim3(256), 0, s, T, d);
   launched(0, "k_mac");
 }
@@ -82,19 +28,17 @@ void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipSt
   a.batch_inner = std::max(a.batch_inner, 0);
   b.batch_inner = std::max(b.batch_inner, 0);
   if (a.batch_inner + b.batch_inner <= 0) return;
+  if (program_record(a, b)) return;
   hipLaunchKernelGGL(k_mac2, dim3(a.batch_inner + b.batch_inner, 2 * N / 256, 1), dim3(256), 0, s, T, a, b);
   launched(0, "k_mac2");
 }
 
 __global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, const int* idx, const u32* src) {
-  const int e = blockIdx.y * 256 + threadIdx.x;
-  const int c = e >> POLY_LEN_LOG2;
-  const int b = blockIdx.x;
-  const long dp = (long)idx[b] * 2 * N + e;
-  dst[dp] = add_mod(dst[dp], src[(size_t)b * 2 * N + e], T.c.mod[c].q);
+  add_poly_into_body(T, dst, idx, src, blockIdx.x, blockIdx.y);
 }
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s) {
   if (batch <= 0) return;
+  if (program_record(AddPolyIntoDesc{dst, idx, src, batch})) return;
   hipLaunchKernelGGL(k_add_poly_into, dim3(batch, 2 * N / 256), dim3(256), 0, s, T, dst, idx, src);
   launched(0, "k_add_poly_into");
 }
@@ -148,18 +92,13 @@ void launch_interleave_query(u64* qv, const u32* row0_ntt, const u64* wire, int 
   launched(0, "k_interleave_query");
 }
 
-__global__ __launch_bounds__(256) void k_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src,
-                                                    const int* src_idx, int src_row_stride, int R) {
-  const int e = blockIdx.y * 256 + threadIdx.x;
-  const int b = blockIdx.x / R, r = blockIdx.x % R;
-  dst[((long)dst_idx[b] + (long)r * dst_row_stride) * 2 * N + e] =
-      src[((long)src_idx[b] + (long)r * src_row_stride) * 2 * N + e];
-}
+__global__ __launch_bounds__(256) void k_copy_polys(CopyPolysDesc d) { copy_polys_body(d, blockIdx.x, blockIdx.y); }
 void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx,
                        int src_row_stride, int R, int batch, hipStream_t s) {
   if (batch <= 0) return;
-  hipLaunchKernelGGL(k_copy_polys, dim3(batch * R, 2 * N / 256), dim3(256), 0, s, dst, dst_idx, dst_row_stride, src,
-                     src_idx, src_row_stride, R);
+  const CopyPolysDesc d{dst, dst_idx, dst_row_stride, src, src_idx, src_row_stride, R, batch};
+  if (program_record(d)) return;
+  hipLaunchKernelGGL(k_copy_polys, dim3(batch * R, 2 * N / 256), dim3(256), 0, s, d);
   launched(0, "k_copy_polys");
 }
 
@@ -191,25 +130,20 @@ __global__ __launch_bounds__(256) void k_copy_words(u32* dst, const u32* src, si
 }
 void launch_copy_words(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
   if (n_words == 0) return;
+  if (program_record(CopyWordsDesc{dst, src, n_words})) return;
   const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 4096);
   hipLaunchKernelGGL(k_copy_words, dim3(blocks), dim3(256), 0, s, dst, src, n_words);
   launched(0, "k_copy_words");
 }
 
-__global__ __launch_bounds__(256) void k_folding_neg(DevTables T, u32* mats, const u32* gadget_ntt, int two_t) {
-  const int e = blockIdx.x * 256 + threadIdx.x;
-  const int c = e >> POLY_LEN_LOG2;
-  const int col = blockIdx.y % two_t, r = blockIdx.y / two_t;
-  const int dd = blockIdx.z;
-  const u32 q = T.c.mod[c].q;
-  u32* row = mats + ((size_t)(dd * 2 + r) * 2 * two_t) * 2 * N;
-  const u32 cv = row[(size_t)(two_t + col) * 2 * N + e];
-  const u32 g = gadget_ntt[((size_t)r * two_t + col) * 2 * N + e];
-  row[(size_t)col * 2 * N + e] = add_mod(g, cv ? q - cv : 0u, q);
+__global__ __launch_bounds__(256) void k_folding_neg(DevTables T, FoldingNegDesc d) {
+  folding_neg_body(T, d, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s) {
   if (nu2 <= 0) return;
-  hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, mats, gadget_ntt, two_t);
+  const FoldingNegDesc d{mats, gadget_ntt, two_t, nu2};
+  if (program_record(d)) return;
+  hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, d);
   launched(0, "k_folding_neg");
 }
 
@@ -284,97 +218,23 @@ void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
   launched(0, "k_u32_to_u64");
 }
 
-// rescale(a, Q, out_mod) of arith.rs:429-444 without 128-bit division: the truncated quotient
-// floor((|v| * out_mod + Q/2) / Q) is < 2^38, so a double estimate is within +-1 and is corrected exactly.
-__device__ __forceinline__ u64 rescale_dev(u64 a, u64 Q, u64 out_mod) {
-  u64 v = a % Q;
-  const bool neg = v >= Q / 2;  // inp_val -= inp_mod
-  const u64 mag = neg ? Q - v : v;
-  // num = mag * out_mod + Q/2  (up to ~2^93): 128-bit as (hi, lo)
-  u64 lo = mag * out_mod, hi = __umul64hi(mag, out_mod);
-  const u64 half = Q / 2;
-  lo += half;
-  hi += lo < half ? 1 : 0;
-  u64 qd = (u64)(((double)hi * 18446744073709551616.0 + (double)lo) / (double)Q);
-  // correct: want qd*Q <= num < (qd+1)*Q
-  for (int it = 0; it < 4; it++) {
-    const u64 plo = qd * Q, phi = __umul64hi(qd, Q);
-    const bool gt = phi > hi || (phi == hi && plo > lo);  // qd*Q > num
-    if (gt) {
-      qd--;
-      continue;
-    }
-    // rem = num - qd*Q  (fits 64 bits when qd is within 1 of the truth and Q < 2^57)
-    const u64 rlo = lo - plo, rhi = hi - phi - (lo < plo ? 1 : 0);
-    if (rhi != 0 || rlo >= Q) {
-      qd++;
-      continue;
-    }
-    break;
-  }
-  // result = (sign*qd + (Q/out)*out + 2*out) % out, then (+out) % out; all terms fit i64 magnitudes
-  const u64 base = (Q / out_mod) * out_mod + 2 * out_mod;
-  const u64 r = neg ? (base - qd) % out_mod : (base + qd) % out_mod;
-  return (r + out_mod) % out_mod;
-}
-__global__ __launch_bounds__(256) void k_encode(EncodeDesc d) {
-  const int per_inst_first = d.n * N, per_inst_rest = d.n * d.n * N;
-  const int per_inst = per_inst_first + per_inst_rest;
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i >= (long)d.instances * per_inst) return;
-  const int inst = (int)(i / per_inst), k = (int)(i % per_inst);
-  const u64* m = d.packed + (size_t)inst * (d.n + 1) * d.n * N;
-  const size_t inst_bits = (size_t)per_inst_first * d.q2_bits + (size_t)per_inst_rest * d.q1_bits;
-  u64 val;
-  size_t bit;
-  int nb;
-  if (k < per_inst_first) {
-    val = rescale_dev(m[k], d.Q, d.q2);
-    nb = d.q2_bits;
-    bit = (size_t)inst * inst_bits + (size_t)k * d.q2_bits;
-  } else {
-    const int kk = k - per_inst_first;
-    val = rescale_dev(m[per_inst_first + kk], d.Q, d.q1);
-    nb = d.q1_bits;
-    bit = (size_t)inst * inst_bits + (size_t)per_inst_first * d.q2_bits + (size_t)kk * d.q1_bits;
-  }
-  val &= nb >= 64 ? ~0ULL : ((1ULL << nb) - 1ULL);
-  const size_t w = bit >> 6;
-  const int off = (int)(bit & 63);
-  atomicOr(d.out + w, (unsigned long long)(val << off));
-  if (off + nb > 64) atomicOr(d.out + w + 1, (unsigned long long)(val >> (64 - off)));
-}
+__global__ __launch_bounds__(256) void k_encode(EncodeDesc d) { encode_body(d, blockIdx.x); }
 void launch_encode(const EncodeDesc& d, hipStream_t s) {
   const long total = (long)d.instances * ((long)d.n * N + (long)d.n * d.n * N);
+  if (program_record(d)) return;
   hipLaunchKernelGGL(k_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
   launched(0, "k_encode");
 }
 
 // out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
-__global__ __launch_bounds__(256) void k_reorient(u64* out, const u32* v, int first, int step, int dim0) {
-  __shared__ u64 tile[32][33];
-  // tile over (z, j) for a fixed r: blockIdx.x -> j tile, blockIdx.y -> z tile, blockIdx.z -> r
-  const int r = blockIdx.z;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int j0 = blockIdx.x * 32, z0 = blockIdx.y * 32;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int j = j0 + ty + 8 * i;
-    if (j < dim0) {
-      const u32* p = v + ((size_t)(first + step * j) * 2 + r) * 2 * N;
-      tile[ty + 8 * i][tx] = (u64)p[z0 + tx] | ((u64)p[N + z0 + tx] << 32);
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int z = z0 + ty + 8 * i;
-    int j = j0 + tx;
-    if (j < dim0) out[((size_t)z * dim0 + j) * 2 + r] = tile[tx][ty + 8 * i];
-  }
+__global__ __launch_bounds__(256) void k_reorient(ReorientDesc d) {
+  __shared__ u64 tile[32 * 33];
+  reorient_body(d, blockIdx.x, blockIdx.y, blockIdx.z, tile);
 }
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
-  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, out, v, first, step, dim0);
+  const ReorientDesc d{out, v, first, step, dim0};
+  if (program_record(d)) return;
+  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, d);
   launched(0, "k_reorient");
 }
 

@@ -2,6 +2,7 @@
 // in registers / LDS.  See DESIGN.md section 3 for the algebra and the roofline.
 #include "device_common.hpp"
 #include "wave_ntt.hpp"
+#include "bodies.hpp"
 
 namespace spiral {
 
@@ -505,16 +506,12 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
 }
 
 // fold_mats (NTT polynomials [crt][z]) -> wave layout, same polynomial order: one thread per word
-__global__ __launch_bounds__(256) void k_mats_to_wave(u32* dst, const u32* __restrict__ src, size_t n_words) {
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= n_words) return;
-  const size_t poly = idx >> POLY_LEN_LOG2;  // (polynomial, crt) pairs are N words each
-  const int n = (int)(idx & (N - 1));
-  dst[poly * N + wave_layout_word(n)] = src[idx];
-}
+__global__ __launch_bounds__(256) void k_mats_to_wave(MatsToWaveDesc d) { mats_to_wave_body(d, blockIdx.x); }
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
   if (n_words == 0) return;
-  hipLaunchKernelGGL(k_mats_to_wave, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, dst, src, n_words);
+  const MatsToWaveDesc d{dst, src, n_words};
+  if (program_record(d)) return;
+  hipLaunchKernelGGL(k_mats_to_wave, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d);
   launched(0, "k_mats_to_wave");
 }
 

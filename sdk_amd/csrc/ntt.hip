@@ -8,6 +8,7 @@
 //
 // This unit: forward / inverse transform kernels, from_ntt of the sweep output, the transform-core micro-benchmark.
 #include "device_common.hpp"
+#include "bodies.hpp"
 
 namespace spiral {
 
@@ -70,42 +71,6 @@ float bench_ntt_core(const DevTables& T, int M, int blocks, int reps, u32* scrat
 // ------------------------------------------------------------------------------------------------
 // forward NTT kernel: grid (n_out, 2 crt)
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void ntt_fwd_body(const DevTables& T, const FwdDesc& d, int o, int c, u32* ldsA, u32* ldsB) {
-  const int tau = threadIdx.x;
-  const int rows = d.rdim * d.t;
-  const int per_b = rows * d.cols;
-  const int b = o / per_b;
-  const int rem = o - b * per_b;
-  const int row = rem / d.cols, col = rem - row * d.cols;
-  const int kdig = row / d.rdim, j = row - kdig * d.rdim;
-  long sb = d.src_idx ? (long)d.src_idx[b] : (long)b;
-  if (d.delta_off) sb = (long)(b / d.delta_inner) * d.delta_outer_stride + (b % d.delta_inner);
-  const u64* src = d.src + (sb * d.src_batch_stride + (long)(d.src_row0 + j) * d.src_cols + col) * N;
-  const ModConst m = T.c.mod[c];
-  const int sh = kdig * d.bits;
-  const bool plain = (d.bits >= 64);
-  const u64 mask = plain ? ~0ULL : ((1ULL << d.bits) - 1ULL);
-  u32 v[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    u64 x = src[tau + 256 * k];
-    u64 piece = (sh >= 64) ? 0ULL : ((x >> sh) & mask);  // gadget.rs:48-53
-    u32 val = (d.bits <= 28) ? (u32)piece : reduce64(piece, m);
-    if (d.delta_off) {
-      u64 x2 = src[(size_t)d.delta_off * N + tau + 256 * k];
-      u64 piece2 = (sh >= 64) ? 0ULL : ((x2 >> sh) & mask);
-      u32 val2 = (d.bits <= 28) ? (u32)piece2 : reduce64(piece2, m);
-      u32 a = val >= m.q ? val - m.q : val, b2 = val2 >= m.q ? val2 - m.q : val2;  // digits may equal 2^28-1 > q
-      val = b2 >= a ? b2 - a : b2 + m.q - a;
-    }
-    v[k] = val;
-  }
-  const u32* fw = T.tw + (size_t)c * 4 * N;
-  ntt_fwd_block(v, tau, ldsA, ldsB, fw, fw + N, m.q, m.two_q);
-  uint4* dst = reinterpret_cast<uint4*>(d.dst + ((size_t)o * 2 + c) * N + 8 * tau);
-  dst[0] = make_uint4(v[0], v[1], v[2], v[3]);
-  dst[1] = make_uint4(v[4], v[5], v[6], v[7]);
-}
 __global__ __launch_bounds__(256) void k_ntt_fwd(DevTables T, FwdDesc d) {
   __shared__ u32 ldsA[LDS_WORDS];
   __shared__ u32 ldsB[LDS_WORDS];
@@ -125,6 +90,7 @@ __global__ __launch_bounds__(256) void k_ntt_fwd3(DevTables T, FwdDesc d0, FwdDe
 }
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
   if (d.n_out <= 0) return;
+  if (program_record(d)) return;
   hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
   launched(0, "k_ntt_fwd");
 }
@@ -135,6 +101,7 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
   a.n_out = std::max(a.n_out, 0);
   b.n_out = std::max(b.n_out, 0);
   c.n_out = std::max(c.n_out, 0);
+  if (program_record(a, b, c)) return;
   hipLaunchKernelGGL(k_ntt_fwd3, dim3(total, 2), dim3(256), 0, s, T, a, b, c);
   launched(0, "k_ntt_fwd3");
 }
@@ -147,107 +114,12 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
 __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
   __shared__ u32 ldsA[LDS_WORDS];
   __shared__ u32 ldsB[LDS_WORDS];
-  const int tau = threadIdx.x;
-  int p = blockIdx.x;
-  long base;
-  long crt_stride = d.crt_stride, z_stride = d.z_stride;
-  if (d.sweep_np > 0) {
-    const long np = d.sweep_np;
-    // The 16 columns ii that share a 64-byte line of the [z][ii] source should be read through ONE XCD's
-    // L2 (blocks are dealt to XCDs round-robin): block b -> XCD b % 8 handles group (b/8/16)*8 + b%8.
-    if ((np % 16) == 0 && ((long)d.n_polys % 128) == 0) {
-      const int b = blockIdx.x;
-      const int xcd = b & 7, slot = b >> 3;
-      const int grp = (slot >> 4) * 8 + xcd, within = slot & 15;  // group = (plane, r, ii/16)
-      const int groups_per_plane = (int)(np / 16) * 2;
-      const int plane_g = grp / groups_per_plane, rem_g = grp % groups_per_plane;
-      const int r_g = rem_g / (int)(np / 16), iig = rem_g % (int)(np / 16);
-      p = (int)(((long)plane_g * np + iig * 16 + within) * 2 + r_g);
-    }
-    const long ct = p >> 1, r = p & 1;
-    const long plane = ct / np, ii = ct - plane * np;
-    base = plane * 4 * N * np + r * 2 * N * np + ii;
-    crt_stride = N * np;
-    z_stride = np;
-  } else if (d.idx) {
-    int e = p / d.polys_per_idx, r = p - e * d.polys_per_idx;
-    base = (long)d.idx[e] * d.idx_stride + (long)r * d.poly_stride;
-  } else {
-    base = (long)p * d.poly_stride;
-  }
-  // fused scalar multiply of coefficient_expansion (contiguous sources only)
-  long scal_store = -1;
-  if (d.scal) {
-    if (p >= d.n_polys) {  // scalar-only entries: form and store, no transform
-      const int e = p - d.n_polys;
-      const int ct = d.scal_only_idx[e >> 1], r = e & 1;
-      const long sp = ((long)(ct - d.scal_thresh) * 2 + r) * 2 * N, dp = ((long)ct * 2 + r) * 2 * N;
-#pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int z = 8 * tau + k;
-          d.scal_dst[dp + c * N + z] = reduce64((u64)d.src[sp + c * N + z] * (u64)d.scal[c * N + z], T.c.mod[c]);
-        }
-      return;
-    }
-    const int e = p / d.polys_per_idx, r = p - e * d.polys_per_idx;
-    const int ct = d.idx[e];
-    if (ct >= d.scal_thresh) {
-      scal_store = base;                                                // destination = this ct's own slot
-      base = (long)(ct - d.scal_thresh) * d.idx_stride + (long)r * d.poly_stride;  // source = v[ct - num_in]
-    }
-  }
-  u32 res[2][8];
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const ModConst m = T.c.mod[c];
-    const u32* src = d.src + base + (long)c * crt_stride;
-    u32 v[8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      u32 x = src[(long)(8 * tau + k) * z_stride];
-      if (d.premod) x = x % m.q;
-      if (scal_store >= 0) {
-        x = reduce64((u64)x * (u64)d.scal[c * N + 8 * tau + k], m);
-        d.scal_dst[scal_store + (long)c * crt_stride + 8 * tau + k] = x;
-      }
-      v[k] = x;
-    }
-    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
-    if (c == 1) __syncthreads();
-    ntt_inv_block(v, tau, ldsA, ldsB, iw, iw + N, m.q, m.two_q);
-#pragma unroll
-    for (int k = 0; k < 8; k++) res[c][k] = v[k];
-  }
-  const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
-  u64* dst = d.dst + (size_t)p * N;
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    u32 x = res[0][k], y = res[1][k];
-    u32 xm = x >= q1 ? x - q1 : x;  // q0 < 2*q1
-    u32 dd = y >= xm ? y - xm : y + q1 - xm;
-    u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
-    u32 e = dd * T.c.q0_inv_q1 - qt * q1;
-    e = e >= q1 ? e - q1 : e;
-    u64 val = (u64)x + (u64)q0 * (u64)e;
-    int z = tau + 256 * k;
-    if (d.automorph_t) {  // poly.rs:393-405
-      unsigned zt = (unsigned)z * (unsigned)d.automorph_t;
-      unsigned num = zt >> POLY_LEN_LOG2, rem = zt & (N - 1);
-      dst[rem] = (num & 1u) ? T.c.Q - val : val;
-    } else if (d.addend) {
-      const long ap = (long)(p / d.add_inner2) * d.add_outer_stride + (p % d.add_inner2);
-      u64 sres = val + d.addend[(size_t)ap * N + z];
-      dst[z] = sres >= T.c.Q ? sres - T.c.Q : sres;
-    } else {
-      dst[z] = val;
-    }
-  }
+  ntt_inv_body(T, d, blockIdx.x, ldsA, ldsB);
 }
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
   const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);
   if (blocks <= 0) return;
+  if (d.sweep_np <= 0 && program_record(d)) return;
   hipLaunchKernelGGL(k_ntt_inv, dim3(blocks), dim3(256), 0, s, T, d);
   launched(d.sweep_np > 0 ? PATH_FROM_SWEEP1 : 0, "k_ntt_inv");
 }
@@ -315,10 +187,102 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
     }
   }
 }
+// ------------------------------------------------------------------------------------------------
+// The same transform with the NEXT operand prefetched (r04, the default): k_from_sweep4's workgroups load, transform and
+// store in strict sequence, and because all of a launch's workgroups start together the whole chip alternates between a
+// memory phase with idle ALUs and a compute phase with an idle memory system (11 ns per transform, 0.17 of the HBM rate:
+// VERDICT r03).  The kernel has no registers to spare for a second operand in flight (the four-column transform needs the
+// whole file), so the next operand is only PULLED INTO THE L2: before a transform starts, every thread issues one
+// throw-away load per 16-byte piece of the operand after it -- modulus 1 of the group before modulus 0 is transformed,
+// modulus 0 of the workgroup's next group (persistent grid, two workgroups per CU) before modulus 1 is -- all into ONE dead
+// register (loads return in order; the register is never read).  The real loads then hit the L2.  Same arithmetic, same
+// XCD-aware group order, same results.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void fsp_prefetch8(const u32* p, int tau, int np) {
+  u32 dead;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    asm volatile("global_load_dword %0, %1, off" : "=v"(dead) : "v"(p + (size_t)(8 * tau + k) * np) : "memory");
+}
+__global__ __launch_bounds__(256, 2) void k_from_sweep4_pipe(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map,
+                                                             int n_groups) {
+  __shared__ u32 lds0[4 * LDS_WORDS];
+  __shared__ u32 lds1[4 * LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int gpr = np / 4;  // groups per (plane, r)
+  const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+  for (int vb = blockIdx.x; vb < n_groups; vb += gridDim.x) {
+    // virtual block vb -> (plane, r, ii0): the order of k_from_sweep4 (the 8 groups sharing a 128-byte line go through ONE XCD)
+    int g = vb, gn = vb + gridDim.x < n_groups ? vb + (int)gridDim.x : vb;
+    if (xcd_map) {
+      g = (((g >> 3) >> 3) * 8 + (g & 7)) * 8 + ((g >> 3) & 7);
+      gn = (((gn >> 3) >> 3) * 8 + (gn & 7)) * 8 + ((gn >> 3) & 7);
+    }
+    const int groups_per_plane = gpr * 2;
+    const int plane = g / groups_per_plane, rem = g % groups_per_plane;
+    const int r = rem / gpr, ii0 = (rem % gpr) * 4;
+    const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
+    const int plane_n = gn / groups_per_plane, rem_n = gn % groups_per_plane;
+    const size_t base_n = ((size_t)plane_n * 4 + (rem_n / gpr) * 2) * N * np + (rem_n % gpr) * 4;
+    u32 res0[4][8];
+#pragma unroll 1
+    for (int c = 0; c < 2; c++) {
+      const ModConst m = T.c.mod[c];
+      const u32* sp = src + base + (size_t)c * N * np;
+      u32 v[4][8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        uint4 x = *reinterpret_cast<const uint4*>(sp + (size_t)(8 * tau + k) * np);
+        if (premod) {
+          x.x %= m.q; x.y %= m.q; x.z %= m.q; x.w %= m.q;
+        }
+        v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
+      }
+      // what the workgroup reads next: modulus 1 of this group / modulus 0 of its next group
+      fsp_prefetch8(c == 0 ? sp + (size_t)N * np : src + base_n, tau, np);
+      // the transform's LDS addresses and twiddle pointers are loop invariants of the modulus / group loops: left alone the
+      // compiler hoists some sixty of them over the loops and spills to make room (the fold kernels do the same)
+      const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+      int tk = tau;
+      asm volatile("" : "+s"(iw));
+      asm volatile("" : "+v"(tk));
+      __syncthreads();  // the exchange buffers are free (previous transform's last reads are done)
+      ntt_inv_block_m<4>(v, tk, lds0, lds1, iw, iw + N, m.q, m.two_q);
+      if (c == 0) {
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++)
+#pragma unroll
+          for (int k = 0; k < 8; k++) res0[mm][k] = v[mm][k];
+      } else {
+#pragma unroll
+        for (int mm = 0; mm < 4; mm++) {
+          u64* out = dst + (((size_t)plane * np + ii0 + mm) * 2 + r) * N;
+#pragma unroll
+          for (int k = 0; k < 8; k++) {
+            const u32 x = res0[mm][k], y = v[mm][k];
+            const u32 xm = x >= q1 ? x - q1 : x;
+            const u32 dd = y >= xm ? y - xm : y + q1 - xm;
+            const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+            u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+            e = e >= q1 ? e - q1 : e;
+            out[tau + 256 * k] = (u64)x + (u64)q0 * (u64)e;
+          }
+        }
+      }
+    }
+  }
+}
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
   const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
   const int xcd_map = tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0;
+  // from_sweep_pipe (default 1): the software-pipelined persistent form; 0: one workgroup per column group
+  if (tunable("from_sweep_pipe", 1) != 0) {
+    const unsigned grid = std::min(groups, 512u);   // two workgroups per CU (LDS-bound), a multiple of 64 whenever xcd_map is on
+    hipLaunchKernelGGL(k_from_sweep4_pipe, dim3(grid), dim3(256), 0, s, T, src, np, premod, dst, xcd_map, (int)groups);
+    launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4_pipe");
+    return;
+  }
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }

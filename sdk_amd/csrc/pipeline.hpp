@@ -20,6 +20,8 @@ struct Workspace {
   hipEvent_t ev_sw[2] = {nullptr, nullptr};  // first sweep launch begins / last sweep launch done (timing)
   bool have_sweep_span = false;
   bool pipelined = false;                   // set by run_sweep_pipelined, consumed by run_finish
+  Program prog_expand;                      // the expansion chain as one persistent launch (switch expand_persist)
+  Program prog_tail;                        // fold-tree tail + pack + encode as one persistent launch (switch finish_persist)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
   // expansion
   DevBuf<u64> q_raw;      // query ct, raw 2x1

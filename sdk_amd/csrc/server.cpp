@@ -759,6 +759,7 @@ void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int
   inv.dst = W.gsw_raw.p;
   inv.n_polys = nb * 2;
   launch_ntt_inv(D.T, inv, s);
+  program_group_end();  // (recording: the caller's group -- reorientation, the copy above, this inverse -- ends here)
   FwdDesc f{};
   f.src = W.gsw_raw.p;
   f.dst = W.gsw_dig.p;
@@ -869,13 +870,37 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   memcpy(W.h_query + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
   HIP_CHECK(hipMemcpyAsync(W.q_raw.p, W.h_query, 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, s));
   FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};  // v[0] = query.ct.ntt()  (server.rs:545)
-  launch_ntt_fwd(D.T, f, s);
   const size_t g = p.g();
   // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
   const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
   if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
   const DeviceState::PrunedPlan* pl = plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
+  // expand_persist (default 1): the whole chain -- NTT of the query, g rounds of three dependent launches, reorientation,
+  // regev_to_gsw, G - C, wave re-layout: ~40 launches of 7-12 us for ~0.3 ms of arithmetic at C2 -- is RECORDED and runs
+  // as ONE launch of the persistent phase-program kernel (program.hip) with device-wide barriers between the phases.
+  if (tunable("expand_persist", 1) != 0) {
+    program_begin(W.prog_expand);
+    try {
+      launch_ntt_fwd(D.T, f, s);
+      run_coefficient_expansion(W, pp, g, pl);
+      if (p.db_dim_2 > 0) {
+        program_group_begin();   // the reorientation and regev_to_gsw's first two launches are independent (group ends inside)
+        launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+        run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+        run_folding_neg(W);
+      } else {
+        launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), s);  // server.rs:574-576
+      }
+    } catch (...) {
+      program_end();
+      throw;
+    }
+    program_end();
+    program_launch(D.T, W.prog_expand, s, PATH_EXPAND_FUSED);
+    return;
+  }
+  launch_ntt_fwd(D.T, f, s);
   const long split_mode = tunable("expand_split", -1);  // -1: only when a long sweep follows (it hides the odd subtree)
   if (p.db_dim_2 > 0 && g >= 2 && (split_mode > 0 || (split_mode < 0 && W.long_sweep_follows))) {
     // expand_split (default -1: only before a per-plane pipelined sweep, i.e. wide packed databases; 1: always; 0: never):

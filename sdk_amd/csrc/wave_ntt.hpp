@@ -477,8 +477,7 @@ __device__ __forceinline__ void wntt_inv(u32 (&v)[32], int lane, u32* buf, const
   }
 }
 
-// word of coefficient n = 32 L + k of a polynomial stored in "wave layout": lane L reads its 32 coefficients as eight
-// coalesced 16-byte vectors (vector g of all lanes is one contiguous KiB)
-__host__ __device__ inline int wave_layout_word(int n) { return ((n & 31) >> 2) * 256 + (n >> 5) * 4 + (n & 3); }
+// (wave_layout_word -- the word of coefficient n = 32 L + k of a polynomial stored in "wave layout", where lane L reads its
+// 32 coefficients as eight coalesced 16-byte vectors -- lives in bodies.hpp beside the re-layout kernel's body)
 
 }  // namespace spiral
