@@ -8,7 +8,15 @@ tests/golden/protocol_vectors.json (+ C1 = BASELINE configs[0] with --c1), the a
     <out>/<case>/db.bin          server::load_preprocessed_db_from_file      (server.rs:373-386; native-endian u64 words,
                                  layout [instance][trial][z][ii][j], the &[u64] process_query takes)
     <out>/<case>/response.bin    what server::process_query must return      (server.rs:650-655)
+    <out>/<case>/v_reg.bin       STAGE: expand_query's first output, v_reg_reoriented as_slice()   (server.rs:525-591)
+    <out>/<case>/v_folding.bin   STAGE: expand_query's second output, the nu_2 GSW matrices' as_slice() concatenated
+    <out>/<case>/plane0.bin      STAGE: multiply_reg_by_database on the first (instance 0, trial 0) database slice: the
+                                 num_per 2x1 PolyMatrixNTT outputs' as_slice() concatenated           (server.rs:155-221)
     <out>/manifest.json          sizes + SHA-256 of every file
+
+The three STAGE files let the Rust side name the stage at which a build of the reference and this repository part ways
+(query expansion incl. the ChaCha20 row-0 regeneration of Query::deserialize / the database multiply / everything after)
+instead of reporting one differing response byte.
 
 The bytes come from the CPU oracle with the fixed seeds of the golden file (their digests are checked against it); with
 --gpu the HIP path must reproduce response.bin from the same files before they are written.  The Rust side that reads
@@ -54,15 +62,33 @@ def main():
         if c["golden"]:
             assert (sha(pp), sha(q), sha(db.tobytes()), sha(resp)) == (c["sha256_pp"], c["sha256_query"], c["sha256_db"],
                                                                        c["sha256_response"]), "golden digests moved"
+        # stage outputs in the reference's own layouts (all native-endian u64 words)
+        # (direct-upload configurations do not expand on the server: process_query takes v_buf / v_ct from the query as they
+        # are, server.rs:666-679 -- no stage files for them)
+        staged = not c["params"].get("direct_upload")
+        slice_words = o.dim0 * o.num_per * o.poly_len
+        if staged:
+            v_reg, v_fold = o.expand_query(pp, q)
+            plane0 = o.multiply_reg_by_database(db[:slice_words], v_reg)
         if args.gpu:
+            import numpy as np
             import sdk_amd as sp
             p = sp.Params(c["params"])
-            got = sp.process_query(p, sp.PublicParameters.deserialize(p, pp), q, sp.Database(p).load(db))
+            gpp = sp.PublicParameters.deserialize(p, pp)
+            got = sp.process_query(p, gpp, q, sp.Database(p).load(db))
             assert got == resp, "HIP response differs from the oracle for " + c["name"]
+            if staged:
+                g_reg, g_fold = sp.expand_query(p, gpp, q)
+                assert (np.asarray(g_reg) == v_reg).all() and (o.db_dim_2 == 0 or (np.asarray(g_fold) == v_fold).all()), \
+                    "HIP expand_query differs from the oracle for " + c["name"]
+                g_plane = sp.multiply_reg_by_database(p, db[:slice_words], v_reg)
+                assert (np.asarray(g_plane) == plane0).all(), "HIP multiply_reg_by_database differs from the oracle for " + c["name"]
         d = os.path.join(args.out, c["name"])
         os.makedirs(d, exist_ok=True)
         files = {"params.json": json.dumps(c["params"], sort_keys=True).encode(), "pp.bin": bytes(pp), "query.bin": bytes(q),
                  "db.bin": db.tobytes(), "response.bin": bytes(resp)}
+        if staged:
+            files.update({"v_reg.bin": v_reg.tobytes(), "v_folding.bin": v_fold.tobytes(), "plane0.bin": plane0.tobytes()})
         for name, blob in files.items():
             with open(os.path.join(d, name), "wb") as f:
                 f.write(blob)

@@ -7,15 +7,38 @@
 //     REF_CHECK_DIR=/path/to/ref_check cargo test --release --features server --test ref_check -- --nocapture
 //
 // It uses nothing but the crate's public API: util::params_from_json (util.rs:219), PublicParameters::deserialize
-// (client.rs:212), Query::deserialize (client.rs:303), server::load_preprocessed_db_from_file (server.rs:373) and
-// server::process_query (server.rs:650).  Run it with and without `RUSTFLAGS="-C target-feature=+avx2"`: the scalar and
-// the AVX2 builds must both agree (their intermediates differ, their response bytes must not).
+// (client.rs:212), Query::deserialize (client.rs:303), server::load_preprocessed_db_from_file (server.rs:373),
+// server::expand_query (server.rs:525), server::multiply_reg_by_database (server.rs:155) and server::process_query
+// (server.rs:650).  STAGES are compared before the whole query, so that a mismatch names where the two part ways:
+//   1. expand_query            -> v_reg.bin (v_reg_reoriented) and v_folding.bin: covers Query::deserialize's ChaCha20 row-0
+//                                 regeneration (client.rs:47-49, 303-329), coefficient_expansion, regev_to_gsw
+//   2. multiply_reg_by_database on the first database slice -> plane0.bin
+//   3. process_query           -> response.bin (fold, pack, encode on top of 1 and 2)
+// Run it twice:
+//     REF_CHECK_DIR=... cargo test --release --features server --test ref_check -- --nocapture
+//     REF_CHECK_DIR=... RUSTFLAGS="-C target-feature=+avx2" cargo test --release --features server --test ref_check -- --nocapture
+// The scalar and the AVX2 builds must both agree with the dump (the AVX2 multiply keeps its sums
+// in a different order and reduces at other points; residues and response bytes must not differ).
 use std::fs::{self, File};
 use std::path::{Path, PathBuf};
 
 use spiral_rs::client::{PublicParameters, Query};
-use spiral_rs::server::{load_preprocessed_db_from_file, process_query};
+use spiral_rs::poly::{PolyMatrix, PolyMatrixNTT};
+use spiral_rs::server::{expand_query, load_preprocessed_db_from_file, multiply_reg_by_database, process_query};
 use spiral_rs::util::params_from_json;
+
+fn read_words(p: &Path) -> Vec<u64> {
+    let b = fs::read(p).unwrap();
+    assert_eq!(b.len() % 8, 0, "{:?}: not a whole number of u64 words", p);
+    b.chunks_exact(8).map(|c| u64::from_ne_bytes(c.try_into().unwrap())).collect()
+}
+
+fn first_diff(a: &[u64], b: &[u64]) -> Option<usize> {
+    if a.len() != b.len() {
+        return Some(a.len().min(b.len()));
+    }
+    a.iter().zip(b.iter()).position(|(x, y)| x != y)
+}
 
 fn case_dirs(root: &Path) -> Vec<PathBuf> {
     let mut v: Vec<PathBuf> = fs::read_dir(root)
@@ -50,10 +73,39 @@ fn reference_process_query_matches_dumped_responses() {
         let query = Query::deserialize(&params, &q_bytes);
         let mut f = File::open(d.join("db.bin")).unwrap();
         let db = load_preprocessed_db_from_file(&params, &mut f);
+        // ---- stage 1: expand_query (only configurations that expand on the server)
+        if params.expand_queries && d.join("v_reg.bin").is_file() {
+            let (v_reg, v_folding) = expand_query(&params, &pp, &query);
+            let want_reg = read_words(&d.join("v_reg.bin"));
+            let diff = first_diff(v_reg.as_slice(), &want_reg);
+            assert!(diff.is_none(), "{}: STAGE expand_query: v_reg_reoriented differs at word {:?}", name, diff);
+            let want_fold = read_words(&d.join("v_folding.bin"));
+            let mut got_fold: Vec<u64> = Vec::with_capacity(want_fold.len());
+            for m in v_folding.iter() {
+                got_fold.extend_from_slice(m.as_slice());
+            }
+            let diff = first_diff(&got_fold, &want_fold);
+            assert!(diff.is_none(), "{}: STAGE expand_query: v_folding differs at word {:?}", name, diff);
+            // ---- stage 2: multiply_reg_by_database on the first (instance 0, trial 0) slice
+            let dim0 = 1usize << params.db_dim_1;
+            let num_per = 1usize << params.db_dim_2;
+            let slice = dim0 * num_per * params.poly_len;
+            let mut inter: Vec<PolyMatrixNTT> = (0..num_per).map(|_| PolyMatrixNTT::zero(&params, 2, 1)).collect();
+            multiply_reg_by_database(&mut inter, &db.as_slice()[0..slice], v_reg.as_slice(), &params, dim0, num_per);
+            let want_plane = read_words(&d.join("plane0.bin"));
+            let mut got_plane: Vec<u64> = Vec::with_capacity(want_plane.len());
+            for m in inter.iter() {
+                got_plane.extend_from_slice(m.as_slice());
+            }
+            let diff = first_diff(&got_plane, &want_plane);
+            assert!(diff.is_none(), "{}: STAGE multiply_reg_by_database: output differs at word {:?}", name, diff);
+            println!("{}: expand_query and multiply_reg_by_database identical", name);
+        }
+        // ---- stage 3: the whole query
         let got = process_query(&params, &pp, &query, db.as_slice());
         assert_eq!(got.len(), want.len(), "{}: response length", name);
-        let first_diff = got.iter().zip(want.iter()).position(|(a, b)| a != b);
-        assert!(first_diff.is_none(), "{}: response differs from the dumped one at byte {:?}", name, first_diff);
+        let diff = got.iter().zip(want.iter()).position(|(a, b)| a != b);
+        assert!(diff.is_none(), "{}: STAGE fold/pack/encode: response differs from the dumped one at byte {:?}", name, diff);
         println!("{}: {} response bytes identical", name, got.len());
     }
 }
