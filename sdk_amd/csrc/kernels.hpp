@@ -41,7 +41,7 @@ enum PathBit : u64 {
   PATH_DIRECT_UPLOAD = 1ull << 13,
   PATH_SCATTER_OUT = 1ull << 14,      // column-interleaved sweep output (multi-GPU reduce-scatter layout)
   PATH_SWEEP_XCD_FROM = 1ull << 15,   // k_from_sweep4 with the XCD-aware block order
-  PATH_FOLD_TAIL_PERSIST = 1ull << 16,// k_fold_tail (all small levels in one launch, grid barrier per level)
+  PATH_FOLD_TAIL_PERSIST = 1ull << 16,// (retired: k_fold_tail of round 1)
   PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_persist (the whole expansion in ONE launch, device-wide barriers between phases)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // RCCL collectives issued by the library itself (sp_comm_create)
@@ -53,7 +53,8 @@ enum PathBit : u64 {
   PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
   PATH_FROM_SWEEP_WAVE = 1ull << 26,  // (retired: k_from_sweep_wave)
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
-  PATH_SWEEP_RING = 1ull << 28        // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
+  PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
+  PATH_FINISH_PROGRAM = 1ull << 29    // fold-tree tail levels and / or pack + encode as one launch of k_program (finish_persist)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -310,6 +311,7 @@ struct Program {
 void program_begin(Program& p);   // the calling thread's launch_* wrappers record into p from here ...
 void program_end();               // ... to here
 bool program_recording();
+Program* program_current();       // the program being recorded on this thread, or null
 // independent consecutive launches: the phases recorded between program_group_begin / _end need no barrier between them
 void program_group_begin();
 void program_group_end();

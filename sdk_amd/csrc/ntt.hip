@@ -192,17 +192,18 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
 // store in strict sequence, and because all of a launch's workgroups start together the whole chip alternates between a
 // memory phase with idle ALUs and a compute phase with an idle memory system (11 ns per transform, 0.17 of the HBM rate:
 // VERDICT r03).  The kernel has no registers to spare for a second operand in flight (the four-column transform needs the
-// whole file), so the next operand is only PULLED INTO THE L2: before a transform starts, every thread issues one
-// throw-away load per 16-byte piece of the operand after it -- modulus 1 of the group before modulus 0 is transformed,
-// modulus 0 of the workgroup's next group (persistent grid, two workgroups per CU) before modulus 1 is -- all into ONE dead
-// register (loads return in order; the register is never read).  The real loads then hit the L2.  Same arithmetic, same
+// whole file), so the next operand is only PULLED INTO THE L2: before a transform starts, every thread loads one dword of
+// each 16-byte piece of the operand after it -- modulus 1 of the group before modulus 0 is transformed, modulus 0 of the
+// workgroup's next group (persistent grid, two workgroups per CU) before modulus 1 is -- eight registers that are looked
+// at only after the transform (a never-true test keeps them alive).  The real loads then hit the L2.  Same arithmetic, same
 // XCD-aware group order, same results.
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void fsp_prefetch8(const u32* p, int tau, int np) {
-  u32 dead;
+// one dword of every 16-byte piece the thread will load next, as ordinary loads the compiler's wait counting knows about (a
+// throw-away destination register written behind the compiler's back could be reused while the load is in flight); the
+// caller looks at them only after its transform
+__device__ __forceinline__ void fsp_prefetch8(u32 (&t)[8], const u32* p, int tau, int np) {
 #pragma unroll
-  for (int k = 0; k < 8; k++)
-    asm volatile("global_load_dword %0, %1, off" : "=v"(dead) : "v"(p + (size_t)(8 * tau + k) * np) : "memory");
+  for (int k = 0; k < 8; k++) t[k] = p[(size_t)(8 * tau + k) * np];
 }
 __global__ __launch_bounds__(256, 2) void k_from_sweep4_pipe(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map,
                                                              int n_groups) {
@@ -239,7 +240,9 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4_pipe(DevTables T, const 
         v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
       }
       // what the workgroup reads next: modulus 1 of this group / modulus 0 of its next group
-      fsp_prefetch8(c == 0 ? sp + (size_t)N * np : src + base_n, tau, np);
+      u32 pulled[8];
+      fsp_prefetch8(pulled, c == 0 ? sp + (size_t)N * np : src + base_n, tau, np);
+      __builtin_amdgcn_sched_barrier(0);  // issued before the transform, looked at after it
       // the transform's LDS addresses and twiddle pointers are loop invariants of the modulus / group loops: left alone the
       // compiler hoists some sixty of them over the loops and spills to make room (the fold kernels do the same)
       const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
@@ -248,6 +251,11 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4_pipe(DevTables T, const 
       asm volatile("" : "+v"(tk));
       __syncthreads();  // the exchange buffers are free (previous transform's last reads are done)
       ntt_inv_block_m<4>(v, tk, lds0, lds1, iw, iw + N, m.q, m.two_q);
+      __builtin_amdgcn_sched_barrier(0);
+      {  // never true (premod is 0 or 1): keeps the pulls alive until here
+        const u32 any = (pulled[0] | pulled[1]) | (pulled[2] | pulled[3]) | ((pulled[4] | pulled[5]) | (pulled[6] | pulled[7]));
+        if (any == 0xFFFFFFFFu && premod == 0x7FFFFFFF) v[0][0] ^= 1u;
+      }
       if (c == 0) {
 #pragma unroll
         for (int mm = 0; mm < 4; mm++)

@@ -40,6 +40,7 @@ void program_end() {
   g_rec_group = 0;
 }
 bool program_recording() { return g_rec != nullptr; }
+Program* program_current() { return g_rec; }
 void program_group_begin() {
   if (g_rec) g_rec_group++;
 }
@@ -132,7 +133,7 @@ bool program_record_fill_zero(u32* dst, size_t n_words) {
 }
 
 // ------------------------------------------------------------------------------------------------ kernel
-constexpr long PROGRAM_SPIN_LIMIT = 12000000;  // s_sleep 2 = ~128 clocks a turn: ~0.7 s at the very least, seconds in practice
+constexpr long PROGRAM_SPIN_LIMIT = 2000000;  // a turn = s_sleep 2 + one agent-scope load (~1-2 us): a few seconds
 
 __device__ __forceinline__ void program_barrier(unsigned* ctr, unsigned target) {
   __syncthreads();  // every wave of the workgroup has issued its stores of the phase and waited for them (vmcnt 0)
@@ -149,17 +150,23 @@ __device__ __forceinline__ void program_barrier(unsigned* ctr, unsigned target) 
   __syncthreads();
 }
 
+// The exchange buffers of the transforms live at module scope: a pointer PARAMETER of a non-inlined function is a generic
+// pointer and every access through it a flat_load / flat_store with an aperture check instead of a ds_ instruction.
+__shared__ __attribute__((aligned(16))) u32 g_program_lds[2 * LDS_WORDS];
+
 // One function per phase kind, NOT inlined: inlined into one kernel body the register allocator sees every kind's loop
 // invariants at once and spills (528 bytes of scratch per lane at 128 VGPRs); as calls, each kind gets the file to itself.
 #define SP_PHASE_FN __device__ __noinline__ static void
-SP_PHASE_FN phase_fwd(const DevTables& T, const Phase* ph, u32* lds) {
+SP_PHASE_FN phase_fwd(const DevTables& T, const Phase* ph) {
+  u32* const lds = g_program_lds;
   const int grid = gridDim.x, units = ph->units;
   for (int u = blockIdx.x; u < units; u += grid) {
     ntt_fwd_body(T, ph->fwd[0], u >> 1, u & 1, lds, lds + LDS_WORDS);
     __syncthreads();  // the LDS buffers are reused by the next unit
   }
 }
-SP_PHASE_FN phase_fwd3(const DevTables& T, const Phase* ph, u32* lds) {
+SP_PHASE_FN phase_fwd3(const DevTables& T, const Phase* ph) {
+  u32* const lds = g_program_lds;
   const int grid = gridDim.x, units = ph->units;
   const int n0 = ph->fwd[0].n_out, n1 = ph->fwd[1].n_out;
   for (int u = blockIdx.x; u < units; u += grid) {
@@ -169,14 +176,15 @@ SP_PHASE_FN phase_fwd3(const DevTables& T, const Phase* ph, u32* lds) {
     __syncthreads();
   }
 }
-SP_PHASE_FN phase_inv(const DevTables& T, const Phase* ph, u32* lds) {
+SP_PHASE_FN phase_inv(const DevTables& T, const Phase* ph) {
+  u32* const lds = g_program_lds;
   const int grid = gridDim.x, units = ph->units;
   for (int u = blockIdx.x; u < units; u += grid) {
     ntt_inv_body(T, ph->inv, u, lds, lds + LDS_WORDS);
     __syncthreads();
   }
 }
-SP_PHASE_FN phase_mac(const DevTables& T, const Phase* ph, u32*) {
+SP_PHASE_FN phase_mac(const DevTables& T, const Phase* ph) {
   const int grid = gridDim.x, units = ph->units;
   const int per = ph->mac[0].batch_inner * 16;
   for (int u = blockIdx.x; u < units; u += grid) {
@@ -184,7 +192,7 @@ SP_PHASE_FN phase_mac(const DevTables& T, const Phase* ph, u32*) {
     mac_body<14>(T, ph->mac[0], rem >> 4, outer, rem & 15);
   }
 }
-SP_PHASE_FN phase_mac2(const DevTables& T, const Phase* ph, u32*) {
+SP_PHASE_FN phase_mac2(const DevTables& T, const Phase* ph) {
   const int grid = gridDim.x, units = ph->units;
   const int b0 = ph->mac[0].batch_inner;
   for (int u = blockIdx.x; u < units; u += grid) {
@@ -192,7 +200,8 @@ SP_PHASE_FN phase_mac2(const DevTables& T, const Phase* ph, u32*) {
     mac_body<14>(T, ph->mac[which], which ? y - b0 : y, 0, u & 15);
   }
 }
-SP_PHASE_FN phase_small(const DevTables& T, const Phase* ph, u32* lds) {  // the elementwise kinds
+SP_PHASE_FN phase_small(const DevTables& T, const Phase* ph) {  // the elementwise kinds
+  u32* const lds = g_program_lds;
   const int grid = gridDim.x, units = ph->units;
   switch (ph->kind) {
     case PH_COPY_POLYS:
@@ -248,17 +257,16 @@ SP_PHASE_FN phase_small(const DevTables& T, const Phase* ph, u32* lds) {  // the
 
 __global__ __launch_bounds__(256, 4) void k_program(DevTables T, const Phase* __restrict__ phases, int n_phases, unsigned* ctr,
                                                     unsigned ctr_base) {
-  __shared__ __attribute__((aligned(16))) u32 lds[2 * LDS_WORDS];
   unsigned barriers = 0;
   for (int pi = 0; pi < n_phases; pi++) {
     const Phase* ph = phases + pi;
     switch (ph->kind) {
-      case PH_FWD: phase_fwd(T, ph, lds); break;
-      case PH_FWD3: phase_fwd3(T, ph, lds); break;
-      case PH_INV: phase_inv(T, ph, lds); break;
-      case PH_MAC: phase_mac(T, ph, lds); break;
-      case PH_MAC2: phase_mac2(T, ph, lds); break;
-      default: phase_small(T, ph, lds); break;
+      case PH_FWD: phase_fwd(T, ph); break;
+      case PH_FWD3: phase_fwd3(T, ph); break;
+      case PH_INV: phase_inv(T, ph); break;
+      case PH_MAC: phase_mac(T, ph); break;
+      case PH_MAC2: phase_mac2(T, ph); break;
+      default: phase_small(T, ph); break;
     }
     if (pi + 1 < n_phases && !ph->no_barrier) {
       barriers++;
