@@ -7,8 +7,8 @@ mkdir -p gpurun_out
 O=gpurun_out/r04_call3
 OFF="SPIRAL_EXPAND_PERSIST=0 SPIRAL_FINISH_PERSIST=0 SPIRAL_FROM_SWEEP_PIPE=0"
 stage() {  # name, env assignments, -k expression
-  local name=$1 envs=$2 expr=$3
-  ( time env $envs timeout 240 python -m pytest tests/test_gpu_parity.py tests/test_sparse_bucket.py tests/test_request_layer.py -m gpu -x -q -k "$expr" ) > ${O}_stage_${name}.txt 2>&1
+  local name=$1 envs=$2 expr=$3 tmo=${4:-240}
+  ( time env $envs timeout $tmo python -m pytest tests/test_gpu_parity.py tests/test_sparse_bucket.py tests/test_request_layer.py -m gpu -x -q -k "$expr" ) > ${O}_stage_${name}.txt 2>&1
   local rc=$?
   echo "stage $name rc=$rc: $(grep -E 'passed|failed|error' ${O}_stage_${name}.txt | tail -1)"
   if [ $rc -ne 0 ]; then tail -25 ${O}_stage_${name}.txt; echo "STOP at stage $name"; exit 1; fi
@@ -16,7 +16,7 @@ stage() {  # name, env assignments, -k expression
 stage s0_off "$OFF" "test_process_query_bytes_and_decode or wave_fold or fused_fold_kernel or overlapped_fold_many_planes"
 stage s1_pipe "SPIRAL_EXPAND_PERSIST=0 SPIRAL_FINISH_PERSIST=0" "test_process_query_bytes_and_decode or overlapped_fold_many_planes or ring_sweep"
 stage s2_expand "SPIRAL_FINISH_PERSIST=0" "expansion_variants or test_process_query_bytes_and_decode"
-stage s3_finish "SPIRAL_EXPAND_PERSIST=0" "test_process_query or config_sweep or sparse or private_read or pack"
+stage s3_finish "SPIRAL_EXPAND_PERSIST=0" "test_process_query_bytes_and_decode or config_sweep or sparse or private_read or pack or v1" 420
 ( time timeout 900 python -m pytest tests -m gpu -x -q --durations=12 ) > ${O}_pytest.txt 2>&1
 rc=$?
 tail -4 ${O}_pytest.txt
