@@ -1,7 +1,8 @@
 // Workgroup-level bodies of the small kernels of the answer path, written against an explicit unit index instead of
-// blockIdx: the stand-alone kernels (ntt.hip, elementwise.hip, fold.hip) call them with their block index, the phase-program
-// kernel (program.hip: a whole chain of dependent launches as ONE persistent launch with device-wide barriers) calls them
-// in a loop over the units of a phase.  Each body is the former kernel verbatim.
+// blockIdx: the stand-alone kernels (ntt.hip, elementwise.hip, fold.hip) call them with their block index.  (Round 4 also ran
+// them in a loop inside one persistent "phase program" kernel with device-wide barriers between the phases -- 2.5-4x
+// slower than the launches on this eight-XCD part; source and numbers under scripts/archive/r04_phase_program/ and
+// profiles/r04_phase_program.md.)
 #pragma once
 #include "device_common.hpp"
 

@@ -188,7 +188,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
-                                "fold_tail_batched", "sweep_ring", "finish_program"};
+                                "fold_tail_batched", "sweep_ring"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 

@@ -19,7 +19,6 @@ __global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d
 }
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
   if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_mac, dim3(d.batch_inner, 2 * N / 256, d.batch_outer), dim3(256), 0, s, T, d);
   launched(0, "k_mac");
 }
@@ -28,7 +27,6 @@ void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipSt
   a.batch_inner = std::max(a.batch_inner, 0);
   b.batch_inner = std::max(b.batch_inner, 0);
   if (a.batch_inner + b.batch_inner <= 0) return;
-  if (program_record(a, b)) return;
   hipLaunchKernelGGL(k_mac2, dim3(a.batch_inner + b.batch_inner, 2 * N / 256, 1), dim3(256), 0, s, T, a, b);
   launched(0, "k_mac2");
 }
@@ -38,7 +36,6 @@ __global__ __launch_bounds__(256) void k_add_poly_into(DevTables T, u32* dst, co
 }
 void launch_add_poly_into(const DevTables& T, u32* dst, const int* idx, const u32* src, int batch, hipStream_t s) {
   if (batch <= 0) return;
-  if (program_record(AddPolyIntoDesc{dst, idx, src, batch})) return;
   hipLaunchKernelGGL(k_add_poly_into, dim3(batch, 2 * N / 256), dim3(256), 0, s, T, dst, idx, src);
   launched(0, "k_add_poly_into");
 }
@@ -97,7 +94,6 @@ void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u
                        int src_row_stride, int R, int batch, hipStream_t s) {
   if (batch <= 0) return;
   const CopyPolysDesc d{dst, dst_idx, dst_row_stride, src, src_idx, src_row_stride, R, batch};
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_copy_polys, dim3(batch * R, 2 * N / 256), dim3(256), 0, s, d);
   launched(0, "k_copy_polys");
 }
@@ -130,7 +126,6 @@ __global__ __launch_bounds__(256) void k_copy_words(u32* dst, const u32* src, si
 }
 void launch_copy_words(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
   if (n_words == 0) return;
-  if (program_record(CopyWordsDesc{dst, src, n_words})) return;
   const unsigned blocks = (unsigned)std::min<size_t>((n_words + 255) / 256, 4096);
   hipLaunchKernelGGL(k_copy_words, dim3(blocks), dim3(256), 0, s, dst, src, n_words);
   launched(0, "k_copy_words");
@@ -142,7 +137,6 @@ __global__ __launch_bounds__(256) void k_folding_neg(DevTables T, FoldingNegDesc
 void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, hipStream_t s) {
   if (nu2 <= 0) return;
   const FoldingNegDesc d{mats, gadget_ntt, two_t, nu2};
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, d);
   launched(0, "k_folding_neg");
 }
@@ -221,7 +215,6 @@ void launch_u32_to_u64(u64* out, const u32* in, long n, hipStream_t s) {
 __global__ __launch_bounds__(256) void k_encode(EncodeDesc d) { encode_body(d, blockIdx.x); }
 void launch_encode(const EncodeDesc& d, hipStream_t s) {
   const long total = (long)d.instances * ((long)d.n * N + (long)d.n * d.n * N);
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_encode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, d);
   launched(0, "k_encode");
 }
@@ -233,7 +226,6 @@ __global__ __launch_bounds__(256) void k_reorient(ReorientDesc d) {
 }
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
   const ReorientDesc d{out, v, first, step, dim0};
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, d);
   launched(0, "k_reorient");
 }

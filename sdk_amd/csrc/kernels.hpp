@@ -42,7 +42,7 @@ enum PathBit : u64 {
   PATH_SCATTER_OUT = 1ull << 14,      // column-interleaved sweep output (multi-GPU reduce-scatter layout)
   PATH_SWEEP_XCD_FROM = 1ull << 15,   // k_from_sweep4 with the XCD-aware block order
   PATH_FOLD_TAIL_PERSIST = 1ull << 16,// (retired: k_fold_tail of round 1)
-  PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_persist (the whole expansion in ONE launch, device-wide barriers between phases)
+  PATH_EXPAND_FUSED = 1ull << 17,     // (retired: one-launch expansion experiments of rounds 2 and 4)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // RCCL collectives issued by the library itself (sp_comm_create)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
@@ -53,8 +53,7 @@ enum PathBit : u64 {
   PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
   PATH_FROM_SWEEP_WAVE = 1ull << 26,  // (retired: k_from_sweep_wave)
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
-  PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
-  PATH_FINISH_PROGRAM = 1ull << 29    // fold-tree tail levels and / or pack + encode as one launch of k_program (finish_persist)
+  PATH_SWEEP_RING = 1ull << 28        // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -230,7 +229,7 @@ void launch_encode(const EncodeDesc& d, hipStream_t s);
 // v (NTT cts, 2 polys each) at ct indices first + step*j, j < dim0  ->  out[z][j][r] = lo | hi << 32
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s);
 
-// ---- descriptors of the small elementwise kernels (also the operands of the phase program's phases) ------------------
+// ---- descriptors of the small elementwise kernels ------------------------------------------------------------------
 struct CopyPolysDesc {  // launch_copy_polys
   u32* dst;
   const int* dst_idx;
@@ -265,72 +264,6 @@ struct CopyWordsDesc {  // launch_copy_words
   const u32* src;
   size_t n_words;
 };
-
-// ---- phase program (program.hip): a chain of dependent small launches as ONE persistent launch ---------------------------
-// The answer path around the sweep is chains of small dependent kernels -- 30 for coefficient_expansion, 3 per level of the
-// fold-tree tail, 5 for pack -- each 7-12 us of launch + ramp + drain for a few microseconds of work (a C2 query spends
-// 0.74 ms in its expansion for ~0.3 ms of arithmetic; at C1 that is 60 % of the query).  A Program records such a chain
-// instead of launching it: while program_begin() is in effect on the calling thread, every launch_* wrapper below appends
-// its descriptor as a PHASE and returns; program_launch() then runs all phases in one launch of a persistent grid
-// (k_program), each workgroup looping over the units of a phase (the former workgroups) and a device-wide barrier between
-// phases.  Same kernels' bodies (bodies.hpp), same order, same results.
-enum PhaseKind : int {
-  PH_FWD = 0, PH_FWD3, PH_INV, PH_MAC, PH_MAC2, PH_COPY_POLYS, PH_FOLDING_NEG, PH_REORIENT, PH_MATS_TO_WAVE, PH_ADD_POLY_INTO,
-  PH_ENCODE, PH_COPY_WORDS, PH_FILL_ZERO
-};
-struct Phase {
-  int kind;
-  int units;       // workgroup-sized units of work in this phase
-  int no_barrier;  // 1: the NEXT phase does not depend on this one (no device-wide barrier in between)
-  int pad_;
-  union {
-    FwdDesc fwd[3];
-    InvDesc inv;
-    MacDesc mac[2];
-    CopyPolysDesc copy_polys;
-    FoldingNegDesc folding_neg;
-    ReorientDesc reorient;
-    MatsToWaveDesc mats_to_wave;
-    AddPolyIntoDesc add_poly_into;
-    EncodeDesc encode;
-    CopyWordsDesc copy_words;  // also PH_FILL_ZERO (dst, n_words)
-  };
-};
-struct Program {
-  std::vector<Phase> phases;   // host copy, as recorded by the last program_begin .. program_end
-  std::vector<Phase> on_device;  // what the device buffer holds (re-uploaded only when the recording differs)
-  Phase* dev = nullptr;        // device copy (capacity dev_cap phases)
-  size_t dev_cap = 0;
-  unsigned* ctr = nullptr;     // barrier counter (device, monotonic) and the value it will have reached after the launches so far
-  unsigned ctr_next = 0;
-  ~Program();
-  Program() = default;
-  Program(const Program&) = delete;
-  Program& operator=(const Program&) = delete;
-};
-void program_begin(Program& p);   // the calling thread's launch_* wrappers record into p from here ...
-void program_end();               // ... to here
-bool program_recording();
-Program* program_current();       // the program being recorded on this thread, or null
-// independent consecutive launches: the phases recorded between program_group_begin / _end need no barrier between them
-void program_group_begin();
-void program_group_end();
-// one launch of k_program on s (nothing if no phase was recorded); workgroups per CU from the switch program_wgs (default 2)
-void program_launch(const DevTables& T, Program& p, hipStream_t s, u64 path_bits);
-// hooks used by the launch wrappers: false = not recording, launch as usual
-bool program_record(const FwdDesc& d);
-bool program_record(const FwdDesc& a, const FwdDesc& b, const FwdDesc& c);
-bool program_record(const InvDesc& d);
-bool program_record(const MacDesc& d);
-bool program_record(const MacDesc& a, const MacDesc& b);
-bool program_record(const CopyPolysDesc& d);
-bool program_record(const FoldingNegDesc& d);
-bool program_record(const ReorientDesc& d);
-bool program_record(const MatsToWaveDesc& d);
-bool program_record(const AddPolyIntoDesc& d);
-bool program_record(const EncodeDesc& d);
-bool program_record(const CopyWordsDesc& d);
-bool program_record_fill_zero(u32* dst, size_t n_words);
 
 // ---- database sweep (server.rs:155-221) -----------------------------------------------------
 // Device DB layout per plane: [z][j_local][ii] u64 (word = lo28 | hi28<<32): the reference's

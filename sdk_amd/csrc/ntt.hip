@@ -90,7 +90,6 @@ __global__ __launch_bounds__(256) void k_ntt_fwd3(DevTables T, FwdDesc d0, FwdDe
 }
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
   if (d.n_out <= 0) return;
-  if (program_record(d)) return;
   hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
   launched(0, "k_ntt_fwd");
 }
@@ -101,7 +100,6 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
   a.n_out = std::max(a.n_out, 0);
   b.n_out = std::max(b.n_out, 0);
   c.n_out = std::max(c.n_out, 0);
-  if (program_record(a, b, c)) return;
   hipLaunchKernelGGL(k_ntt_fwd3, dim3(total, 2), dim3(256), 0, s, T, a, b, c);
   launched(0, "k_ntt_fwd3");
 }
@@ -119,7 +117,6 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
   const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);
   if (blocks <= 0) return;
-  if (d.sweep_np <= 0 && program_record(d)) return;
   hipLaunchKernelGGL(k_ntt_inv, dim3(blocks), dim3(256), 0, s, T, d);
   launched(d.sweep_np > 0 ? PATH_FROM_SWEEP1 : 0, "k_ntt_inv");
 }

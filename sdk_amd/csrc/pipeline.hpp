@@ -20,9 +20,6 @@ struct Workspace {
   hipEvent_t ev_sw[2] = {nullptr, nullptr};  // first sweep launch begins / last sweep launch done (timing)
   bool have_sweep_span = false;
   bool pipelined = false;                   // set by run_sweep_pipelined, consumed by run_finish
-  Program prog_expand;                      // the expansion chain as one persistent launch (switch expand_persist)
-  Program prog_tail;                        // fold-tree tail (+ pack + encode when the fold runs inside sp_query_finish) as one persistent launch (switch finish_persist)
-  Program prog_pack;                        // pack + encode alone (pipelined and sharded queries: their tails ran earlier)
   hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};  // begin, after expand, after sweep, after fold, end
   // expansion
   DevBuf<u64> q_raw;      // query ct, raw 2x1
@@ -88,8 +85,7 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db);
 bool sweep_is_pipelined(const Params& p, const sp_db& db);
 void launch_plane_sweep(Workspace& W, const sp_db& db, size_t plane);
 bool fused_fold_supported(const Params& p);
-// may_record: this call's tail levels may open the workspace's finishing program (the caller closes and launches it)
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1, bool may_record = false);
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1);
 void run_fold_local(Workspace& W, const u32* reduced_chunk, int G);
 void run_fold_local_plane(Workspace& W, const u32* reduced_plane_chunk, int G, int plane);
 void run_fold_local_join(Workspace& W);

@@ -191,9 +191,6 @@ void launched(u64 bits, const char* kernel) {
   g_paths |= bits;
   const hipError_t e = hipGetLastError();
   if (e != hipSuccess) throw HipError(std::string("launch of ") + kernel + " failed: " + hipGetErrorString(e));
-  // a real launch while a phase program is being recorded would run BEFORE the recorded phases it depends on
-  if (program_recording() && strcmp(kernel, "k_program") != 0)
-    throw HipError(std::string("internal: ") + kernel + " was launched while a phase program was being recorded");
   // debug_sync: 1 = device-wide synchronisation after every launch (tells a race from a logic error); 11 / 12 / 13 =
   // only after the launches of the expansion / sweep / fold-pack-encode stage; 2 = only at the stage boundaries (capi.cpp)
   const long ds = tunable("debug_sync", 0);
@@ -762,7 +759,6 @@ void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int
   inv.dst = W.gsw_raw.p;
   inv.n_polys = nb * 2;
   launch_ntt_inv(D.T, inv, s);
-  program_group_end();  // (recording: the caller's group -- reorientation, the copy above, this inverse -- ends here)
   FwdDesc f{};
   f.src = W.gsw_raw.p;
   f.dst = W.gsw_dig.p;
@@ -879,30 +875,6 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
   const DeviceState::PrunedPlan* pl = plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
-  // expand_persist (default 1): the whole chain -- NTT of the query, g rounds of three dependent launches, reorientation,
-  // regev_to_gsw, G - C, wave re-layout: ~40 launches of 7-12 us for ~0.3 ms of arithmetic at C2 -- is RECORDED and runs
-  // as ONE launch of the persistent phase-program kernel (program.hip) with device-wide barriers between the phases.
-  if (tunable("expand_persist", 1) != 0) {
-    program_begin(W.prog_expand);
-    try {
-      launch_ntt_fwd(D.T, f, s);
-      run_coefficient_expansion(W, pp, g, pl);
-      if (p.db_dim_2 > 0) {
-        program_group_begin();   // the reorientation and regev_to_gsw's first two launches are independent (group ends inside)
-        launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
-        run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-        run_folding_neg(W);
-      } else {
-        launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), s);  // server.rs:574-576
-      }
-    } catch (...) {
-      program_end();
-      throw;
-    }
-    program_end();
-    program_launch(D.T, W.prog_expand, s, PATH_EXPAND_FUSED);
-    return;
-  }
   launch_ntt_fwd(D.T, f, s);
   const long split_mode = tunable("expand_split", -1);  // -1: only when a long sweep follows (it hides the odd subtree)
   if (p.db_dim_2 > 0 && g >= 2 && (split_mode > 0 || (split_mode < 0 && W.long_sweep_follows))) {
@@ -913,7 +885,11 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
     // fold_mats order themselves after ev_right (join_right).  Measured (profiles/r02_expand_experiments.md): -6 % at C2,
     // nothing at C1/P2, where the odd subtree then competes with the short sweep.  The enqueue order of the two sides and a
     // one-launch-per-round kernel (one workgroup per ciphertext) were measured in round 2 and bought nothing
-    // (profiles/r02_expand_order.txt, r02_expand_experiments.md); both are gone.
+    // (profiles/r02_expand_order.txt, r02_expand_experiments.md); both are gone.  Round 4 ran the WHOLE chain as one
+    // persistent launch with device-wide barriers between its ~40 phases: byte-identical and 2.5-4x
+    // SLOWER (C2 expansion 0.71 -> 2.7 ms) -- on this eight-XCD part a device-wide barrier is an L2 write-back +
+    // invalidate per XCD plus hundreds of serialised memory-side atomics, i.e. what a kernel boundary costs, paid by every
+    // workgroup; source and numbers: scripts/archive/r04_phase_program/, profiles/r04_phase_program.md.
     note_path(PATH_EXPAND_SPLIT);
     run_coefficient_expansion(W, pp, 1, pl, 0, 0);
     HIP_CHECK(hipEventRecord(W.ev_round0, s));
@@ -961,28 +937,8 @@ void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const i
                       p.db_dim_2 > 0 ? 2 : 1, W.sweep_out.p, (int)p.num_per(), W.stream);
 }
 
-// finish_persist (default 1): the small dependent launches at the END of a query -- the fold tree's tail levels (three
-// launches per level), the copy of the folded ciphertexts, pack (five launches), encode -- are recorded and run as ONE launch
-// of the phase-program kernel (program.hip), like the expansion at the beginning.  A program never spans two API calls
-// (the recorder is thread-local state): the pipelined query launches its batched tails from sp_query_sweep and pack + encode
-// from sp_query_finish, everything else runs tail + pack + encode as one program from sp_query_finish.
-static bool finish_persist_on() { return tunable("finish_persist", 1) != 0; }
-// device-to-device copy of raw ciphertext words in stream order: a phase while a program is being recorded
-static void copy_cts(Workspace& W, u64* dst, const u64* src, size_t words) {
-  if (program_recording())
-    launch_copy_words(reinterpret_cast<u32*>(dst), reinterpret_cast<const u32*>(src), words * 2, W.stream);
-  else
-    HIP_CHECK(hipMemcpyAsync(dst, src, words * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
-}
-static void finish_program_launch(Workspace& W, u64 bits) {
-  Program* prog = program_current();
-  if (!prog) return;
-  program_end();
-  program_launch(W.D->T, *prog, W.stream, bits);
-}
-
 // from_ntt + fold of `np` planes starting at plane pg0 (sweep_out -> final_cts), on W.stream
-static void fold_planes(Workspace& W, size_t pg0, int np, bool premod, bool last_group = false) {
+static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
@@ -998,10 +954,8 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod, bool last
     inv.premod = premod ? 1 : 0;
     launch_ntt_inv(D.T, inv, s);
   }
-  // the last group's tail levels may open the finishing program (run_finish closes and launches it)
-  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1, 0, -1, last_group);
-  copy_cts(W, W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN);
-  (void)s;
+  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 
 // Pipelined queries (switch pipe_tail_defer = cts per plane, 0 = off): under the sweeps a plane is folded only down to
@@ -1027,14 +981,8 @@ static void fold_tails(Workspace& W, int levels) {  // the parked planes togethe
   const Params& p = *W.P;
   const size_t cts = p.num_per() >> levels;
   u64* other = W.fold_tail.p + p.planes() * cts * 2 * POLY_LEN;
-  try {
-    u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1, true);
-    copy_cts(W, W.final_cts.p, res, p.planes() * 2 * POLY_LEN);
-    finish_program_launch(W, PATH_FINISH_PROGRAM);  // (this runs inside sp_query_sweep: the program ends here)
-  } catch (...) {
-    program_end();
-    throw;
-  }
+  u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1);
+  HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, p.planes() * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
 }
 
 // Single-GPU query on a wide PACKED database: the database is swept one (instance, trial) plane per launch, and
@@ -1097,7 +1045,7 @@ bool fused_fold_supported(const Params& p) { return 4 * p.t_gsw <= 128 && p.bits
 
 // fold_ciphertexts (server.rs:388-427) on `np` planes of `num_cts` raw cts each, dense in X;
 // result ct of plane i ends up at the returned buffer + i*2N.
-u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin, int d_end, bool may_record) {
+u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin, int d_end) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
@@ -1133,8 +1081,6 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
       cur = half;
       continue;
     }
-    // a tail level: three small dependent launches.  From the first one on they are phases of the finishing program
-    if (may_record && finish_persist_on() && !program_recording()) program_begin(W.prog_tail);
     if (W.delta_tail) {
       // tree tail in the same delta form as k_fold_fused (half the digit transforms, C only), digit-parallel
       FwdDesc f{};
@@ -1340,8 +1286,7 @@ void run_pack(Workspace& W, const sp_pp& pp) {
 void run_fold_all(Workspace& W, bool premod) {
   const Params& p = *W.P;
   const size_t pg = W.plane_group();
-  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg)
-    fold_planes(W, pg0, (int)std::min(pg, p.planes() - pg0), premod, pg0 + pg >= p.planes());
+  for (size_t pg0 = 0; pg0 < p.planes(); pg0 += pg) fold_planes(W, pg0, (int)std::min(pg, p.planes() - pg0), premod);
 }
 
 // ---- encode (server.rs:470-503) on the host: rescale (arith.rs:429-444) + LSB-first bit packing
@@ -1460,26 +1405,15 @@ void run_finish_gathered(Workspace& W, const sp_pp& pp, const u64* gathered, int
   u64* res = run_fold(W, W.foldX.p, W.foldY.p, planes, G, lg - 1);
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, (size_t)planes * ctw * sizeof(u64), hipMemcpyDeviceToDevice, s));
   HIP_CHECK(hipEventRecord(W.ev[3], s));
-  try {
-    // (packing version 1 uses a kernel the recorder does not know: its pack runs as launches, after the recorded tail)
-    if (W.P->version == 1)
-      finish_program_launch(W, PATH_FINISH_PROGRAM);
-    else if (finish_persist_on() && !program_recording())
-      program_begin(W.prog_pack);
-    run_pack(W, pp);
-    run_encode_device(W);
-  } catch (...) {
-    program_end();
-    throw;
-  }
+  run_pack(W, pp);
+  run_encode_device(W);
   HIP_CHECK(hipEventRecord(W.ev[4], s));
 }
 
 void run_encode_device(Workspace& W) {
   const Params& p = *W.P;
   hipStream_t s = W.stream;
-  if (!program_record_fill_zero(reinterpret_cast<u32*>(W.enc_out.p), W.enc_out.bytes() / 4))
-    HIP_CHECK(hipMemsetAsync(W.enc_out.p, 0, W.enc_out.bytes(), s));
+  HIP_CHECK(hipMemsetAsync(W.enc_out.p, 0, W.enc_out.bytes(), s));
   EncodeDesc e{};
   e.packed = W.pack_raw.p;
   e.out = reinterpret_cast<unsigned long long*>(W.enc_out.p);
@@ -1493,32 +1427,21 @@ void run_encode_device(Workspace& W) {
   e.q1_bits = q1_bits;
   e.q2_bits = (int)p.q2_bits;
   launch_encode(e, s);
-  finish_program_launch(W, PATH_FINISH_PROGRAM);  // (no-op unless a finishing program is being recorded)
   HIP_CHECK(hipMemcpyAsync(W.h_response, W.enc_out.p, p.response_bytes(), hipMemcpyDeviceToHost, s));
 }
 
 void run_finish(Workspace& W, const sp_pp& pp, bool premod) {
   const Params& p = *W.P;
   W.ensure_finish();
-  try {
-    if (W.pipelined) {  // folds were issued by run_sweep_pipelined on stream2
-      HIP_CHECK(hipStreamWaitEvent(W.stream, W.ev_fold, 0));
-      W.pipelined = false;
-    } else {
-      run_fold_all(W, premod);
-    }
-    HIP_CHECK(hipEventRecord(W.ev[3], W.stream));  // (tail levels recorded into the finishing program run after this mark)
-    // (packing version 1 uses a kernel the recorder does not know: its pack runs as launches, after the recorded tail)
-    if (W.P->version == 1)
-      finish_program_launch(W, PATH_FINISH_PROGRAM);
-    else if (finish_persist_on() && !program_recording())
-      program_begin(W.prog_pack);
-    run_pack(W, pp);
-    run_encode_device(W);
-  } catch (...) {
-    program_end();
-    throw;
+  if (W.pipelined) {  // folds were issued by run_sweep_pipelined on stream2
+    HIP_CHECK(hipStreamWaitEvent(W.stream, W.ev_fold, 0));
+    W.pipelined = false;
+  } else {
+    run_fold_all(W, premod);
   }
+  HIP_CHECK(hipEventRecord(W.ev[3], W.stream));
+  run_pack(W, pp);
+  run_encode_device(W);
   HIP_CHECK(hipEventRecord(W.ev[4], W.stream));
   (void)p;
 }

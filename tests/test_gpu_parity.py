@@ -1150,20 +1150,16 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
 
 
-@pytest.mark.parametrize("mode", ["split", "launches", "persist", "persist-4wg"])
+@pytest.mark.parametrize("mode", ["split", "launches"])
 @pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
 def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
-    """The expansion schedules over gadget widths from 2 to 56 digits, 28-bit digits included: the default (one persistent
-    launch with device-wide barriers between the ~40 phases), one launch per step, and the odd subtree + GSW side on the
-    second stream (SPIRAL_EXPAND_SPLIT, profiles/r02_expand_experiments.md); expand_query and the response must not change,
-    twice in a row on the same workspace (the barrier counter carries over)."""
+    """The expansion schedules over gadget widths from 2 to 56 digits, 28-bit digits included: everything on one stream, and
+    the odd subtree + GSW side on the second stream (SPIRAL_EXPAND_SPLIT, profiles/r02_expand_experiments.md); expand_query
+    and the response must not change, twice in a row on the same workspace (join of the previous odd side)."""
     cfg = _FUZZ[ci]
-    # persist (the default): the whole chain recorded and run as ONE launch of the phase-program kernel (program.hip);
-    # launches: one launch per step of the chain; split: launches, with the odd subtree on the second stream
-    monkeypatch.setenv("SPIRAL_EXPAND_PERSIST", "1" if mode.startswith("persist") else "0")
+    # launches (the default of narrow databases): one stream; split (the default before a pipelined sweep): the odd subtree
+    # + GSW side on the second stream
     monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1" if mode == "split" else "0")
-    if mode == "persist-4wg":
-        monkeypatch.setenv("SPIRAL_PROGRAM_WGS", "4")
     o = oracle_mod.Params(cfg)
     idx = (613 * (ci + 1)) % o.num_items
     cl = oracle_mod.Client(o)
@@ -1176,7 +1172,7 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     sp.paths_taken()
     v_reg, v_fold = sp.expand_query(p, gpp, q)
     taken = sp.paths_taken()
-    assert ("expand_split" in taken) == (mode == "split") and ("expand_head_fused" in taken) == mode.startswith("persist"), taken
+    assert ("expand_split" in taken) == (mode == "split"), taken
     e_reg, e_fold = o.expand_query(pp, q)
     assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
     expect = o.process_query(pp, q, db)
