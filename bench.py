@@ -87,7 +87,7 @@ def pmc_traffic(cfg_name, world, launches):
     tracked record and `traffic_source` says so.  (None, None) when no matching record exists."""
     if cfg_name != "c2" or world != 1:
         return None, None
-    for name in ("r03_final_pmc_sweep_c2.json", "r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
+    for name in ("r04_final_pmc_sweep_c2.json", "r03_final_pmc_sweep_c2.json", "r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             rec = json.load(open(path))

@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void k_read_quarters(const u32* db, u32* sink,
 struct Ctx {
   int nz, num_per, nj, chunks, npairs, batch;
   u32* db;
-  u64* qv[8];
+  u64* qv[16];
   u32* rq;
-  u32* out[8];
+  u32* out[16];
   DevTables T;
   SweepMfmaDesc d;
 };
@@ -226,6 +226,45 @@ static void run_variant(Ctx& c, int cpw, size_t lds_pad, int reps, const char* t
   printf("[mfma %s] NB=%d MINWG=%d cpw=%d lds=%zu regs=%d: best %.3f ms avg %.3f ms per plane-pass of %d z-rows = %.0f GB/s of database (x4 planes: %.2f ms per B=8 pass)\n",
          tag, NB, MINWG, cpw, lds, fa.numRegs, best, sum / reps, c.nz, bytes / (best * 1e-3) / 1e9, 4.0 * best * 2048.0 / c.nz);
   if (DIAG == 0) verify(c, tag, 400);
+}
+
+// QT = 2: sixteen queries per pass (two digit tables in LDS: one workgroup per CU)
+template <int NB, int DIAG = 0>
+static void run_variant16(Ctx& c, int cpw, int reps, const char* tag) {
+  c.d.cpw = cpw;
+  const int batch_was = c.batch;
+  c.batch = 16;
+  c.d.batch = 16;
+  const size_t lds = (size_t)c.nj * 128 * 2;
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB, 1, DIAG, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  for (int b = 0; b < 16; b++) CK(hipMemset(c.out[b], 0xEE, (size_t)4 * N * c.num_per * 4));
+  const dim3 grid((unsigned)((size_t)c.nz * (c.chunks / cpw)));
+  hipEvent_t e0, e1;
+  CK(hipEventCreate(&e0));
+  CK(hipEventCreate(&e1));
+  hipLaunchKernelGGL((k_sweep_mfma_batch<NB, 1, DIAG, 2>), grid, dim3(256), lds, 0, c.T, c.d);
+  CK(hipGetLastError());
+  CK(hipDeviceSynchronize());
+  float best = 1e9f, sum = 0;
+  for (int r = 0; r < reps; r++) {
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_sweep_mfma_batch<NB, 1, DIAG, 2>), grid, dim3(256), lds, 0, c.T, c.d);
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    best = ms < best ? ms : best;
+    sum += ms;
+  }
+  const double bytes = (double)c.nz * c.chunks * c.npairs * 1792.0;
+  hipFuncAttributes fa;
+  CK(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB, 1, DIAG, 2>)));
+  printf("[mfma16 %s] QT=2 NB=%d cpw=%d lds=%zu regs=%d scratch=%zu: best %.3f ms avg %.3f ms per plane-pass of %d z-rows = %.0f GB/s of database (x4 planes: %.2f ms per B=16 pass = %.3f ms per query)\n",
+         tag, NB, cpw, lds, fa.numRegs, (size_t)fa.localSizeBytes, best, sum / reps, c.nz, bytes / (best * 1e-3) / 1e9, 4.0 * best * 2048.0 / c.nz,
+         4.0 * best * 2048.0 / c.nz / 16.0);
+  if (DIAG == 0) verify(c, tag, 400);
+  c.batch = batch_was;
+  c.d.batch = batch_was;
 }
 
 template <int NB, int DIAG = 0>
@@ -323,12 +362,12 @@ int main(int argc, char** argv) {
   CK(hipMalloc(&c.db, db_dwords * 4 + 65536));
   k_fill_db<<<256 * 32, 256>>>(c.db, db_dwords + 16384);
   const size_t qn = (size_t)N * c.nj * 2;
-  for (int b = 0; b < 8; b++) {
+  for (int b = 0; b < 16; b++) {
     CK(hipMalloc(&c.qv[b], qn * 8));
     k_fill_q<<<(unsigned)((qn + 255) / 256), 256>>>(c.qv[b], b, qn);
     CK(hipMalloc(&c.out[b], (size_t)4 * N * c.num_per * 4 * (b == 0 ? 8 : 1)));
   }
-  CK(hipMalloc(&c.rq, (size_t)N * (c.nj / 16) * 128 * 16 + (size_t)N * 32 * 4));  // digit table + offset terms
+  CK(hipMalloc(&c.rq, 2 * ((size_t)N * (c.nj / 16) * 128 * 16 + (size_t)N * 32 * 4)));  // two digit tables + two sets of offset terms
   CK(hipDeviceSynchronize());
   printf("database: %d z-rows x %d columns x %d rows = %.2f GB packed\n", nz, c.num_per, c.nj, db_dwords * 4 / 1e9);
 
@@ -397,16 +436,26 @@ int main(int argc, char** argv) {
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("[k_query_digits] %.3f ms for 8 queries\n", ms);
   CK(hipEventRecord(e0));
-  k_query_offset_terms<<<N, 256>>>(c.T, qd, c.rq + entries * 4);
+  k_query_offset_terms<<<N, 256>>>(c.T, qd, c.rq + 2 * entries * 4);
   CK(hipEventRecord(e1));
   CK(hipEventSynchronize(e1));
   CK(hipEventElapsedTime(&ms, e0, e1));
   printf("[k_query_offset_terms] %.3f ms for 8 queries\n", ms);
 
+  {  // second tile: queries 8 .. 15 -> table 1 / offset terms 1 (layout [tile][N][...], tables first, then the offset terms)
+    QueryDigitsDesc qd2 = qd;
+    for (int b = 0; b < 8; b++) qd2.qv[b] = c.qv[8 + b];
+    qd2.rq = c.rq + entries * 4;
+    k_query_digits<<<(unsigned)((entries + 255) / 256), 256>>>(qd2);
+    // offset terms: [tile 0][N][32] right after BOTH tables, then [tile 1][N][32]
+    k_query_offset_terms<<<N, 256>>>(c.T, qd, c.rq + 2 * entries * 4);
+    k_query_offset_terms<<<N, 256>>>(c.T, qd2, c.rq + 2 * entries * 4 + (size_t)N * 32);
+    CK(hipDeviceSynchronize());
+  }
   c.d.db = reinterpret_cast<const u64*>(c.db);
   c.d.rq = c.rq;
-  c.d.rq_off = c.rq + entries * 4;
-  for (int b = 0; b < 8; b++) c.d.out[b] = c.out[b];
+  c.d.rq_off = c.rq + 2 * entries * 4;
+  for (int b = 0; b < 16; b++) c.d.out[b] = c.out[b];
   c.d.batch = 8;
   c.d.planes = 1;
   c.d.num_per = c.num_per;
@@ -434,6 +483,17 @@ int main(int argc, char** argv) {
     mfma_rate<8>(3, o);
   }
   run_variant<2, 2>(c, 16, 0, reps, "a");
+  if (getenv("MFMA_UBENCH_B16")) {  // round 4: sixteen queries per pass
+    run_variant16<2>(c, 16, reps, "QT2 NB=2");
+    run_variant16<4>(c, 16, reps, "QT2 NB=4");
+    run_variant16<8>(c, 16, reps, "QT2 NB=8");
+    run_variant16<4>(c, 4, reps, "QT2 NB=4 cpw=4");
+    run_variant16<4, 4>(c, 16, reps, "QT2 NB=4 DIAG4 no stores");
+    run_variant16<4, 1>(c, 16, reps, "QT2 NB=4 DIAG1 compute only");
+    run_variant<4, 1>(c, 16, 32768, reps, "B=8 forced 1 WG/CU NB=4 (reference)");
+    run_variant<2, 2>(c, 16, 0, reps, "a again");
+    return 0;
+  }
   run_variant6<2>(c, 16, reps, "six-wave NB=2");
   run_variant6<1>(c, 16, reps, "six-wave NB=1");
   run_variant6<2>(c, 8, reps, "six-wave NB=2 cpw=8");

@@ -40,12 +40,13 @@ __host__ __device__ __forceinline__ u32 signed_digits(u32 x) { return (x + DIGIT
 constexpr u32 DIGIT_OFFSET = 0x80808080u;  // = 128 (1 + 2^8 + 2^16 + 2^24), also the value the offsets add up to
 __host__ __device__ __forceinline__ u32 offset_digits(u32 x) { return x ^ DIGIT_OFFSET; }
 
+constexpr int SWEEP_MFMA_MAX = 16;  // two query tiles of 8 queries (16 query columns = one MFMA M dimension) per pass
 struct SweepMfmaDesc {
   const u64* db;                  // PACKED database: plane 0 of the launch
-  const u32* rq;                  // query digit table [N][nj / 16][2][64][4] (k_query_digits)
-  const u32* rq_off;              // offset terms [N][2][16]: DIGIT_OFFSET * sum_j y_j mod q per (z, crt, query column)
-  u32* out[SWEEP_BATCH_MAX];      // per query: sweep-native [plane][r][crt][z][ii]
-  int batch;                      // 1 .. 8 (unused query columns of the table are zero)
+  const u32* rq;                  // query digit table [tile][N][nj / 16][2][64][4] (k_query_digits, one call per tile of 8 queries)
+  const u32* rq_off;              // offset terms [tile][N][2][16]: DIGIT_OFFSET * sum_j y_j mod q per (z, crt, query column)
+  u32* out[SWEEP_MFMA_MAX];       // per query: sweep-native [plane][r][crt][z][ii]
+  int batch;                      // 1 .. 8 QT (unused query columns of the tables are zero)
   int planes, num_per, nj;        // nj % 16 == 0, nj <= 512 (LDS-staged table), num_per % 128 == 0
   int cpw;                        // chunks per workgroup, divides num_per / 128
   u32 c4[2], c5[2], c6[2];        // 2^32, 2^40, 2^48 mod q_crt
@@ -118,7 +119,11 @@ __device__ __forceinline__ u32 combine_digit_sums(int d0, int d1, int d2, int d3
 // digit extraction, no operand shifts: loads + MFMA only), 4 = no output stores, 5 = every workgroup stores to the first
 // z-row and chunk (writes stay in L2), 6 = plain instead of non-temporal stores (results valid), 7 = the 4 KiB a wave produces per chunk
 // stored as one contiguous block of out[0] (16 KiB per workgroup and chunk, 256 KiB per z-row: layout experiment).  Results are meaningless for DIAG 1-5.
-template <int NB, int MINWG, int DIAG = 0>
+// QT = query tiles per pass (r04): with QT = 2 sixteen queries share ONE pass -- the database words are loaded and split
+// into digits once (60 of the 139 VALU instructions of a 16-row step) and multiplied against two digit tables; the
+// accumulators (2 x 112 registers) then need the whole register file: one workgroup per CU (MINWG = 1), accumulators in
+// AGPRs, and a deeper load ring (NB) to keep the HBM pipe full with one wave per SIMD.
+template <int NB, int MINWG, int DIAG = 0, int QT = 1>
 __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, SweepMfmaDesc d) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_rq[];
   const int lane = threadIdx.x & 63;
@@ -130,19 +135,22 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
   const int chunk0 = (blockIdx.x - zp * wgs_per_zp) * d.cpw;
   const int z = zp & (N - 1), plane = zp >> POLY_LEN_LOG2;
   const int steps = d.nj >> 4, npairs = d.nj >> 1;
-  {  // this z's digit table -> LDS (steps * 2 KiB): up to 16 loads per thread in flight, then the LDS writes
-    const mf_u32x4_t* src = reinterpret_cast<const mf_u32x4_t*>(d.rq) + (size_t)z * steps * 128;
-    mf_u32x4_t* dst = reinterpret_cast<mf_u32x4_t*>(smem_rq);
-    const int n16 = steps * 128;
-    int i0 = 0;
-    for (; i0 + 16 * 256 <= n16; i0 += 16 * 256) {  // no bounds checks inside: a guarded load costs a branch + vmcnt(0)
-      mf_u32x4_t t[16];
+  const int n16 = steps * 128;   // 16-byte entries of one tile's z-row
+  {  // this z's digit table(s) -> LDS (steps * 2 KiB per tile): up to 16 loads per thread in flight, then the LDS writes
 #pragma unroll
-      for (int k = 0; k < 16; k++) t[k] = src[i0 + k * 256 + threadIdx.x];
+    for (int qt = 0; qt < QT; qt++) {
+      const mf_u32x4_t* src = reinterpret_cast<const mf_u32x4_t*>(d.rq) + ((size_t)qt * N + z) * n16;
+      mf_u32x4_t* dst = reinterpret_cast<mf_u32x4_t*>(smem_rq) + (size_t)qt * n16;
+      int i0 = 0;
+      for (; i0 + 16 * 256 <= n16; i0 += 16 * 256) {  // no bounds checks inside: a guarded load costs a branch + vmcnt(0)
+        mf_u32x4_t t[16];
 #pragma unroll
-      for (int k = 0; k < 16; k++) dst[i0 + k * 256 + threadIdx.x] = t[k];
+        for (int k = 0; k < 16; k++) t[k] = src[i0 + k * 256 + threadIdx.x];
+#pragma unroll
+        for (int k = 0; k < 16; k++) dst[i0 + k * 256 + threadIdx.x] = t[k];
+      }
+      for (int i = i0 + threadIdx.x; i < n16; i += 256) dst[i] = src[i];
     }
-    for (int i = i0 + threadIdx.x; i < n16; i += 256) dst[i] = src[i];
     __syncthreads();
   }
   const mf_u32x4_t* rql = reinterpret_cast<const mf_u32x4_t*>(smem_rq) + lane;
@@ -159,16 +167,22 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
   // store instruction wrote 16-byte pieces of 16 arrays: +38 % on the pass).  Queries b = 2 kb and 2 kb + 1 of this lane
   // group: their output arrays are picked from the kernel-argument pointers with scalar loads + v_cndmask -- a VECTOR
   // load d.out[b] in the epilogue would need s_waitcnt vmcnt(0), i.e. drain the prefetch ring at every chunk end.
-  u32* out_b0 = d.out[0];
-  u32* out_b1 = d.out[1];
+  u32* out_b0[QT];
+  u32* out_b1[QT];
+  mf_u32x4_t off0[QT], off1[QT];
 #pragma unroll
-  for (int k2 = 1; k2 < SWEEP_BATCH_MAX / 2; k2++) {
-    out_b0 = kb == k2 ? d.out[2 * k2] : out_b0;
-    out_b1 = kb == k2 ? d.out[2 * k2 + 1] : out_b1;
+  for (int qt = 0; qt < QT; qt++) {
+    out_b0[qt] = d.out[8 * qt];
+    out_b1[qt] = d.out[8 * qt + 1];
+#pragma unroll
+    for (int k2 = 1; k2 < 4; k2++) {
+      out_b0[qt] = kb == k2 ? d.out[8 * qt + 2 * k2] : out_b0[qt];
+      out_b1[qt] = kb == k2 ? d.out[8 * qt + 2 * k2 + 1] : out_b1[qt];
+    }
+    // offset terms of this lane's four query columns n = 4 kb + i of the tile, both moduli (the same for every chunk)
+    off0[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + kb];
+    off1[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + 4 + kb];
   }
-  // offset terms of this lane's four query columns n = 4 kb + i, both moduli (the same for every chunk of the workgroup)
-  const mf_u32x4_t off0 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + kb];
-  const mf_u32x4_t off1 = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[(size_t)z * 8 + 4 + kb];
   mf_u32x4_t va[NB][2];
   mf_u32x3_t vb[NB][2];
 
@@ -215,18 +229,18 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
         A[e][c][3] = (int)offset_digits(f[1][4 + 2 * e + c]);                                        \
       }                                                                                              \
     }                                                                                                \
-    _Pragma("unroll") for (int c = 0; c < 2; c++) {                                                  \
-      const mf_u32x4_t R = rql[((SL) * 2 + c) * 64];                                                 \
+    _Pragma("unroll") for (int qt = 0; qt < QT; qt++) _Pragma("unroll") for (int c = 0; c < 2; c++) { \
+      const mf_u32x4_t R = rql[(size_t)qt * n16 + ((SL) * 2 + c) * 64];                              \
       _Pragma("unroll") for (int s = 0; s < 7; s++) {                                                \
         const u32 sh = (u32)(8 * (s < 3 ? 3 - s : s - 3));                                           \
         const mf_u32x4_t Bs = DIAG == 3 ? R : (s < 3 ? R >> sh : R << sh);                           \
         const v4i_t Bi = __builtin_bit_cast(v4i_t, Bs);                                              \
         if (DIAG == 2) {                                                                             \
-          acc[0][c][s] ^= A[0][c] + Bi;                                                              \
-          acc[1][c][s] ^= A[1][c] - Bi;                                                              \
+          acc[qt][0][c][s] ^= A[0][c] + Bi;                                                          \
+          acc[qt][1][c][s] ^= A[1][c] - Bi;                                                          \
         } else {                                                                                     \
-          acc[0][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[0][c], acc[0][c][s], 0, 0, 0);  \
-          acc[1][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[1][c], acc[1][c][s], 0, 0, 0);  \
+          acc[qt][0][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[0][c], acc[qt][0][c][s], 0, 0, 0);  \
+          acc[qt][1][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[1][c], acc[qt][1][c][s], 0, 0, 0);  \
         }                                                                                            \
       }                                                                                              \
     }                                                                                                \
@@ -239,13 +253,15 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
   // stream is contiguous) and, for the last NB - 1 steps of the workgroup, re-reads its own last step (cache hits)
   // instead of running past the range.
   for (int ch = 0; ch < d.cpw; ch++) {
-    v4i_t acc[2][2][7];  // [tile e][crt][shift]
+    v4i_t acc[QT][2][2][7];  // [query tile][column tile e][crt][shift]
 #pragma unroll
-    for (int e = 0; e < 2; e++)
+    for (int qt = 0; qt < QT; qt++)
 #pragma unroll
-      for (int c = 0; c < 2; c++)
+      for (int e = 0; e < 2; e++)
 #pragma unroll
-        for (int s = 0; s < 7; s++) acc[e][c][s] = v4i_t{0, 0, 0, 0};
+        for (int c = 0; c < 2; c++)
+#pragma unroll
+          for (int s = 0; s < 7; s++) acc[qt][e][c][s] = v4i_t{0, 0, 0, 0};
     for (int s0 = 0; s0 < steps; s0 += NB) {
 #pragma unroll
       for (int k = 0; k < NB; k++) {
@@ -261,17 +277,19 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
     const size_t col = DIAG == 5 ? (size_t)(32 * g + 2 * mp)
                                  : (size_t)z * d.num_per + (size_t)(chunk0 + ch) * 128 + 32 * g + 2 * mp;
 #pragma unroll
+    for (int qt = 0; qt < QT; qt++)
+#pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (2 * kb + (i >> 1) < d.batch) {
-        u32* ob = ((i >> 1) ? out_b1 : out_b0) + ((size_t)plane * 4 + (i & 1) * 2) * rcw + col;
+      if (8 * qt + 2 * kb + (i >> 1) < d.batch) {
+        u32* ob = ((i >> 1) ? out_b1[qt] : out_b0[qt]) + ((size_t)plane * 4 + (i & 1) * 2) * rcw + col;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const ModConst mc = c ? m1 : m0;
-          const u32 oc = c ? off1[i] : off0[i];
-          const u32 v0 = combine_digit_sums(acc[0][c][0][i], acc[0][c][1][i], acc[0][c][2][i], acc[0][c][3][i],
-                                            acc[0][c][4][i], acc[0][c][5][i], acc[0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
-          const u32 v1 = combine_digit_sums(acc[1][c][0][i], acc[1][c][1][i], acc[1][c][2][i], acc[1][c][3][i],
-                                            acc[1][c][4][i], acc[1][c][5][i], acc[1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
+          const u32 oc = c ? off1[qt][i] : off0[qt][i];
+          const u32 v0 = combine_digit_sums(acc[qt][0][c][0][i], acc[qt][0][c][1][i], acc[qt][0][c][2][i], acc[qt][0][c][3][i],
+                                            acc[qt][0][c][4][i], acc[qt][0][c][5][i], acc[qt][0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
+          const u32 v1 = combine_digit_sums(acc[qt][1][c][0][i], acc[qt][1][c][1][i], acc[qt][1][c][2][i], acc[qt][1][c][3][i],
+                                            acc[qt][1][c][4][i], acc[qt][1][c][5][i], acc[qt][1][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
           if (DIAG == 4 && (v0 ^ v1) != 0xDEADBEEFu) continue;  // (practically) no stores
           if (DIAG == 7) {
             u32* o7 = d.out[0] + ((((size_t)zp * chunks + chunk0 + ch) * 4 + g) * 8 + (i * 2 + c)) * 128 + 2 * lane;
