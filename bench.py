@@ -326,6 +326,35 @@ def secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step):
                              "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
                              "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                              "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        # sixteen queries per step: ONE pass for all of them (two query tiles on the matrix cores, r04) where the shape allows
+        B16 = 16
+        qs16 = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(B16)]
+        outs16 = sp.process_query_batch(p, pp, qs16, db)
+        check16 = "ok" if outs16[:8] == single and outs16[8:] == [sp.process_query(p, pp, q, db) for q in qs16[8:]] else "MISMATCH"
+        if check16 != "ok":
+            print("bench: responses of the 16-query pass DIFFER from the single-query path", file=sys.stderr, flush=True)
+        sp.paths_taken()
+        sp.process_query_batch(p, pp, qs16, db)
+        two_tiles = "sweep_batch_mfma_two_tiles" in sp.paths_taken()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            sp.process_query_batch(p, pp, qs16, db)
+        torch.cuda.synchronize()
+        dt16 = time.perf_counter() - t0
+        runs = [sp.QueryRun(p, pp, q, db=db) for q in qs16]
+        pass16_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
+        for r in runs:
+            r.free()
+        pass16_bytes = db.device_bytes() + B16 * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
+        out["batch16"] = {
+            "workload": "16 queries per step sharing ONE database pass (sp_process_query_batch; two query tiles per pass: %s)" % two_tiles,
+            "value": (B16 * 3 / dt16) if check16 == "ok" else None, "unit": "queries/s", "steps": 3, "queries_per_step": B16,
+            "ms_per_step": dt16 * 1e3 / 3, "batch_selfcheck": check16,
+            "batched_pass": {"kernel": "k_sweep_mfma_batch<8, 1, 0, 2>" if two_tiles else "two passes of k_sweep_mfma_batch<2, 2>",
+                             "ms_per_pass": pass16_ms, "ms_of_pass_per_query": pass16_ms / B16, "bytes_per_pass": pass16_bytes,
+                             "achieved": pass16_bytes / (pass16_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                             "frac": pass16_bytes / (pass16_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
     return out
 
 

@@ -188,7 +188,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
-                                "fold_tail_batched", "sweep_ring"};
+                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -966,14 +966,18 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     g_last_error = "out_stride smaller than response_bytes";
     return SP_E_ARG;
   }
-  // Groups of up to SWEEP_BATCH_MAX queries share one database pass.  Nothing waits for a group's folds before the next
+  // Groups of up to 8 queries -- 16 where the two-tile matrix-core pass applies (batch_group = 0, the default, asks the
+  // kernel side; a positive value caps the group) -- share one database pass.  Nothing waits for a group's folds before the next
   // group's expansions and pass are queued (the passes themselves run one after the other: both are HBM-bound), and at
   // most two groups hold workspaces at a time.  Measured at C2 (profiles/r02_fold_batch_experiments.md): the overlap
   // buys nothing yet -- 16 queries take 2 x the time of 8, and 8 as 2 x 4 are slower (195 vs 236 queries/s) -- because
   // the batched sweep's workgroups fill every CU's register file, so a fold wave only starts when the pass drains.
-  int group_max = (int)tunable("batch_group", SWEEP_BATCH_MAX);
-  if (group_max <= 0) group_max = SWEEP_BATCH_MAX;
-  group_max = std::max(1, std::min(SWEEP_BATCH_MAX, group_max));
+  const int shape_max = sweep_batch_group_max(db->np_local, db->nj);
+  int group_max = (int)tunable("batch_group", 0);
+  if (group_max <= 0) group_max = shape_max;
+  group_max = std::max(1, std::min(shape_max, group_max));
+  // a list of exactly 9 .. 16 queries is one group; longer lists are cut into groups of group_max (a last group of <= 8
+  // takes the one-tile pass)
   std::vector<sp_query_t*> all_qs;   // queries in flight (at most two groups: bounds the workspaces held)
   size_t drained = 0;                // responses copied out so far
   hipEvent_t prev_pass = nullptr;
@@ -1022,7 +1026,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       // matrix-core form of the pass (sweep_mfma.hpp): the group's query digit table lives with the group's first
       // workspace (allocated on its first batched call, then reused)
       if (sweep_batch_wants_mfma(d)) {
-        W0.batch_rq.ensure(sweep_batch_rq_words(d.nj));
+        W0.batch_rq.ensure(sweep_batch_rq_words(d.nj, sweep_batch_tiles(d.batch)));
         d.rq = W0.batch_rq.p;
       }
       sweep_batch_prepare(W0.D->T, d, W0.stream);
@@ -1084,7 +1088,7 @@ int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane
 
 int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, int iters, float* ms_per_pass) {
   return guarded([&] {
-    need(qs && db && ms_per_pass && iters > 0 && batch >= 1 && batch <= SWEEP_BATCH_MAX, "bad argument");
+    need(qs && db && ms_per_pass && iters > 0 && batch >= 1 && batch <= sweep_batch_group_max(db ? db->np_local : 0, db ? db->nj : 0), "bad argument");
     need(db->packed && db->num_shards == 1 && db->col_G == 1, "the batched pass needs an unsharded PACKED database");
     check_device(db->device);
     for (int i = 0; i < batch; i++) {
@@ -1109,7 +1113,7 @@ int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, in
       HIP_CHECK(hipStreamSynchronize(qs[i]->ws->stream2));
     }
     if (sweep_batch_wants_mfma(d)) {
-      W0.batch_rq.ensure(sweep_batch_rq_words(d.nj));
+      W0.batch_rq.ensure(sweep_batch_rq_words(d.nj, sweep_batch_tiles(d.batch)));
       d.rq = W0.batch_rq.p;
     }
     TimingEvents ev;   // destroyed on every path out of here (launches and HIP_CHECK throw)

@@ -53,7 +53,8 @@ enum PathBit : u64 {
   PATH_CUSTOM_TRANSPORT = 1ull << 25, // sharded query whose collectives were the host's (sp_comm_create_custom), not RCCL
   PATH_FROM_SWEEP_WAVE = 1ull << 26,  // (retired: k_from_sweep_wave)
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
-  PATH_SWEEP_RING = 1ull << 28        // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
+  PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
+  PATH_SWEEP_MFMA2 = 1ull << 29       // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -304,12 +305,15 @@ void launch_sweep(const DevTables& T, const SweepDesc& d, hipStream_t s);
 // wgs_per_cu workgroups per CU
 void launch_sweep_persist(const DevTables& T, const SweepDesc& d, int wgs_per_cu, hipStream_t s, int n_cus = 256);
 // B queries against ONE pass over the (PACKED) database: every database word is multiplied into B
-// accumulator sets.  B <= SWEEP_BATCH_MAX; qv[b] / out[b] as in SweepDesc.
+// accumulator sets.  qv[b] / out[b] as in SweepDesc.  B <= SWEEP_BATCH_MAX = 8 for the vector kernel and for one query
+// TILE of the matrix-core kernel (16 query columns = the M dimension of one MFMA); the matrix-core kernel takes two tiles
+// (r04): up to SWEEP_GROUP_MAX = 16 queries share the loads AND the digit extraction of every database word.
 constexpr int SWEEP_BATCH_MAX = 8;
+constexpr int SWEEP_GROUP_MAX = 16;
 struct SweepBatchDesc {
   const u64* db;
-  const u64* qv[SWEEP_BATCH_MAX];
-  u32* out[SWEEP_BATCH_MAX];
+  const u64* qv[SWEEP_GROUP_MAX];
+  u32* out[SWEEP_GROUP_MAX];
   int batch;
   int planes, num_per, dim0, j0, nj;
   // matrix-core form (sweep_mfma.hpp): rq = scratch for the group's query digit table (sweep_batch_rq_words words),
@@ -318,9 +322,17 @@ struct SweepBatchDesc {
   int use_mfma;
 };
 // does this shape / group size run on the matrix cores (switch batch_mfma, default on from batch_mfma_min = 4 queries)?
+// Groups of more than SWEEP_BATCH_MAX queries exist only there.
 bool sweep_batch_wants_mfma(const SweepBatchDesc& d);
-// digit table [N][nj / 16][2][64][4] + offset-correction table [N][2][16] (k_query_digits / k_query_offset_terms)
-inline size_t sweep_batch_rq_words(int nj) { return (size_t)N * (size_t)(nj / 16) * 128 * 4 + (size_t)N * 32; }
+// largest group one pass takes for this shape: SWEEP_GROUP_MAX where the two-tile matrix-core form applies (switch
+// batch_mfma_tiles, default 2), else SWEEP_BATCH_MAX
+int sweep_batch_group_max(int num_per, int nj);
+inline int sweep_batch_tiles(int batch) { return batch > SWEEP_BATCH_MAX ? 2 : 1; }
+// per tile: digit table [N][nj / 16][2][64][4]; then per tile the offset-correction table [N][2][16]
+// (k_query_digits / k_query_offset_terms)
+inline size_t sweep_batch_rq_words(int nj, int tiles = 1) {
+  return (size_t)tiles * ((size_t)N * (size_t)(nj / 16) * 128 * 4 + (size_t)N * 32);
+}
 // once per group of queries, before the pass (all planes share the table): builds the digit table when the matrix-core
 // form applies and d.rq is set
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s);

@@ -2,6 +2,7 @@
 // database shape (PACKED wide, persistent, batched, 8-byte wide, narrow).  The judged kernel lives here.
 #include "device_common.hpp"
 #include "sweep_mfma.hpp"
+#include "server.hpp"
 
 namespace spiral {
 
@@ -456,34 +457,47 @@ __global__ __launch_bounds__(256, 2) void k_sweep_packed_batch(DevTables T, Swee
     *reinterpret_cast<uint2*>(o + 3 * rc) = make_uint2((u32)acc[b][3], (u32)acc[b][7]);  // r=1, crt=1
   }
 }
+static bool mfma_shape_ok(int num_per, int nj) {
+  // the matrix-core form needs whole 16-row steps in rings of 2 (nj % 32), the z-row's digit table(s) in LDS (nj <= 512:
+  // 64 KiB per tile) and whole 128-column chunks
+  return tunable("batch_mfma", 1) != 0 && nj > 0 && (nj % 32) == 0 && nj <= 512 && num_per >= 128 && (num_per % 128) == 0;
+}
 bool sweep_batch_wants_mfma(const SweepBatchDesc& d) {
-  // the matrix-core form needs whole 16-row steps in rings of 2 (nj % 32), the z-row's digit table in LDS (nj <= 512)
-  // and whole 128-column chunks; below batch_mfma_min queries per pass the VALU kernel is HBM-bound as well
-  return tunable("batch_mfma", 1) != 0 && d.batch >= (int)tunable("batch_mfma_min", 4) && d.nj > 0 && (d.nj % 32) == 0 &&
-         d.nj <= 512 && d.num_per >= 128 && (d.num_per % 128) == 0;
+  // below batch_mfma_min queries per pass the VALU kernel is HBM-bound as well
+  return mfma_shape_ok(d.num_per, d.nj) && d.batch >= (int)tunable("batch_mfma_min", 4) && d.batch <= SWEEP_GROUP_MAX &&
+         (d.batch <= SWEEP_BATCH_MAX || tunable("batch_mfma_tiles", 2) >= 2);
+}
+int sweep_batch_group_max(int num_per, int nj) {
+  return mfma_shape_ok(num_per, nj) && tunable("batch_mfma_tiles", 2) >= 2 ? SWEEP_GROUP_MAX : SWEEP_BATCH_MAX;
 }
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
   d.use_mfma = 0;
   if (!d.rq || !sweep_batch_wants_mfma(d)) return;
-  QueryDigitsDesc q{};
-  for (int b = 0; b < d.batch; b++) q.qv[b] = d.qv[b];
-  q.rq = d.rq;
-  q.batch = d.batch;
-  q.dim0 = d.dim0;
-  q.j0 = d.j0;
-  q.nj = d.nj;
+  // per tile of <= 8 queries: the digit table [tile][N][steps][2][64][4], then (after ALL tables) the offset terms [tile][N][32]
+  const int tiles = sweep_batch_tiles(d.batch);
   const size_t entries = (size_t)N * (d.nj >> 4) * 128;
-  hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
-  launched(0, "k_query_digits");
-  hipLaunchKernelGGL(k_query_offset_terms, dim3(N), dim3(256), 0, s, T, q, d.rq + entries * 4);
-  launched(0, "k_query_offset_terms");
+  for (int t = 0; t < tiles; t++) {
+    QueryDigitsDesc q{};
+    const int nb = std::min(SWEEP_BATCH_MAX, d.batch - t * SWEEP_BATCH_MAX);
+    for (int b = 0; b < nb; b++) q.qv[b] = d.qv[t * SWEEP_BATCH_MAX + b];
+    q.rq = d.rq + (size_t)t * entries * 4;
+    q.batch = nb;
+    q.dim0 = d.dim0;
+    q.j0 = d.j0;
+    q.nj = d.nj;
+    hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
+    launched(0, "k_query_digits");
+    hipLaunchKernelGGL(k_query_offset_terms, dim3(N), dim3(256), 0, s, T, q, d.rq + (size_t)tiles * entries * 4 + (size_t)t * N * 32);
+    launched(0, "k_query_offset_terms");
+  }
   d.use_mfma = 1;
 }
 static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
   SweepMfmaDesc m{};
   m.db = d.db;
+  const int tiles = sweep_batch_tiles(d.batch);
   m.rq = d.rq;
-  m.rq_off = d.rq + (size_t)N * (d.nj >> 4) * 128 * 4;
+  m.rq_off = d.rq + (size_t)tiles * N * (d.nj >> 4) * 128 * 4;
   for (int b = 0; b < d.batch; b++) m.out[b] = d.out[b];
   m.batch = d.batch;
   m.planes = d.planes;
@@ -501,6 +515,24 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
     m.c6[c] = (u32)((1ull << 48) % qs[c]);
   }
   const dim3 grid((unsigned)((size_t)d.planes * N * (chunks / cpw)));
+  if (tiles == 2) {
+    // sixteen queries per pass (r04): both tiles' z-rows in LDS (128 KiB at nj = 512: one workgroup per CU, 224 accumulator
+    // registers in AGPRs), the load ring as deep as the step count allows (one wave per SIMD has to keep the HBM pipe full
+    // alone).  Measured (scripts/ubench/mfma_sweep.hip, profiles/r04_mfma_two_tiles.md): 4.19 ms per C2 plane for 16 queries
+    // against 2.95 for 8 -- 1.05 instead of 1.48 ms of database pass per query.
+    const size_t lds2 = (size_t)d.nj * 128 * 2;
+    const int steps = d.nj >> 4;
+#define SP_MFMA2(NB_)                                                                                                  \
+  {                                                                                                                    \
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB_, 1, 0, 2>),                        \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                  \
+    hipLaunchKernelGGL((k_sweep_mfma_batch<NB_, 1, 0, 2>), grid, dim3(256), lds2, s, T, m);                            \
+  }
+    if (steps % 8 == 0) SP_MFMA2(8) else if (steps % 4 == 0) SP_MFMA2(4) else SP_MFMA2(2)
+#undef SP_MFMA2
+    launched(PATH_SWEEP_BATCH | PATH_SWEEP_MFMA | PATH_SWEEP_MFMA2, "k_sweep_mfma_batch (two query tiles)");
+    return;
+  }
   const size_t lds = (size_t)d.nj * 128;  // one z-row of the group's query digit table
   if (lds > 65536)
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -513,6 +545,7 @@ void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t
     launch_sweep_mfma(T, d, s);
     return;
   }
+  if (d.batch > SWEEP_BATCH_MAX) throw HipError("internal: a group of more than 8 queries needs the matrix-core pass");
   const long units = (long)d.planes * N * (d.num_per >> 7);
   const dim3 grid((unsigned)((units + 3) / 4));
   const bool unroll = ((d.nj >> 1) % 8) == 0;  // U = 4 (and the U = 2 LDS form) run ping-pong: npairs % (2 U) == 0

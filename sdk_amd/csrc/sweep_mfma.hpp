@@ -114,15 +114,6 @@ __device__ __forceinline__ u32 combine_digit_sums(int d0, int d1, int d2, int d3
   return reduce64((u64)(v + ((long long)m.q << 29) + (long long)off), m);  // off < q: the offset term (k_query_offset_terms)
 }
 
-// One multiply-accumulate with the accumulator PINNED to four AGPRs and updated in place (two query tiles: 224 accumulator
-// registers).  Left to the register allocator the accumulators end up half in VGPRs, half in AGPRs, every MFMA gets a fresh
-// destination and each step pays 76 v_accvgpr moves (a third of its vector instructions).  The compiler does not know this
-// statement is an MFMA: the kernel separates it by s_nop from the zero-initialisation before and the reads after the step
-// loop (inside the loop an accumulator is touched once per 56 MFMAs).
-__device__ __forceinline__ void mfma_i8_in_agpr(v4i_t& acc, const v4i_t a, const v4i_t b) {
-  asm("v_mfma_i32_16x16x64_i8 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
-}
-
 // DIAG (microbenchmark only, scripts/ubench/mfma_sweep.hip; 0 in the library): 1 = no database loads after the
 // prologue (compute only), 2 = MFMAs replaced by one XOR each (loads + VALU only), 3 = raw dwords fed to the MFMAs (no
 // digit extraction, no operand shifts: loads + MFMA only), 4 = no output stores, 5 = every workgroup stores to the first
@@ -247,9 +238,6 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
         if (DIAG == 2) {                                                                             \
           acc[qt][0][c][s] ^= A[0][c] + Bi;                                                          \
           acc[qt][1][c][s] ^= A[1][c] - Bi;                                                          \
-        } else if (QT > 1) {                                                                         \
-          mfma_i8_in_agpr(acc[qt][0][c][s], Bi, A[0][c]);                                            \
-          mfma_i8_in_agpr(acc[qt][1][c][s], Bi, A[1][c]);                                            \
         } else {                                                                                     \
           acc[qt][0][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[0][c], acc[qt][0][c][s], 0, 0, 0);  \
           acc[qt][1][c][s] = __builtin_amdgcn_mfma_i32_16x16x64_i8(Bi, A[1][c], acc[qt][1][c][s], 0, 0, 0);  \
@@ -274,7 +262,6 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
         for (int c = 0; c < 2; c++)
 #pragma unroll
           for (int s = 0; s < 7; s++) acc[qt][e][c][s] = v4i_t{0, 0, 0, 0};
-    if (QT > 1) asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");  // (accumulator writes -> the first in-place MFMAs)
     for (int s0 = 0; s0 < steps; s0 += NB) {
 #pragma unroll
       for (int k = 0; k < NB; k++) {
@@ -284,7 +271,6 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
         SPM_STEP(k, s0 + k)
       }
     }
-    if (QT > 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");  // (the last in-place MFMAs -> the reads below)
     // chunk done: recombine the digit sums, reduce, store: register i = query column 4 kb + i (b = 2 kb + i / 2,
     // r = i % 2), lane mp = slot 16 g + mp = columns 2 (16 g + mp) + e
     const size_t rcw = (size_t)N * d.num_per;

@@ -572,7 +572,7 @@ class QueryRun:
 
 
 def bench_sweep_batch(runs, db, iters):
-    """average milliseconds per batched database PASS of the begun queries `runs` (QueryRun objects, <= 8) -- the pass
+    """average milliseconds per batched database PASS of the begun queries `runs` (QueryRun objects, <= 16) -- the pass
     sp_process_query_batch issues for such a group (sp_bench_sweep_batch)"""
     ms = C.c_float(0)
     arr = (C.c_void_p * len(runs))(*[r.h for r in runs])

@@ -129,6 +129,34 @@ def test_c2_batch8_matrix_core_pass_at_full_size(sp, oracle_mod):
     gc.collect()
 
 
+def test_c2_batch16_two_query_tiles_at_full_size(sp, oracle_mod):
+    """Sixteen queries per database pass at full size (k_sweep_mfma_batch, two query tiles: 128 KiB of query digits in LDS,
+    one workgroup per CU, ring of 8 sixteen-row steps): one response of each tile byte for byte against the oracle, all
+    sixteen against the groups-of-8 path that the test above ties to the oracle."""
+    import ctypes as C
+    _need_hbm(130)
+    o, cl, pp = _client(oracle_mod, C2, 501)
+    p = sp.Params(C2)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    db = sp.Database(p).fill_synthetic(SEED)
+    queries = [cl.generate_query((65537 * k + 11) % o.num_items, 970 + k) for k in range(16)]
+    sp.paths_taken()
+    outs = sp.process_query_batch(p, gpp, queries, db)
+    taken = sp.paths_taken()
+    assert {"sweep_batch", "sweep_batch_mfma", "sweep_batch_mfma_two_tiles"} <= taken, taken
+    for k in (3, 12):
+        want = o.process_query_synth(pp, queries[k], SEED)
+        assert outs[k] == want, "query %d of the sixteen differs from the oracle (sha %s vs %s)" % (
+            k, hashlib.sha256(outs[k]).hexdigest()[:16], hashlib.sha256(want).hexdigest()[:16])
+    sp.lib().sp_debug_set(b"batch_group", C.c_long(8))
+    try:
+        assert sp.process_query_batch(p, gpp, queries, db) == outs
+    finally:
+        sp.lib().sp_debug_set(b"batch_group", C.c_long(0))
+    del db
+    gc.collect()
+
+
 def test_c2_fold_thresholds_agree_at_full_size(sp, oracle_mod, monkeypatch):
     """The two extremes of the fold dispatch produce the oracle's bytes at full size as well: every level through the
     fused kernel (threshold 1), and no level through it (threshold 2048 > the 1024 pairs of a plane's first level:

@@ -1073,6 +1073,51 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
         assert cls[1].decode_response(resp[1]) == o.item_to_vec(o.generate_random_db_and_get_item(idxs[1])[0])
 
 
+@pytest.mark.parametrize("nu_1,nu_2,B,check", [(6, 7, 16, "all"), (5, 8, 12, "all"), (7, 7, 9, "all"), (8, 8, 16, "some"), (9, 7, 16, "some"),
+                                               (5, 7, 19, "all")],
+                         ids=["64x128-B16", "32x256-B12", "128x128-B9", "256x256-B16", "512x128-B16", "32x128-B19"])
+def test_process_query_batch_two_query_tiles(sp, oracle_mod, nu_1, nu_2, B, check):
+    """Nine to sixteen queries share ONE database pass (k_sweep_mfma_batch with two query tiles, r04: the database words are
+    loaded and split into digits once for both tiles; ring depths 2, 4 and 8 by row count): byte-identical to the oracle, to
+    groups of at most 8 (SPIRAL_BATCH_GROUP=8, the one-tile pass) and to one-at-a-time queries; unused query columns of the
+    second tile (B = 9, 12) stay out of the way; a list of 19 is cut into a group of 16 and a group of 3 (vector kernel).
+    Two clients' keys."""
+    import ctypes as C
+    cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256 << max(0, 16 - nu_1 - nu_2)}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cls = [oracle_mod.Client(o), oracle_mod.Client(o)]
+    pps = [cls[0].generate_keys(43), cls[1].generate_keys(44)]
+    gpps = [sp.PublicParameters.deserialize(p, x) for x in pps]
+    if check == "all":
+        item, db = o.generate_random_db_and_get_item(3)
+    else:
+        rng = np.random.default_rng(nu_1 * 16 + nu_2 + 1)
+        n_words = 4 * 2048 * o.num_per * o.dim0
+        db = rng.integers(0, Q0, n_words, dtype=np.uint64) | (rng.integers(0, Q1, n_words, dtype=np.uint64) << np.uint64(32))
+    gdb = sp.Database(p).load(db)
+    idxs = [(1013 * i + 5) % o.num_items for i in range(B)]
+    qs = [cls[i % 2].generate_query(idxs[i], 700 + i) for i in range(B)]
+    sp.paths_taken()
+    resp = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
+    assert "sweep_batch_mfma_two_tiles" in sp.paths_taken()
+    sp.lib().sp_debug_set(b"batch_group", C.c_long(8))
+    try:
+        sp.paths_taken()
+        one_tile = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
+        assert "sweep_batch_mfma_two_tiles" not in sp.paths_taken()
+    finally:
+        sp.lib().sp_debug_set(b"batch_group", C.c_long(0))
+    assert resp == one_tile
+    for i in (range(B) if check == "all" else (0, 7, 8, B - 1)):
+        assert resp[i] == o.process_query(pps[i % 2], qs[i], db), i
+    for i in range(B):
+        assert resp[i] == sp.process_query(p, gpps[i % 2], qs[i], gdb), i
+    if check == "all":
+        assert cls[1].decode_response(resp[9 if B > 9 else 1]) == o.item_to_vec(o.generate_random_db_and_get_item(idxs[9 if B > 9 else 1])[0])
+
+
 def test_process_query_batch_matrix_core_extreme_digits(sp, oracle_mod):
     """Database words whose residues sit at the edges of the signed-digit split (every byte 0x80 / 0x7f, q - 1, 0, the
     largest top digit) in every row: the i32 digit sums of k_sweep_mfma_batch reach their largest magnitudes; 256 rows.
