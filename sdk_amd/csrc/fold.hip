@@ -296,7 +296,7 @@ struct FoldMac {  // hooks into wntt_fwd: operand vectors of coefficient group g
   }
 };
 
-template <int ES, bool SUM64>
+template <int ES>
 __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, const u32* __restrict__ mats_w) {
   extern __shared__ __attribute__((aligned(16))) u32 smem_fw[];
   u32* wbuf = smem_fw;                      // transposes (one region per wave) ...
@@ -420,97 +420,44 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
     u32* park = reinterpret_cast<u32*>(out);
     u32 rr[32];                                  // modulus-1 round: the row this wave transforms back
     const int irow = wv & 1, imod = wv < 2 ? 1 : 0;
-    if (SUM64) {
-      u64* sum = reinterpret_cast<u64*>(smem_fw);   // 2 rows x 2048 x 8 B = the first 32 KiB (transpose buffers + tables)
-      __syncthreads();  // every wave is done with its transpose buffer and the tables
-      if (wv == 0) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-          sum[k * 64 + lt] = acc0[k];
-          sum[2048 + k * 64 + lt] = acc1[k];
-        }
-      }
-      __syncthreads();
-      if (wv != 0) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) {
-          __hip_atomic_fetch_add(sum + k * 64 + lt, acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          __hip_atomic_fetch_add(sum + 2048 + k * 64 + lt, acc1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-      }
-      __syncthreads();
-      // The four inverse transforms of the step (2 rows x 2 moduli) run at the END, one per wave: modulus 0's rows are
-      // parked in the output slot (as u32, its first 16 KiB) and picked up by waves 2 and 3, so that no wave idles while
-      // two others transform back.
-      if (c == 0) {
-        // wave w reduces coefficients 16 (w & 1) .. + 15 of every lane's 32 of row w >> 1 and parks them
-        const int prow = wv >> 1, ph = wv & 1;
-        u32 pr[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) pr[k] = reduce64(sum[prow * 2048 + (16 * ph + k) * 64 + lt], m);
-#pragma unroll
-        for (int g = 0; g < 4; g++) {
-          u32x4w_t t4;
-          t4.x = pr[4 * g]; t4.y = pr[4 * g + 1]; t4.z = pr[4 * g + 2]; t4.w = pr[4 * g + 3];
-          *reinterpret_cast<u32x4w_t*>(park + prow * N + 32 * lt + 16 * ph + 4 * g) = t4;
-        }
-      } else if (wv < 2) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) rr[k] = reduce64(sum[irow * 2048 + k * 64 + lt], m);
-      }
-      __syncthreads();  // the sums are read: the scratch is free again
-    } else {
-      // round-3 form (switch fold_sum64 = 0): every wave reduces its 64 sums, the u32 residues are combined through LDS in
-      // two rounds as b128 vectors at [(g * 64 + lane)]; region s holds one row of one wave (2048 words)
-      u32 r0[32], r1[32];
+    u64* sum = reinterpret_cast<u64*>(smem_fw);   // 2 rows x 2048 x 8 B = the first 32 KiB (transpose buffers + tables)
+    __syncthreads();  // every wave is done with its transpose buffer and the tables
+    if (wv == 0) {
 #pragma unroll
       for (int k = 0; k < 32; k++) {
-        r0[k] = reduce64(acc0[k], m);
-        r1[k] = reduce64(acc1[k], m);
-      }
-      u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(smem_fw);
-#define SP_PUT(R, REGION)                                                                              \
-  _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
-    u32x4w_t t4;                                                                                       \
-    t4.x = R[4 * g]; t4.y = R[4 * g + 1]; t4.z = R[4 * g + 2]; t4.w = R[4 * g + 3];                    \
-    sc[(REGION) * 512 + g * 64 + lt] = t4;                                                             \
-  }
-#define SP_ADD(R, REGION)                                                                              \
-  _Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
-    const u32x4w_t t4 = sc[(REGION) * 512 + g * 64 + lt];                                              \
-    R[4 * g] = add_mod(R[4 * g], t4.x, m.q); R[4 * g + 1] = add_mod(R[4 * g + 1], t4.y, m.q);          \
-    R[4 * g + 2] = add_mod(R[4 * g + 2], t4.z, m.q); R[4 * g + 3] = add_mod(R[4 * g + 3], t4.w, m.q);  \
-  }
-      __syncthreads();  // every wave is done with its transpose buffer and the tables
-      if (wv == 2) { SP_PUT(r0, 0) SP_PUT(r1, 1) }
-      if (wv == 3) { SP_PUT(r0, 2) SP_PUT(r1, 3) }
-      __syncthreads();
-      if (wv == 0) { SP_ADD(r0, 0) SP_ADD(r0, 2) }
-      if (wv == 1) { SP_ADD(r1, 1) SP_ADD(r1, 3) }
-      __syncthreads();
-      if (wv == 0) { SP_PUT(r1, 0) }
-      if (wv == 1) { SP_PUT(r0, 1) }
-      __syncthreads();
-      if (wv == 0) { SP_ADD(r0, 1) }
-      if (wv == 1) { SP_ADD(r1, 0) }
-      __syncthreads();  // the scratch is free again: waves 0 and 1 use their own regions for the inverse transform
-#undef SP_PUT
-#undef SP_ADD
-      if (c == 0) {
-        if (wv < 2) {
-#pragma unroll
-          for (int g = 0; g < 8; g++) {
-            u32x4w_t t4;
-            t4.x = wv == 0 ? r0[4 * g] : r1[4 * g]; t4.y = wv == 0 ? r0[4 * g + 1] : r1[4 * g + 1];
-            t4.z = wv == 0 ? r0[4 * g + 2] : r1[4 * g + 2]; t4.w = wv == 0 ? r0[4 * g + 3] : r1[4 * g + 3];
-            *reinterpret_cast<u32x4w_t*>(park + wv * N + 32 * lt + 4 * g) = t4;
-          }
-        }
-      } else if (wv < 2) {
-#pragma unroll
-        for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
+        sum[k * 64 + lt] = acc0[k];
+        sum[2048 + k * 64 + lt] = acc1[k];
       }
     }
+    __syncthreads();
+    if (wv != 0) {
+#pragma unroll
+      for (int k = 0; k < 32; k++) {
+        __hip_atomic_fetch_add(sum + k * 64 + lt, acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(sum + 2048 + k * 64 + lt, acc1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      }
+    }
+    __syncthreads();
+    // The four inverse transforms of the step (2 rows x 2 moduli) run at the END, one per wave: modulus 0's rows are
+    // parked in the output slot (as u32, its first 16 KiB) and picked up by waves 2 and 3, so that no wave idles while
+    // two others transform back.
+    if (c == 0) {
+      // wave w reduces coefficients 16 (w & 1) .. + 15 of every lane's 32 of row w >> 1 and parks them
+      const int prow = wv >> 1, ph = wv & 1;
+      u32 pr[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) pr[k] = reduce64(sum[prow * 2048 + (16 * ph + k) * 64 + lt], m);
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        u32x4w_t t4;
+        t4.x = pr[4 * g]; t4.y = pr[4 * g + 1]; t4.z = pr[4 * g + 2]; t4.w = pr[4 * g + 3];
+        *reinterpret_cast<u32x4w_t*>(park + prow * N + 32 * lt + 16 * ph + 4 * g) = t4;
+      }
+    } else if (wv < 2) {
+#pragma unroll
+      for (int k = 0; k < 32; k++) rr[k] = reduce64(sum[irow * 2048 + k * 64 + lt], m);
+    }
+    __syncthreads();  // the sums are read: the scratch is free again
     if (c == 1) {
       const ModConst mi = T.c.mod[imod];
       if (wv >= 2) {
@@ -571,22 +518,12 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
     // the LDS bound, stated for the reader)
     if (lds <= 80 * 1024 && 2 * d.t <= 21) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
       // (> 64 KiB of dynamic LDS needs no opt-in on gfx950, scripts/ubench/dyn_lds.hip)
-      // fold_sum64 (default 1): the four waves' raw 64-bit sums added exactly in LDS and reduced once (r04); 0: round 3's
-      // per-wave reductions + two rounds of u32 exchanges
-      const bool sum64 = tunable("fold_sum64", 1) != 0;
-#define SP_FW_LAUNCH(ES_)                                                                         \
-  if (sum64)                                                                                      \
-    hipLaunchKernelGGL((k_fold_wave<ES_, true>), grid, block, lds, s, T, d, d.mats_w);            \
-  else                                                                                            \
-    hipLaunchKernelGGL((k_fold_wave<ES_, false>), grid, block, lds, s, T, d, d.mats_w);
-      if (es == 1) {
-        SP_FW_LAUNCH(1)
-      } else if (es == 2) {
-        SP_FW_LAUNCH(2)
-      } else {
-        SP_FW_LAUNCH(4)
-      }
-#undef SP_FW_LAUNCH
+      if (es == 1)
+        hipLaunchKernelGGL(k_fold_wave<1>, grid, block, lds, s, T, d, d.mats_w);
+      else if (es == 2)
+        hipLaunchKernelGGL(k_fold_wave<2>, grid, block, lds, s, T, d, d.mats_w);
+      else
+        hipLaunchKernelGGL(k_fold_wave<4>, grid, block, lds, s, T, d, d.mats_w);
       launched(PATH_FOLD_FUSED | PATH_FOLD_WAVE, "k_fold_wave");
       return;
     }

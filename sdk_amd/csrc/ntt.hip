@@ -184,110 +184,13 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
     }
   }
 }
-// ------------------------------------------------------------------------------------------------
-// The same transform with the NEXT operand prefetched (r04, the default): k_from_sweep4's workgroups load, transform and
-// store in strict sequence, and because all of a launch's workgroups start together the whole chip alternates between a
-// memory phase with idle ALUs and a compute phase with an idle memory system (11 ns per transform, 0.17 of the HBM rate:
-// VERDICT r03).  The kernel has no registers to spare for a second operand in flight (the four-column transform needs the
-// whole file), so the next operand is only PULLED INTO THE L2: before a transform starts, every thread loads one dword of
-// each 16-byte piece of the operand after it -- modulus 1 of the group before modulus 0 is transformed, modulus 0 of the
-// workgroup's next group (persistent grid, two workgroups per CU) before modulus 1 is -- eight registers that are looked
-// at only after the transform (a never-true test keeps them alive).  The real loads then hit the L2.  Same arithmetic, same
-// XCD-aware group order, same results.
-// ------------------------------------------------------------------------------------------------
-// one dword of every 16-byte piece the thread will load next, as ordinary loads the compiler's wait counting knows about (a
-// throw-away destination register written behind the compiler's back could be reused while the load is in flight); the
-// caller looks at them only after its transform
-__device__ __forceinline__ void fsp_prefetch8(u32 (&t)[8], const u32* p, int tau, int np) {
-#pragma unroll
-  for (int k = 0; k < 8; k++) t[k] = p[(size_t)(8 * tau + k) * np];
-}
-__global__ __launch_bounds__(256, 2) void k_from_sweep4_pipe(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map,
-                                                             int n_groups) {
-  __shared__ u32 lds0[4 * LDS_WORDS];
-  __shared__ u32 lds1[4 * LDS_WORDS];
-  const int tau = threadIdx.x;
-  const int gpr = np / 4;  // groups per (plane, r)
-  const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
-  for (int vb = blockIdx.x; vb < n_groups; vb += gridDim.x) {
-    // virtual block vb -> (plane, r, ii0): the order of k_from_sweep4 (the 8 groups sharing a 128-byte line go through ONE XCD)
-    int g = vb, gn = vb + gridDim.x < n_groups ? vb + (int)gridDim.x : vb;
-    if (xcd_map) {
-      g = (((g >> 3) >> 3) * 8 + (g & 7)) * 8 + ((g >> 3) & 7);
-      gn = (((gn >> 3) >> 3) * 8 + (gn & 7)) * 8 + ((gn >> 3) & 7);
-    }
-    const int groups_per_plane = gpr * 2;
-    const int plane = g / groups_per_plane, rem = g % groups_per_plane;
-    const int r = rem / gpr, ii0 = (rem % gpr) * 4;
-    const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
-    const int plane_n = gn / groups_per_plane, rem_n = gn % groups_per_plane;
-    const size_t base_n = ((size_t)plane_n * 4 + (rem_n / gpr) * 2) * N * np + (rem_n % gpr) * 4;
-    u32 res0[4][8];
-#pragma unroll 1
-    for (int c = 0; c < 2; c++) {
-      const ModConst m = T.c.mod[c];
-      const u32* sp = src + base + (size_t)c * N * np;
-      u32 v[4][8];
-#pragma unroll
-      for (int k = 0; k < 8; k++) {
-        uint4 x = *reinterpret_cast<const uint4*>(sp + (size_t)(8 * tau + k) * np);
-        if (premod) {
-          x.x %= m.q; x.y %= m.q; x.z %= m.q; x.w %= m.q;
-        }
-        v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
-      }
-      // what the workgroup reads next: modulus 1 of this group / modulus 0 of its next group
-      u32 pulled[8];
-      fsp_prefetch8(pulled, c == 0 ? sp + (size_t)N * np : src + base_n, tau, np);
-      __builtin_amdgcn_sched_barrier(0);  // issued before the transform, looked at after it
-      // the transform's LDS addresses and twiddle pointers are loop invariants of the modulus / group loops: left alone the
-      // compiler hoists some sixty of them over the loops and spills to make room (the fold kernels do the same)
-      const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
-      int tk = tau;
-      asm volatile("" : "+s"(iw));
-      asm volatile("" : "+v"(tk));
-      __syncthreads();  // the exchange buffers are free (previous transform's last reads are done)
-      ntt_inv_block_m<4>(v, tk, lds0, lds1, iw, iw + N, m.q, m.two_q);
-      __builtin_amdgcn_sched_barrier(0);
-      {  // never true (premod is 0 or 1): keeps the pulls alive until here
-        const u32 any = (pulled[0] | pulled[1]) | (pulled[2] | pulled[3]) | ((pulled[4] | pulled[5]) | (pulled[6] | pulled[7]));
-        if (any == 0xFFFFFFFFu && premod == 0x7FFFFFFF) v[0][0] ^= 1u;
-      }
-      if (c == 0) {
-#pragma unroll
-        for (int mm = 0; mm < 4; mm++)
-#pragma unroll
-          for (int k = 0; k < 8; k++) res0[mm][k] = v[mm][k];
-      } else {
-#pragma unroll
-        for (int mm = 0; mm < 4; mm++) {
-          u64* out = dst + (((size_t)plane * np + ii0 + mm) * 2 + r) * N;
-#pragma unroll
-          for (int k = 0; k < 8; k++) {
-            const u32 x = res0[mm][k], y = v[mm][k];
-            const u32 xm = x >= q1 ? x - q1 : x;
-            const u32 dd = y >= xm ? y - xm : y + q1 - xm;
-            const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
-            u32 e = dd * T.c.q0_inv_q1 - qt * q1;
-            e = e >= q1 ? e - q1 : e;
-            out[tau + 256 * k] = (u64)x + (u64)q0 * (u64)e;
-          }
-        }
-      }
-    }
-  }
-}
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
   const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
   const int xcd_map = tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0;
-  // from_sweep_pipe (default 1): the software-pipelined persistent form; 0: one workgroup per column group
-  if (tunable("from_sweep_pipe", 1) != 0) {
-    const unsigned grid = std::min(groups, 512u);   // two workgroups per CU (LDS-bound), a multiple of 64 whenever xcd_map is on
-    hipLaunchKernelGGL(k_from_sweep4_pipe, dim3(grid), dim3(256), 0, s, T, src, np, premod, dst, xcd_map, (int)groups);
-    launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4_pipe");
-    return;
-  }
+  // (r04: a persistent form of this kernel that pulled each workgroup's next operand into the L2 ahead of its transform was
+  // measured on one allocation and changes nothing -- 85.8 vs 85.5 queries/s, 2.08 vs 2.05 ms of un-pipelined from_ntt +
+  // fold, 30.4 vs 30.1 ms per 8-query step -- and is gone again: profiles/r04_fold_from_ntt_ab.md)
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
   launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
