@@ -286,9 +286,12 @@ def secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step):
         tel1 = gpu_telemetry()
         k = max(1, min(100, n // 3))
         dt = np.diff(stamps)
+        rel = stamps[1:] - stamps[0]
+        by_second = [int(((rel > t) & (rel <= t + 1)).sum()) for t in range(int(rel[-1]))]   # completed queries per whole second
         out["sustained"] = {
             "queries": n, "value": n / (stamps[-1] - stamps[0]), "unit": "queries/s",
             "first_%d_qps" % k: k / (stamps[k] - stamps[0]), "last_%d_qps" % k: k / (stamps[-1] - stamps[-1 - k]),
+            "queries_completed_per_second": by_second,
             "ms_per_query_p50": float(np.median(dt) * 1e3), "ms_per_query_max": float(dt.max() * 1e3),
             "seconds": float(stamps[-1] - stamps[0]),
             "telemetry_before": tel0, "telemetry_after": tel1,
@@ -428,7 +431,9 @@ def main():
     ap.add_argument("--headline-only", action="store_true",
                     help="only the headline timed region + roofline (no `secondary` objects: batch8 / sustained / c4); "
                          "what the profiling scripts use so that kernel statistics hold the headline's launches only")
-    ap.add_argument("--sustained", type=int, default=300, help="queries of the `secondary.sustained` run (0 = skip)")
+    ap.add_argument("--sustained", type=int, default=1000,
+                    help="queries of the `secondary.sustained` run (0 = skip); the default runs for ~12 s at C2: round 3 saw a "
+                         "loop lose 8 %% after ten seconds")
     ap.add_argument("--via-torchrun", action="store_true",
                     help="re-exec under torch.distributed.run even for --gpus 1 (what --gpus N > 1 does on its own when "
                          "no launcher set WORLD_SIZE)")

@@ -1110,7 +1110,9 @@ def test_process_query_batch_two_query_tiles(sp, oracle_mod, nu_1, nu_2, B, chec
     finally:
         sp.lib().sp_debug_set(b"batch_group", C.c_long(0))
     assert resp == one_tile
-    for i in (range(B) if check == "all" else (0, 7, 8, B - 1)):
+    # against the oracle: both ends of both tiles (+ the second group's last query); everything against one-at-a-time queries,
+    # which the other tests tie to the oracle
+    for i in sorted({0, 7, 8, min(B, 16) - 1, B - 1}):
         assert resp[i] == o.process_query(pps[i % 2], qs[i], db), i
     for i in range(B):
         assert resp[i] == sp.process_query(p, gpps[i % 2], qs[i], gdb), i
