@@ -277,7 +277,7 @@ int sp_server_forget(sp_server_t*, const char* uuid);
 /* POST /private-read (bin/server.rs:98-164) on decoded requests: request i is uuid (36 bytes) || serialized query when
  * the params expand queries (bin/server.rs:107-121), serialized public parameters || query otherwise (:123-138).  The
  * reference answers the list one query at a time (:152-158); here the whole list goes through the batch scheduler
- * (sp_process_query_batch: groups of <= 8 queries share one pass over the database, each with its own client's public
+ * (sp_process_query_batch: groups of <= 16 queries (two tiles of 8 on the matrix cores; <= 8 elsewhere) share one pass over the database, each with its own client's public
  * parameters).  Response i (response_bytes long) is written at out + i * out_stride.  A malformed length is SP_E_ARG
  * (the reference asserts), an unknown uuid SP_E_NOTFOUND; nothing is answered in either case. */
 int sp_server_private_read(sp_server_t*, const uint8_t* const* requests, const size_t* request_lens, int n, uint8_t* out,
@@ -298,7 +298,7 @@ int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_la
 /* per_plane_launches: 1 = one launch per plane (what sp_query_sweep_scatter_plane issues), 0 = one launch,
  * -1 = what sp_query_sweep would do for this db (sp_bench_sweep). */
 int sp_bench_sweep_ex(sp_query_t* q, const sp_db_t* db, int iters, int per_plane_launches, float* ms_per_launch);
-/* The same for the BATCHED pass of sp_process_query_batch (BASELINE configs[4]): the `batch` (<= 8) begun queries `qs`
+/* The same for the BATCHED pass of sp_process_query_batch (BASELINE configs[4]): the `batch` (<= 16 where the two-tile pass applies, else <= 8) begun queries `qs`
  * share database passes exactly as a group of sp_process_query_batch does (query digit table + k_sweep_mfma_batch on
  * the matrix cores from 4 queries, k_sweep_packed_batch below; one launch over all planes); returns average
  * milliseconds per PASS.  The queries' partial buffers hold the pass's outputs afterwards. */

@@ -354,7 +354,7 @@ pub fn process_query(params: &Params, public_params: &PublicParameters, query: &
     must(try_process_query(params, public_params, query, db))
 }
 
-/// The per-request query loop of lib/server/src/bin/server.rs:152-158 in one call: groups of <= 8 queries share one
+/// The per-request query loop of lib/server/src/bin/server.rs:152-158 in one call: groups of <= 16 queries share one
 /// pass over the database.  `items[i] = (public parameters of the query's client, serialized query)`.
 pub fn process_query_batch(params: &Params, items: &[(&PublicParameters, &[u8])], db: &Database) -> Vec<Vec<u8>> {
     let n = params.response_bytes();

@@ -409,55 +409,65 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
                  reinterpret_cast<const u32x4w_t*>(mats_w + ((size_t)(four_t + kk) * 2 + c) * N) + ln};
       wntt_fwd<false>(v, ln, mybuf, fwi, stw, ltw, m.q, m.two_q, hk);
     }
-    // Partial sums of the four waves -> ONE exact 64-bit sum per (row, coefficient) in LDS, then Barrett-reduced ONCE (r04).
-    // Round 3 reduced every wave's 64 sums to u32 residues and combined those through LDS in two rounds: 512 reductions
-    // and five barriers per step and modulus.  The raw sums fit 64 bits together (16 digits x 12 q x q < 2^64), so wave 0
-    // stores its sums, waves 1-3 add theirs with ds_add_u64, and 128 reductions remain: modulus 0's are spread over all
-    // four waves (16 coefficients of one row per lane, parked for the inverse transforms at the end), modulus 1's run on
-    // waves 0 and 1, which transform them back.  sum[row][k][lane] (u64): every access is 64 consecutive 8-byte words.
+    // partial sums of the four waves -> wave 0 (row 0) and wave 1 (row 1): every wave reduces its 64 sums, the u32 residues
+    // travel through LDS as b128 vectors at [(g * 64 + lane)] (conflict-free) in two rounds; region s holds one row of one wave
+    // (2048 words).  (r04 tried the alternative -- the four waves' raw 64-bit sums added exactly in LDS with ds_add_u64 and
+    // reduced once: 1655 instead of 2125 vector instructions per transform, 3 instead of 5 barriers -- and measured it on one
+    // allocation: equal alone and in batches, 1.5-3 % SLOWER for the pipelined query, whose sweeps lose more beside it:
+    // profiles/r04_fold_from_ntt_ab.md.)
     int lt = lane;  // (as above: keeps the tail's addresses from being hoisted over the digit loop)
     asm volatile("" : "+v"(lt));
     u32* park = reinterpret_cast<u32*>(out);
     u32 rr[32];                                  // modulus-1 round: the row this wave transforms back
     const int irow = wv & 1, imod = wv < 2 ? 1 : 0;
-    u64* sum = reinterpret_cast<u64*>(smem_fw);   // 2 rows x 2048 x 8 B = the first 32 KiB (transpose buffers + tables)
+    u32 r0[32], r1[32];
+#pragma unroll
+    for (int k = 0; k < 32; k++) {
+      r0[k] = reduce64(acc0[k], m);
+      r1[k] = reduce64(acc1[k], m);
+    }
+    u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(smem_fw);
+#define SP_PUT(R, REGION)                                                                              \
+_Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
+  u32x4w_t t4;                                                                                       \
+  t4.x = R[4 * g]; t4.y = R[4 * g + 1]; t4.z = R[4 * g + 2]; t4.w = R[4 * g + 3];                    \
+  sc[(REGION) * 512 + g * 64 + lt] = t4;                                                             \
+}
+#define SP_ADD(R, REGION)                                                                              \
+_Pragma("unroll") for (int g = 0; g < 8; g++) {                                                      \
+  const u32x4w_t t4 = sc[(REGION) * 512 + g * 64 + lt];                                              \
+  R[4 * g] = add_mod(R[4 * g], t4.x, m.q); R[4 * g + 1] = add_mod(R[4 * g + 1], t4.y, m.q);          \
+  R[4 * g + 2] = add_mod(R[4 * g + 2], t4.z, m.q); R[4 * g + 3] = add_mod(R[4 * g + 3], t4.w, m.q);  \
+}
     __syncthreads();  // every wave is done with its transpose buffer and the tables
-    if (wv == 0) {
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        sum[k * 64 + lt] = acc0[k];
-        sum[2048 + k * 64 + lt] = acc1[k];
-      }
-    }
+    if (wv == 2) { SP_PUT(r0, 0) SP_PUT(r1, 1) }
+    if (wv == 3) { SP_PUT(r0, 2) SP_PUT(r1, 3) }
     __syncthreads();
-    if (wv != 0) {
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        __hip_atomic_fetch_add(sum + k * 64 + lt, acc0[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __hip_atomic_fetch_add(sum + 2048 + k * 64 + lt, acc1[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      }
-    }
+    if (wv == 0) { SP_ADD(r0, 0) SP_ADD(r0, 2) }
+    if (wv == 1) { SP_ADD(r1, 1) SP_ADD(r1, 3) }
     __syncthreads();
-    // The four inverse transforms of the step (2 rows x 2 moduli) run at the END, one per wave: modulus 0's rows are
-    // parked in the output slot (as u32, its first 16 KiB) and picked up by waves 2 and 3, so that no wave idles while
-    // two others transform back.
+    if (wv == 0) { SP_PUT(r1, 0) }
+    if (wv == 1) { SP_PUT(r0, 1) }
+    __syncthreads();
+    if (wv == 0) { SP_ADD(r0, 1) }
+    if (wv == 1) { SP_ADD(r1, 0) }
+    __syncthreads();  // the scratch is free again: waves 0 and 1 use their own regions for the inverse transform
+#undef SP_PUT
+#undef SP_ADD
     if (c == 0) {
-      // wave w reduces coefficients 16 (w & 1) .. + 15 of every lane's 32 of row w >> 1 and parks them
-      const int prow = wv >> 1, ph = wv & 1;
-      u32 pr[16];
+      if (wv < 2) {
 #pragma unroll
-      for (int k = 0; k < 16; k++) pr[k] = reduce64(sum[prow * 2048 + (16 * ph + k) * 64 + lt], m);
-#pragma unroll
-      for (int g = 0; g < 4; g++) {
-        u32x4w_t t4;
-        t4.x = pr[4 * g]; t4.y = pr[4 * g + 1]; t4.z = pr[4 * g + 2]; t4.w = pr[4 * g + 3];
-        *reinterpret_cast<u32x4w_t*>(park + prow * N + 32 * lt + 16 * ph + 4 * g) = t4;
+        for (int g = 0; g < 8; g++) {
+          u32x4w_t t4;
+          t4.x = wv == 0 ? r0[4 * g] : r1[4 * g]; t4.y = wv == 0 ? r0[4 * g + 1] : r1[4 * g + 1];
+          t4.z = wv == 0 ? r0[4 * g + 2] : r1[4 * g + 2]; t4.w = wv == 0 ? r0[4 * g + 3] : r1[4 * g + 3];
+          *reinterpret_cast<u32x4w_t*>(park + wv * N + 32 * lt + 4 * g) = t4;
+        }
       }
     } else if (wv < 2) {
 #pragma unroll
-      for (int k = 0; k < 32; k++) rr[k] = reduce64(sum[irow * 2048 + k * 64 + lt], m);
+      for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
     }
-    __syncthreads();  // the sums are read: the scratch is free again
     if (c == 1) {
       const ModConst mi = T.c.mod[imod];
       if (wv >= 2) {
@@ -514,9 +524,7 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)
     const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
     const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
-    // (2 t <= 21: the four waves' raw 64-bit sums are added up exactly before ONE reduction, 21 x 12 q x q < 2^64 -- implied by
-    // the LDS bound, stated for the reader)
-    if (lds <= 80 * 1024 && 2 * d.t <= 21) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
+    if (lds <= 80 * 1024) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
       // (> 64 KiB of dynamic LDS needs no opt-in on gfx950, scripts/ubench/dyn_lds.hip)
       if (es == 1)
         hipLaunchKernelGGL(k_fold_wave<1>, grid, block, lds, s, T, d, d.mats_w);

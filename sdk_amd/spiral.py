@@ -593,7 +593,7 @@ def process_query(params, public_params, query, db):
 
 
 def process_query_batch(params, public_params_list, queries, db):
-    """B queries against one database pass per group of <= 8 (sp_process_query_batch; BASELINE configs[4]).
+    """B queries against one database pass per group of <= 16 (sp_process_query_batch; BASELINE configs[4]).
     Equivalent to [process_query(params, pp_i, q_i, db) for i in ...] -- the reference's per-request loop
     (lib/server/src/bin/server.rs:152-158)."""
     B = len(queries)
@@ -717,7 +717,7 @@ def encode(params, v_packed_ct):
 class Server:
     """ServerState of lib/server/src/bin/server.rs:21-28 without the HTTP transport (sp_server_*): POST /setup and POST
     /private-read bodies in, response bodies out; public parameters stay device resident per client uuid and a list of
-    queries goes through the batch scheduler (<= 8 queries per pass over the database)."""
+    queries goes through the batch scheduler (<= 16 queries per pass over the database)."""
 
     def __init__(self, params, db):
         L = lib()
