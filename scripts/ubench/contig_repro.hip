@@ -5,7 +5,7 @@
 // Mode 2 ("fragment"): first fill most of the device with 1-GiB buffers, free every other one (free memory = many 1-GiB
 // holes), THEN ask for the contiguous range: it can only be satisfied by relocating live buffers -- the situation the
 // round-2 record blames.  The surviving 1-GiB buffers are checked as well.
-// Mode 3 ("history"): what the library did when the corruption was seen (scripts/diag_c2.py): a few SMALL contiguous
+// Mode 3 ("history"): what the library did when the corruption was seen (scripts/archive/r03/diag_c2.py): a few SMALL contiguous
 // allocations are made, filled and freed first (the databases of small configurations), then the plain small buffers
 // (public parameters), then the big contiguous one.
 // hipcc --offload-arch=gfx950 -O2 contig_repro.hip -o contig_repro ;  ./contig_repro [big_gib=56] [nbuf=96] [rounds=3] [contiguous=1|2|3]
@@ -23,7 +23,7 @@ __global__ void k_check(const unsigned* p, size_t n, unsigned buf, unsigned long
   for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) b += p[i] != pat(buf, i);
   if (b) atomicAdd(bad, b);
 }
-// Mode 4 ("reuse"): the sequence that actually fails in the library (scripts/diag_c2b.py: the public parameters are wrong
+// Mode 4 ("reuse"): the sequence that actually fails in the library (scripts/archive/r03/diag_c2b.py: the public parameters are wrong
 // right after sp_pp_deserialize, before any large allocation): small contiguous buffers are written by a KERNEL and freed;
 // a plain hipMalloc then reuses the memory, is zero-filled (hipMemset), receives host data (hipMemcpy H2D) and is read by
 // a kernel.  Does the kernel see the host data?

@@ -305,7 +305,7 @@ class Comm:
 
 class NullTransport:
     """Collectives that return at once (no data moves): the custom transport for timing ONE rank's critical path of a
-    G-rank sharded query on a single GPU (scripts/r03_rank_critical_path.py).  Results are meaningless."""
+    G-rank sharded query on a single GPU (scripts/archive/r03/r03_rank_critical_path.py).  Results are meaningless."""
 
     def __init__(self, rank, world):
         self.comm = Comm.custom(rank, world, lambda send, recv, count, stream: 0, lambda send, recv, count, stream: 0)

@@ -194,6 +194,26 @@ def _session(oracle_mod, cfg, idx, seed):
     return o, cl, pp, q
 
 
+_CASE = {}
+
+
+def _oracle_case(oracle_mod, cfg, idx, key_seed, query_seed):
+    """The CPU side of one end-to-end case -- client, keys, query, random database, the oracle's response -- computed once
+    and shared by the consecutive parametrizations that only vary a switch of the GPU library (the oracle's CPU time, not
+    the GPU's, is most of this suite).  One case is kept at a time: the databases are gigabytes."""
+    import json
+    key = (json.dumps(cfg, sort_keys=True), idx, key_seed, query_seed)
+    if key not in _CASE:
+        _CASE.clear()
+        o = oracle_mod.Params(cfg)
+        cl = oracle_mod.Client(o)
+        pp = cl.generate_keys(key_seed)
+        q = cl.generate_query(idx, query_seed)
+        item, db = o.generate_random_db_and_get_item(idx)
+        _CASE[key] = {"o": o, "cl": cl, "pp": pp, "q": q, "item": item, "db": db, "resp": o.process_query(pp, q, db)}
+    return _CASE[key]
+
+
 @pytest.mark.parametrize("cfg", [FAST, FAST56], ids=["fast", "fast56"])
 def test_pp_deserialize(sp, oracle_mod, cfg):
     o, cl, pp, q = _session(oracle_mod, cfg, 5, 40)
@@ -975,9 +995,9 @@ def test_overlapped_fold_many_planes_parity(sp, oracle_mod):
     (5, 10, 4, "8", "1", "256"),   # the defaults: two buffers of 8 row pairs, one workgroup per CU, tails batched
     (5, 10, 4, "4", "2", "256"),
     (5, 10, 4, "2", "1", "64"),    # two more levels per plane before parking
-    (5, 11, 4, "8", "1", "256"),
     (5, 10, 4, "0", "1", "256"),   # plain persistent sweep, batched tails
     (5, 10, 4, "8", "1", "0"),     # ring sweep, every plane folded to the end under the next sweep
+    (5, 11, 4, "8", "1", "256"),
     (4, 10, 2, "8", "1", "256"),   # 8 row pairs per stream: the ring falls back to buffers of 4
     (3, 10, 3, "8", "1", "256"),   # 4 row pairs per stream: buffers of 2
 ])
@@ -991,9 +1011,9 @@ def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, 
     monkeypatch.setenv("SPIRAL_PIPE_TAIL_DEFER", defer)
     cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": t_gsw, "t_conv": 4, "t_exp_left": 8,
            "t_exp_right": 56, "instances": 1, "db_item_size": 8192}
-    o, cl, pp, q = _session(oracle_mod, cfg, 97, 11)
+    c = _oracle_case(oracle_mod, cfg, 97, 11, 12)
+    o, cl, pp, q, item, db = c["o"], c["cl"], c["pp"], c["q"], c["item"], c["db"]
     p = sp.Params(cfg)
-    item, db = o.generate_random_db_and_get_item(97)
     gpp = sp.PublicParameters.deserialize(p, pp)
     gdb = sp.Database(p).load(db)
     sp.paths_taken()
@@ -1003,7 +1023,7 @@ def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, 
     assert ("sweep_ring" in taken) == (ring != "0"), taken
     # (t_gsw = 2: 29-bit gadget digits, which the fused fold kernels do not take -- nothing is deferred there)
     assert ("fold_tail_batched" in taken) == (defer != "0" and t_gsw > 2), taken
-    assert resp == o.process_query(pp, q, db)
+    assert resp == c["resp"]
     if t_gsw >= 4:  # (fewer gadget digits: the noise is too large to decode, the bytes still have to agree)
         assert cl.decode_response(resp) == o.item_to_vec(item)
 
@@ -1185,16 +1205,12 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     cfg = _FUZZ[ci]
     assert _valid_cfg(cfg), cfg
     monkeypatch.setenv("SPIRAL_FUSED_MIN_PAIRS", fused_min)
-    o = oracle_mod.Params(cfg)
-    idx = (977 * (ci + 1)) % o.num_items
-    cl = oracle_mod.Client(o)
-    pp = cl.generate_keys(60 + ci)
-    q = cl.generate_query(idx, 160 + ci)
+    idx = (977 * (ci + 1)) % oracle_mod.Params(cfg).num_items
+    c = _oracle_case(oracle_mod, cfg, idx, 60 + ci, 160 + ci)   # (shared by the two thresholds of a configuration)
     p = sp.Params(cfg)          # workspaces of this handle read the env at creation
-    item, db = o.generate_random_db_and_get_item(idx)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    gdb = sp.Database(p).load(db)
-    assert sp.process_query(p, gpp, q, gdb) == o.process_query(pp, q, db)
+    gpp = sp.PublicParameters.deserialize(p, c["pp"])
+    gdb = sp.Database(p).load(c["db"])
+    assert sp.process_query(p, gpp, c["q"], gdb) == c["resp"]
 
 
 @pytest.mark.parametrize("mode", ["split", "launches"])
@@ -1207,13 +1223,10 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     # launches (the default of narrow databases): one stream; split (the default before a pipelined sweep): the odd subtree
     # + GSW side on the second stream
     monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1" if mode == "split" else "0")
-    o = oracle_mod.Params(cfg)
-    idx = (613 * (ci + 1)) % o.num_items
-    cl = oracle_mod.Client(o)
-    pp = cl.generate_keys(70 + ci)
-    q = cl.generate_query(idx, 170 + ci)
+    idx = (613 * (ci + 1)) % oracle_mod.Params(cfg).num_items
+    c = _oracle_case(oracle_mod, cfg, idx, 70 + ci, 170 + ci)   # (shared by the two schedules of a configuration)
+    o, pp, q, db = c["o"], c["pp"], c["q"], c["db"]
     p = sp.Params(cfg)
-    item, db = o.generate_random_db_and_get_item(idx)
     gpp = sp.PublicParameters.deserialize(p, pp)
     gdb = sp.Database(p).load(db)
     sp.paths_taken()
@@ -1222,7 +1235,7 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     assert ("expand_split" in taken) == (mode == "split"), taken
     e_reg, e_fold = o.expand_query(pp, q)
     assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
-    expect = o.process_query(pp, q, db)
+    expect = c["resp"]
     assert sp.process_query(p, gpp, q, gdb) == expect
     assert sp.process_query(p, gpp, q, gdb) == expect
     # row shard: pruned even subtree through the same schedules

@@ -225,6 +225,17 @@ def test_chacha20_rfc8439(oracle_mod):
     assert ks[64:80].hex() == "9f07e7be5551387a98ba977c732d080d"
     first = int(oracle_mod.chacha20_rng_u64(bytes(32), 1)[0])
     assert first == (0x903df1a0 << 32) | 0xade0b876   # gen::<u64>() = lo word first
+    # The two further keystreams a seed can reach (RFC 8439 appendix A.1 #3: key 00..01, block 1; #4: key 00 ff 00.., block 2).
+    # #1/#2 above and #3 are the very vectors rand_chacha 0.3.1 (Cargo.toml:25; the crate itself is not under /root/reference)
+    # pins ChaCha20Rng::from_seed to in its own tests (chacha.rs test_chacha_true_values_a / _b: words 0xade0b876 0x903df1a0 ...
+    # and, after skipping block 0, 0x2452eb3a 0x9249f8ec ...): key = seed, 64-bit block counter from 0, stream 0, words in order.
+    ks3 = oracle_mod.chacha20_rng_u64(bytes(31) + b"\x01", 16).tobytes()
+    assert ks3[64:128].hex() == ("3aeb5224ecf849929b9d828db1ced4dd832025e8018b8160b82284f3c949aa5a"
+                                 "8eca00bbb4a73bdad192b5c42f73f2fd4e273644c8b36125a64addeb006c13a0")
+    assert int.from_bytes(ks3[64:68], "little") == 0x2452eb3a and int.from_bytes(ks3[68:72], "little") == 0x9249f8ec
+    ks4 = oracle_mod.chacha20_rng_u64(b"\x00\xff" + bytes(30), 24).tobytes()
+    assert ks4[128:192].hex() == ("72d54dfbf12ec44b362692df94137f328fea8da73990265ec1bbbea1ae9af0ca"
+                                  "13b25aa26cb4a648cb9b9d1be65b2c0924a66c54d545ec1b7374f4872e99f096")
 
 
 # ---- the add_u64 quirk of barrett_raw_u128 (arith.rs:155-180) and why it can never be observed with Q ------------------
