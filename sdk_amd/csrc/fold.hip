@@ -461,7 +461,7 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
           u32x4w_t t4;
           t4.x = wv == 0 ? r0[4 * g] : r1[4 * g]; t4.y = wv == 0 ? r0[4 * g + 1] : r1[4 * g + 1];
           t4.z = wv == 0 ? r0[4 * g + 2] : r1[4 * g + 2]; t4.w = wv == 0 ? r0[4 * g + 3] : r1[4 * g + 3];
-          *reinterpret_cast<u32x4w_t*>(park + wv * N + 32 * lt + 4 * g) = t4;
+          *reinterpret_cast<u32x4w_t*>(park + wv * N + (d.park_coalesced ? g * 256 + 4 * lt : 32 * lt + 4 * g)) = t4;
         }
       }
     } else if (wv < 2) {
@@ -473,7 +473,7 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
       if (wv >= 2) {
 #pragma unroll
         for (int g = 0; g < 8; g++) {
-          const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + 32 * lt + 4 * g);
+          const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + (d.park_coalesced ? g * 256 + 4 * lt : 32 * lt + 4 * g));
           rr[4 * g] = t4.x; rr[4 * g + 1] = t4.y; rr[4 * g + 2] = t4.z; rr[4 * g + 3] = t4.w;
         }
       }
