@@ -15,7 +15,7 @@ import torch
 import bench
 import sdk_amd as sp
 
-DEFAULTS = {"pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256, "fold_park": 1}
+DEFAULTS = {"pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256}
 
 
 def single(p, pp, qs, db, steps):

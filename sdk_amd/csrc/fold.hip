@@ -417,6 +417,9 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
     // profiles/r04_fold_from_ntt_ab.md.)
     int lt = lane;  // (as above: keeps the tail's addresses from being hoisted over the digit loop)
     asm volatile("" : "+v"(lt));
+    // (parking layout: vector g of all lanes contiguous -- whole 1-KiB runs per store instruction; with a 128-byte lane stride
+    // the 16-byte pieces made the kernel write 3.3x its algorithmic bytes, profiles/r04_final_pmc_per_kernel_unpipelined.md;
+    // measured on one allocation: -1 % on the un-pipelined fold and on 8-query steps, profiles/r04_fold_park_ab_raw.txt)
     u32* park = reinterpret_cast<u32*>(out);
     u32 rr[32];                                  // modulus-1 round: the row this wave transforms back
     const int irow = wv & 1, imod = wv < 2 ? 1 : 0;
@@ -461,7 +464,7 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
           u32x4w_t t4;
           t4.x = wv == 0 ? r0[4 * g] : r1[4 * g]; t4.y = wv == 0 ? r0[4 * g + 1] : r1[4 * g + 1];
           t4.z = wv == 0 ? r0[4 * g + 2] : r1[4 * g + 2]; t4.w = wv == 0 ? r0[4 * g + 3] : r1[4 * g + 3];
-          *reinterpret_cast<u32x4w_t*>(park + wv * N + (d.park_coalesced ? g * 256 + 4 * lt : 32 * lt + 4 * g)) = t4;
+          *reinterpret_cast<u32x4w_t*>(park + wv * N + g * 256 + 4 * lt) = t4;
         }
       }
     } else if (wv < 2) {
@@ -473,7 +476,7 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
       if (wv >= 2) {
 #pragma unroll
         for (int g = 0; g < 8; g++) {
-          const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + (d.park_coalesced ? g * 256 + 4 * lt : 32 * lt + 4 * g));
+          const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + g * 256 + 4 * lt);
           rr[4 * g] = t4.x; rr[4 * g + 1] = t4.y; rr[4 * g + 2] = t4.z; rr[4 * g + 3] = t4.w;
         }
       }

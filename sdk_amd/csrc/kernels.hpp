@@ -173,10 +173,6 @@ struct FoldDesc {
   int zero_shortcuts;
   // the level's operands in wave layout (k_fold_wave); nullptr: not available
   const u32* mats_w;
-  // k_fold_wave parks modulus 0's rows in the output slot between the two modulus rounds: 1 = vector g of all lanes
-  // contiguous (whole 1-KiB runs per store instruction), 0 = 128-byte lane stride (16-byte pieces: the PMC showed 3.3x the
-  // fold's algorithmic write bytes, profiles/r04_final_pmc_per_kernel_unpipelined.md); switch fold_park
-  int park_coalesced;
 };
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);

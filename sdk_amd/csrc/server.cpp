@@ -1076,7 +1076,6 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
       fd.planes = np;
       fd.t = (int)p.t_gsw;
       fd.bits = (int)p.bits_per(p.t_gsw);
-      fd.park_coalesced = (int)tunable("fold_park", 1);
       launch_fold_fused(D.T, fd, s);
       std::swap(X, Y);
       cur = half;
