@@ -57,7 +57,7 @@ const char* sp_last_error(void);
 uint64_t sp_paths_taken(int reset);
 const char* sp_path_name(int bit); /* NULL past the last defined bit */
 /* Run-time tunables for A/B measurements inside one process (the same switches as the SPIRAL_<NAME> environment
- * variables of DESIGN.md section 8, e.g. "pipe_wgs", "pipe_unroll", "sweep_prio", "cu_split"): takes effect on the next launch / next workspace. */
+ * variables of DESIGN.md section 8, e.g. "pipe_ring", "pipe_tail_defer", "sweep_prio", "batch_group"): takes effect on the next launch / next workspace. */
 int sp_debug_set(const char* name, long value);
 /* Number of visible HIP devices (0 if none); selects `device` for this thread's subsequent calls. */
 int sp_device_count(void);
