@@ -976,6 +976,14 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
   int group_max = (int)tunable("batch_group", 0);
   if (group_max <= 0) group_max = shape_max;
   group_max = std::max(1, std::min(shape_max, group_max));
+  if (group_max > SWEEP_BATCH_MAX && batch > SWEEP_BATCH_MAX) {
+    // two groups of 16 hold up to 32 workspaces: keep to groups of 8 when the device could not hold them beside the database
+    // (a rough bound -- three times the first-dimension output per workspace; pooled workspaces only make it conservative)
+    size_t fr = 0, tot = 0;
+    const size_t per_ws = (size_t)3 * p.planes() * 4 * POLY_LEN * (size_t)db->np_local * sizeof(u32);
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < (size_t)2 * SWEEP_GROUP_MAX * per_ws) group_max = SWEEP_BATCH_MAX;
+    (void)hipGetLastError();
+  }
   // a list of exactly 9 .. 16 queries is one group; longer lists are cut into groups of group_max (a last group of <= 8
   // takes the one-tile pass)
   std::vector<sp_query_t*> all_qs;   // queries in flight (at most two groups: bounds the workspaces held)
