@@ -647,7 +647,7 @@ def main():
     sweep_paths = sp.paths_taken()
     batch_pass = None
     if mode in ("single", "replicas") and batch > 1 and cfg["nu_2"] >= 7 and (1 << cfg["nu_1"]) % 2 == 0:   # PACKED databases only
-        runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 8))]
+        runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 16 if batch > 8 else 8))]
         sp.paths_taken()
         pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
         taken = sp.paths_taken()
@@ -655,7 +655,8 @@ def main():
             r.free()
         N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
         pass_bytes = db.device_bytes() + len(runs) * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
-        batch_pass = {"kernel": "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % len(runs),
+        batch_pass = {"kernel": "k_sweep_mfma_batch<8, 1, 0, 2> (two query tiles)" if "sweep_batch_mfma_two_tiles" in taken else
+                                "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % len(runs),
                       "queries_per_pass": len(runs), "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
                       "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "note": "one pass over the whole resident database for the whole group (sp_bench_sweep_batch, HIP events "
