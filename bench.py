@@ -429,7 +429,7 @@ def main():
                     help="queries per step per GPU (single-GPU and replicas modes): groups of <= 8 queries share one "
                          "database pass (sp_process_query_batch).  Default 1 (single) / 8 (replicas).")
     ap.add_argument("--headline-only", action="store_true",
-                    help="only the headline timed region + roofline (no `secondary` objects: batch8 / sustained / c4); "
+                    help="only the headline timed region + roofline (no `secondary` objects: sustained / batch8 / batch16 / c4); "
                          "what the profiling scripts use so that kernel statistics hold the headline's launches only")
     ap.add_argument("--sustained", type=int, default=1000,
                     help="queries of the `secondary.sustained` run (0 = skip); the default runs for ~12 s at C2: round 3 saw a "
