@@ -524,8 +524,12 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
     const int steps = d.nj >> 4;
 #define SP_MFMA2(NB_)                                                                                                  \
   {                                                                                                                    \
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB_, 1, 0, 2>),                        \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                  \
+    static thread_local size_t allowed = 0;  /* (more than 64 KiB of dynamic LDS: raised once per thread and size) */   \
+    if (lds2 > allowed) {                                                                                              \
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB_, 1, 0, 2>),                      \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                \
+      allowed = lds2;                                                                                                  \
+    }                                                                                                                  \
     hipLaunchKernelGGL((k_sweep_mfma_batch<NB_, 1, 0, 2>), grid, dim3(256), lds2, s, T, m);                            \
   }
     if (steps % 8 == 0) SP_MFMA2(8) else if (steps % 4 == 0) SP_MFMA2(4) else SP_MFMA2(2)
