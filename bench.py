@@ -462,6 +462,8 @@ def main():
     if args.gpus != world:
         raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
+    if hasattr(sp.lib(), "sp_emulated_device_marker"):   # SPIRAL_HIP_LIB pointing at tests/emu/_build: a test tool, not a device
+        raise SystemExit("bench.py measures the gfx950 library; the loaded one is the tests' host emulation")
     if sp.lib().sp_set_device(local_rank) != 0:
         raise SystemExit("sp_set_device failed")
     # SPIRAL_FORCE_DIST=1: run the N > 1 code path (process group, collectives) at world size 1 (1-GPU boxes)

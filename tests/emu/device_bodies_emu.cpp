@@ -2,7 +2,7 @@
 // UNCHANGED for the host and run as emulated workgroups (emu_runtime.cpp), behind a small C interface for
 // tests/test_device_bodies_emulated.py.  What it buys: the CPU suite checks the kernels' arithmetic, index patterns, LDS
 // exchanges and wave swaps against the oracle before anything reaches a GPU.  What it cannot do: run the product (the
-// sweep, the fold kernel's forward transform and every launch wrapper need gfx950), or say anything about speed.
+// sweep kernels, the kernels' cross-wave reductions and every launch wrapper need gfx950), or say anything about speed.
 #include <cstring>
 #include <stdexcept>
 #include <string>
@@ -30,9 +30,10 @@ int guarded(F&& f) {
     return 1;
   }
 }
-// LDS of the emulated workgroup (one workgroup at a time)
-u32 g_ldsA[2 * LDS_WORDS], g_ldsB[2 * LDS_WORDS];
-u32 g_wbuf[4][WBUF_WORDS];
+// LDS of the emulated workgroup (one copy per host thread of the emulation = per workgroup in flight)
+thread_local u32 g_ldsA[2 * LDS_WORDS], g_ldsB[2 * LDS_WORDS];
+thread_local u32 g_wbuf[4][WBUF_WORDS];
+thread_local u32 g_ltw[2 * N];
 }  // namespace
 
 extern "C" {
@@ -57,7 +58,7 @@ int emu_ntt_block(void* h, int c, int inverse, uint32_t* data) {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
     const u32* tw = E.T.tw + ((size_t)c * 4 + (inverse ? 2 : 0)) * N;
-    emu::run_block(256, 0, 0, [&] {
+    emu::run_block(256, [&] {
       const int tau = threadIdx.x;
       u32 v[8];
       if (!inverse) {
@@ -81,7 +82,7 @@ int emu_ntt_block_m2(void* h, int c, int inverse, uint32_t* data) {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
     const u32* tw = E.T.tw + ((size_t)c * 4 + (inverse ? 2 : 0)) * N;
-    emu::run_block(256, 0, 0, [&] {
+    emu::run_block(256, [&] {
       const int tau = threadIdx.x;
       u32 v[2][8];
       if (!inverse) {
@@ -109,7 +110,7 @@ int emu_wave_ntt_inv(void* h, int c, uint32_t* data) {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
     const u32* itw = E.T.tw + ((size_t)c * 4 + 2) * N;
-    emu::run_block(256, 0, 0, [&] {
+    emu::run_block(256, [&] {
       const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
       u32* poly = data + (size_t)wv * N;
       u32 v[32];
@@ -117,6 +118,32 @@ int emu_wave_ntt_inv(void* h, int c, uint32_t* data) {
       __syncthreads();
       wntt_inv(v, lane, g_wbuf[wv], itw, m.q, m.two_q);
       for (int k = 0; k < 32; k++) poly[64 * k + lane] = v[k];
+    });
+  });
+}
+
+// wntt_fwd: four waves, each its own polynomial of modulus c (values < 2q allowed in); canon = the CANON form (canonical out),
+// otherwise the lazy form (< 12q out, same residues)
+int emu_wave_ntt_fwd(void* h, int c, int canon, uint32_t* data) {
+  return guarded([&] {
+    const EmuParams& E = *(EmuParams*)h;
+    const ModConst m = E.T.c.mod[c];
+    const u32* tw = E.T.tw + (size_t)c * 4 * N;
+    emu::run_block(256, [&] {
+      const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      u32* poly = data + (size_t)wv * N;
+      wtw_stage(g_ltw, tw, threadIdx.x);
+      WaveScalarTw s;
+      wntt_scalar_tw(s, tw);
+      u32 v[32];
+      for (int k = 0; k < 32; k++) v[k] = poly[64 * k + lane];
+      __syncthreads();
+      WaveNoHooks hk;
+      if (canon)
+        wntt_fwd<true>(v, lane, g_wbuf[wv], tw, s, g_ltw, m.q, m.two_q, hk);
+      else
+        wntt_fwd<false>(v, lane, g_wbuf[wv], tw, s, g_ltw, m.q, m.two_q, hk);
+      for (int k = 0; k < 32; k++) poly[32 * lane + k] = v[k];
     });
   });
 }
@@ -133,7 +160,7 @@ int emu_from_ntt(void* h, const uint32_t* src, int n, int automorph_t, uint64_t*
     d.dst = dst;
     d.n_polys = n;
     d.automorph_t = automorph_t;
-    for (int blk = 0; blk < n; blk++) emu::run_block(256, blk, 0, [&] { ntt_inv_body(E.T, d, blk, g_ldsA, g_ldsB); });
+    for (int blk = 0; blk < n; blk++) emu::run_block(256, [&] { ntt_inv_body(E.T, d, blk, g_ldsA, g_ldsB); });
   });
 }
 // the same from the sweep-native buffer [plane][r][crt][z][ii] (num_per = np), sums of residues allowed when premod
@@ -146,7 +173,7 @@ int emu_from_sweep(void* h, const uint32_t* src, int np, int planes, int premod,
     d.n_polys = planes * np * 2;
     d.premod = premod;
     d.sweep_np = np;
-    for (int blk = 0; blk < d.n_polys; blk++) emu::run_block(256, blk, 0, [&] { ntt_inv_body(E.T, d, blk, g_ldsA, g_ldsB); });
+    for (int blk = 0; blk < d.n_polys; blk++) emu::run_block(256, [&] { ntt_inv_body(E.T, d, blk, g_ldsA, g_ldsB); });
   });
 }
 
@@ -167,7 +194,7 @@ int emu_digits_to_ntt(void* h, const uint64_t* src, int batch, int rdim, int col
     d.src_row0 = 0;
     d.src_cols = cols;
     for (int o = 0; o < d.n_out; o++)
-      for (int c = 0; c < 2; c++) emu::run_block(256, o, c, [&] { ntt_fwd_body(E.T, d, o, c, g_ldsA, g_ldsB); });
+      for (int c = 0; c < 2; c++) emu::run_block(256, [&] { ntt_fwd_body(E.T, d, o, c, g_ldsA, g_ldsB); });
   });
 }
 

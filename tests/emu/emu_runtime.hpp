@@ -1,10 +1,8 @@
-// TEST INFRASTRUCTURE: runs a callable as one workgroup of host threads (see hip/hip_runtime.h in this directory).
+// TEST INFRASTRUCTURE: see hip/hip_runtime.h in this directory.
 #pragma once
 #include <hip/hip_runtime.h>
 
-#include <functional>
-
 namespace emu {
-// body() runs once per work-item with threadIdx.x = 0 .. nthreads-1 and blockIdx = (bx, by); one workgroup at a time
-void run_block(unsigned nthreads, unsigned bx, unsigned by, const std::function<void()>& body);
+// body() runs once per work-item of ONE workgroup of `nthreads`
+inline void run_block(unsigned nthreads, const std::function<void()>& body) { emu_launch(dim3(1), dim3(nthreads), 0, body); }
 }  // namespace emu

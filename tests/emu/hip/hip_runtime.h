@@ -1,19 +1,56 @@
-// TEST INFRASTRUCTURE, not a runtime: the few names of <hip/hip_runtime.h> that sdk_amd/csrc/device_common.hpp needs, so that
-// g++ can compile the DEVICE helper functions of the product headers unchanged and tests/emu/device_bodies_emu.cpp can run
-// them as one 256-thread workgroup on host threads (a thread per work-item, a pthread barrier for __syncthreads).  It lets the
-// CPU suite check the kernels' arithmetic and LDS index patterns against the oracle; nothing in sdk_amd/ includes it and
-// nothing here is a fallback for the GPU path (the product library is built by hipcc for gfx950 only and fails without a GPU).
+// TEST INFRASTRUCTURE, not a runtime and not a fallback.
+//
+// A stand-in for <hip/hip_runtime.h> with which the HOST compiler can build the sources of sdk_amd/csrc unchanged, so that the
+// CPU test suite can run the kernels' code against the oracle without a GPU (tests/test_device_bodies_emulated.py,
+// tests/test_emulated_library.py):
+//   * a workgroup is a set of fibers (one per work-item) on one host thread, scheduled round-robin; __syncthreads, the
+//     lockstep points of a wave (LDS hand-over inside a wave, v_permlane32_swap, __shfl_xor, readfirstlane) are barriers among
+//     them; the workgroups of a launch are dealt to a few host threads (emu_runtime.cpp);
+//   * "device memory" is host memory, every launch and copy completes before the call returns, streams and events are names;
+//   * gfx950 builtins are restated in C (the matrix-core instruction included: see emu_mfma_i32_16x16x64_i8).
+// Nothing in sdk_amd/ includes this file; the product library is built by hipcc for gfx950 only and fails without a GPU.  The
+// emulation says nothing about speed, occupancy, memory ordering between workgroups, or anything else the hardware decides.
 #pragma once
+// every standard header the product sources use, BEFORE the keyword macros at the end of this file
+#include <algorithm>
+#include <array>
+#include <atomic>
+#include <cctype>
+#include <cerrno>
+#include <chrono>
+#include <cmath>
+#include <condition_variable>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <new>
+#include <random>
+#include <shared_mutex>
+#include <stdexcept>
+#include <string>
+#include <sys/random.h>
+#include <thread>
+#include <unordered_map>
+#include <vector>
 
 #define __device__
 #define __host__
 #define __global__
-#define __shared__ static
+#define __constant__
+// LDS: one copy per host thread = per workgroup in flight (all fibers of a workgroup run on one host thread).  At block scope
+// thread_local implies static; `extern __shared__ T name[];` becomes a declaration of spiral::name, defined in emu_library.cpp.
+#define __shared__ thread_local
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
 #define __noinline__ __attribute__((noinline))
+#define HIP_KERNEL_NAME(...) __VA_ARGS__
 
 struct dim3 {
   unsigned x = 1, y = 1, z = 1;
@@ -22,21 +59,17 @@ struct dim3 {
 struct emu_uint3 {
   unsigned x = 0, y = 0, z = 0;
 };
-extern thread_local emu_uint3 threadIdx, blockIdx;
-extern thread_local dim3 blockDim, gridDim;
+struct emu_workitem {  // what a fiber knows about itself
+  emu_uint3 tid, bid;
+  dim3 bdim, gdim;
+};
+emu_workitem* emu_self();
+#define threadIdx (emu_self()->tid)
+#define blockIdx (emu_self()->bid)
+#define blockDim (emu_self()->bdim)
+#define gridDim (emu_self()->gdim)
 
-typedef struct emu_stream* hipStream_t;
-typedef struct emu_event* hipEvent_t;
-typedef int hipError_t;
-
-void emu_syncthreads();
-int emu_syncthreads_or(int v);
-inline void __syncthreads() { emu_syncthreads(); }
-inline int __syncthreads_or(int v) { return emu_syncthreads_or(v); }
-
-inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
-inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
-
+// ---- vector types ----------------------------------------------------------------------------------------------------
 struct uint2 {
   uint32_t x, y;
 };
@@ -53,23 +86,182 @@ template <typename T>
 inline T min(T a, T b) { return a < b ? a : b; }
 template <typename T>
 inline T max(T a, T b) { return a > b ? a : b; }
-// atomics on global / LDS words: the emulated work-items are real host threads
+
+// ---- work-item functions ---------------------------------------------------------------------------------------------
+void emu_syncthreads();
+int emu_syncthreads_or(int v);
+inline void __syncthreads() { emu_syncthreads(); }
+inline int __syncthreads_or(int v) { return emu_syncthreads_or(v); }
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_system() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+inline void __threadfence_block() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }
+
+inline uint32_t __umulhi(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) >> 32); }
+inline uint64_t __umul64hi(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) >> 64); }
+inline int __popc(unsigned v) { return __builtin_popcount(v); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline int __clz(int v) { return v ? __builtin_clz((unsigned)v) : 32; }
+inline int __ffs(int v) { return __builtin_ffs(v); }
+
+// atomics on global / LDS words: workgroups of one launch run on several host threads
 inline unsigned atomicOr(unsigned* p, unsigned v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 inline int atomicOr(int* p, int v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
-inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
-inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long atomicOr(unsigned long long* p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long atomicAdd(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned atomicMax(unsigned* p, unsigned v) {
+  unsigned o = __atomic_load_n(p, __ATOMIC_RELAXED);
+  while (o < v && !__atomic_compare_exchange_n(p, &o, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {
+  }
+  return o;
+}
+inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 
-// ---- wave-level operations (a wave = 64 consecutive work-items of the emulated workgroup) ----
+// ---- wave-level operations (a wave = 64 consecutive work-items of the workgroup) -----------------------------------------
 typedef uint32_t emu_u32x2 __attribute__((ext_vector_type(2)));
+typedef int emu_i32x4 __attribute__((ext_vector_type(4)));
 void emu_wave_barrier();
 emu_u32x2 emu_permlane32_swap(uint32_t vdst, uint32_t vsrc);
+uint32_t emu_wave_exchange(uint32_t mine, unsigned from_lane);  // every lane contributes `mine`, gets lane `from_lane`'s
+template <typename T>
+inline T emu_shfl(T v, unsigned from_lane) {
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "4- or 8-byte shuffles");
+  if (sizeof(T) == 4) {
+    uint32_t b;
+    std::memcpy(&b, &v, 4);
+    b = emu_wave_exchange(b, from_lane);
+    std::memcpy(&v, &b, 4);
+    return v;
+  }
+  uint32_t b[2];
+  std::memcpy(b, &v, 8);
+  b[0] = emu_wave_exchange(b[0], from_lane);
+  b[1] = emu_wave_exchange(b[1], from_lane);
+  std::memcpy(&v, b, 8);
+  return v;
+}
+unsigned emu_lane();
+template <typename T>
+inline T __shfl_xor(T v, int mask, int width = 64) { (void)width; return emu_shfl(v, emu_lane() ^ (unsigned)mask); }
+template <typename T>
+inline T __shfl(T v, int lane, int width = 64) { (void)width; return emu_shfl(v, (unsigned)lane & 63u); }
+template <typename T>
+inline T __shfl_down(T v, unsigned d, int width = 64) { (void)width; const unsigned l = emu_lane(); return emu_shfl(v, l + d < 64 ? l + d : l); }
+
 #define __builtin_amdgcn_sched_barrier(mask) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
+#define __builtin_amdgcn_s_sleep(n) ((void)0)
 #define __builtin_amdgcn_wave_barrier() emu_wave_barrier()
 // v_permlane32_swap_b32 vdst, vsrc: the upper 32 lanes of vdst trade places with the lower 32 lanes of vsrc
 #define __builtin_amdgcn_permlane32_swap(vdst, vsrc, fi, bc) emu_permlane32_swap((vdst), (vsrc))
+#define __builtin_amdgcn_readfirstlane(v) ((decltype(v))emu_wave_exchange((uint32_t)(v), 0))
+// v_alignbit_b32: low 32 bits of ({hi, lo} >> (shift & 31))
+inline uint32_t emu_alignbit(uint32_t hi, uint32_t lo, uint32_t sh) { return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31)); }
+#define __builtin_amdgcn_alignbit(hi, lo, sh) emu_alignbit((hi), (lo), (sh))
+// v_bfe_i32 / v_bfe_u32: `width` bits of src from bit `off`, sign- / zero-extended (width 0 gives 0)
+inline int emu_sbfe(int src, unsigned off, unsigned width) {
+  off &= 31;
+  width &= 31;
+  if (!width) return 0;
+  const uint32_t f = ((uint32_t)src >> off) & ((width == 32 ? 0u : (1u << width)) - 1u);
+  const uint32_t sign = 1u << (width - 1);
+  return (int)((f ^ sign) - sign);
+}
+inline uint32_t emu_ubfe(uint32_t src, unsigned off, unsigned width) {
+  off &= 31;
+  width &= 31;
+  if (!width) return 0;
+  return (src >> off) & ((1u << width) - 1u);
+}
+#define __builtin_amdgcn_sbfe(src, off, width) emu_sbfe((src), (off), (width))
+#define __builtin_amdgcn_ubfe(src, off, width) emu_ubfe((src), (off), (width))
+// v_mfma_i32_16x16x64_i8 (one wave): D[16][16] = A[16][64] * B[64][16] + C, int8 operands, int32 sums.  Operand layout of the
+// instruction: lane l holds, of A, row l % 16, the 16 values k = 16 (l / 16) .. + 15 (four dwords, byte b of dword w = k offset
+// 4 w + b); of B, column l % 16, the same 16 values of k; of C / D, column l % 16, rows 4 (l / 16) .. + 3.
+emu_i32x4 emu_mfma_i32_16x16x64_i8(emu_i32x4 a, emu_i32x4 b, emu_i32x4 c);
+#define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu_mfma_i32_16x16x64_i8((a), (b), (c))
 
-// gfx950 inline assembly cannot run here: the statement is replaced by a call that throws, so a test that reaches one fails
-// loudly instead of computing something else (wave_ntt.hpp's forward butterfly batch is the one user; its inverse has none).
-[[noreturn]] void emu_unsupported_asm();
-#define asm(...) emu_unsupported_asm()
+// ---- host API: everything completes before the call returns -------------------------------------------------------------
+typedef int hipError_t;
+enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
+typedef struct emu_stream* hipStream_t;
+struct emu_event {
+  std::chrono::steady_clock::time_point t;
+};
+typedef emu_event* hipEvent_t;
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0,
+                  hipDeviceMallocDefault = 0, hipDeviceMallocContiguous = 4 };
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+struct hipDeviceProp_t {
+  int multiProcessorCount = 256;
+  char gcnArchName[32] = "host-emulation";
+  size_t totalGlobalMem = (size_t)1 << 36;
+};
+
+inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory" : "emulated HIP error"; }
+inline const char* hipGetErrorName(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipErrorEmulated"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = (size_t)1 << 35; *tot = (size_t)1 << 36; return hipSuccess; }
+hipError_t emu_malloc(void** p, size_t bytes);
+template <typename T>
+inline hipError_t hipMalloc(T** p, size_t bytes) { return emu_malloc((void**)p, bytes); }
+template <typename T>
+inline hipError_t hipExtMallocWithFlags(T** p, size_t bytes, unsigned) { return emu_malloc((void**)p, bytes); }
+template <typename T>
+inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { return emu_malloc((void**)p, bytes); }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
+inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
+  for (size_t r = 0; r < height; r++) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
+  return hipSuccess;
+}
+inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
+inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t) new char; return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreate(s); }
+inline hipError_t hipStreamDestroy(hipStream_t s) { delete (char*)s; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{std::chrono::steady_clock::now()}; return hipSuccess; }
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
+  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
+  return hipSuccess;
+}
+inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+
+// a launch: every workgroup runs to completion before this returns
+void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item);
+#define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
+  emu_launch(dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
+
+// ---- keyword macros (last: nothing from the standard library is parsed after this point by way of this header) -----------
+// Inline assembly.  `asm volatile("" : "+v"(x))` (an optimisation barrier; the gfx950 constraints do not exist here) becomes an
+// empty statement.  `asm("...")` with text: the product headers contain exactly ONE such statement outside the placement probe
+// (wave_ntt.hpp, ct_bfly_batch: four v_mad_u64_u32, nl[b + i] += qt[b + i] * q as 64-bit sums); it is restated here BY OPERAND
+// NAME -- any other one fails to compile (unknown names) instead of computing something else.  That one line of arithmetic is
+// therefore the emulation's, not the product's.
+static const int EMU_ASM_ = 0;
+#define asm (void)EMU_ASM_
+#define EMU_ASM_(...)                                                                   \
+  [&] {                                                                                 \
+    for (int i_ = 0; i_ < 4; i_++) nl[b + i_] += (uint64_t)qt[b + i_] * (uint64_t)q;    \
+  }()
+#define volatile(...)

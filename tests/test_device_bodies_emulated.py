@@ -54,7 +54,7 @@ def emu():
     lib.emu_params_new.restype = C.c_void_p
     lib.emu_params_new.argtypes = [C.c_char_p]
     lib.emu_last_error.restype = C.c_char_p
-    for name in ("emu_params_free", "emu_ntt_block", "emu_ntt_block_m2", "emu_wave_ntt_inv", "emu_from_ntt", "emu_from_sweep",
+    for name in ("emu_params_free", "emu_ntt_block", "emu_ntt_block_m2", "emu_wave_ntt_inv", "emu_wave_ntt_fwd", "emu_from_ntt", "emu_from_sweep",
                  "emu_digits_to_ntt", "emu_reduce64", "emu_rescale"):
         getattr(lib, name).argtypes = None
     h = lib.emu_params_new(json.dumps(FAST).encode())
@@ -132,6 +132,25 @@ def test_wave_inverse_transform(emu, oracle_mod, c):              # wntt_inv: 32
         emu.call("emu_wave_ntt_inv", C.c_int(c), _p32(data))
         want = np.concatenate([_oracle_ntt(o.ntt_inverse, p, c) for p in four])
         assert np.array_equal(data.astype(np.uint64), want), (c, g)
+
+
+@pytest.mark.parametrize("c", [0, 1])
+def test_wave_forward_transform(emu, oracle_mod, c):              # wntt_fwd: lazy five-instruction butterflies, LDS twiddle copy
+    o = oracle_mod.Params(FAST)
+    q = (Q0, Q1)[c]
+    rng = np.random.default_rng(35 + c)
+    polys = _edge_polys(rng, q, 2)[:8]
+    polys[1] = polys[1] + np.uint64(q)                  # inputs < 2q are allowed (the fold's digit differences)
+    for g in range(0, 8, 4):
+        four = polys[g:g + 4]
+        want = np.concatenate([_oracle_ntt(o.ntt_forward, p % np.uint64(q), c) for p in four])
+        data = np.concatenate(four).astype(np.uint32)
+        emu.call("emu_wave_ntt_fwd", C.c_int(c), C.c_int(1), _p32(data))
+        assert np.array_equal(data.astype(np.uint64), want), (c, g)
+        data = np.concatenate(four).astype(np.uint32)
+        emu.call("emu_wave_ntt_fwd", C.c_int(c), C.c_int(0), _p32(data))   # lazy form: < 12q, same residues
+        assert int(data.max()) < 12 * q
+        assert np.array_equal(data.astype(np.uint64) % np.uint64(q), want), (c, g)
 
 
 def test_from_ntt_body(emu, oracle_mod):                          # poly.rs:646-663 (+ automorph, poly.rs:393-405) vs ntt_inv_body
