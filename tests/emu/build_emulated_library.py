@@ -16,7 +16,7 @@ BUILD = os.environ.get("SPIRAL_EMU_BUILD") or os.path.join(HERE, "_build")   # (
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 PRODUCT = ["params.cpp", "ntt.hip", "fold.hip", "elementwise.hip", "sweep.hip", "db.hip", "sparse.hip", "server.cpp", "capi.cpp",
            "comm.cpp", "endpoint.cpp"]
-OWN = ["emu_runtime.cpp", "emu_library.cpp"]
+OWN = ["emu_runtime.cpp", "emu_library.cpp", "emu_rccl.cpp"]
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
 
@@ -55,8 +55,8 @@ def build(force=False, asan=False):
             raise RuntimeError(f"emulated build of {name} failed:\n{err[-4000:]}")
     so = library_path(asan)
     if jobs or not os.path.exists(so):
-        subprocess.run([CLANG, "-shared", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if asan else []) + ["-o", so] + objs,
-                       check=True)
+        subprocess.run([CLANG, "-shared", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if asan else []) + ["-o", so] + objs +
+                       ["-lrt"], check=True)
     return so
 
 

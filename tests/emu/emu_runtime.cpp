@@ -79,6 +79,19 @@ struct Block {
     if (stacks) munmap(stacks, stacks_for * STACK_BYTES);
   }
 };
+int g_schedule = 0;  // 0 forward, 1 reverse, 2 random
+unsigned long long g_schedule_seed = 1;
+struct ScheduleInit {
+  ScheduleInit() {
+    if (const char* e = std::getenv("SPIRAL_EMU_SCHEDULE")) {
+      if (!std::strncmp(e, "reverse", 7)) g_schedule = 1;
+      if (!std::strncmp(e, "random", 6)) {
+        g_schedule = 2;
+        if (e[6] == ':') g_schedule_seed = std::strtoull(e + 7, nullptr, 10);
+      }
+    }
+  }
+} g_schedule_init;
 thread_local Block* tl_block = nullptr;
 thread_local Fiber* tl_fiber = nullptr;
 thread_local emu_workitem tl_host_item;  // threadIdx etc. read outside a launch
@@ -159,13 +172,25 @@ void run_block(Block& b, dim3 grid, dim3 block, unsigned bx, unsigned by, unsign
     f.stack_lo = b.stacks + (size_t)t * STACK_BYTES;
   }
   tl_block = &b;
+  // the order in which the work-items of a round run: 0 .. n-1, reversed, or shuffled every round (SPIRAL_EMU_SCHEDULE).  A
+  // kernel whose result depends on it has a data race (a missing barrier between an LDS write and another work-item's read)
+  std::vector<unsigned> order(n);
+  for (unsigned t = 0; t < n; t++) order[t] = g_schedule == 1 ? n - 1 - t : t;
+  unsigned long long rng = g_schedule_seed ^ ((unsigned long long)bx * 0x9E3779B97F4A7C15ull) ^ ((unsigned long long)by << 40) ^ bz;
   unsigned alive = n;
   unsigned idle_rounds = 0;
   b.events = 0;
   while (alive) {
     unsigned progressed = 0;
     const unsigned long ev0 = b.events;
-    for (unsigned t = 0; t < n; t++) {
+    if (g_schedule == 2) {  // a fresh order every round
+      for (unsigned i = n - 1; i > 0; i--) {
+        rng = rng * 6364136223846793005ull + 1442695040888963407ull;
+        std::swap(order[i], order[(unsigned)((rng >> 33) % (i + 1))]);
+      }
+    }
+    for (unsigned oi = 0; oi < n; oi++) {
+      const unsigned t = order[oi];
       Fiber& f = b.fibers[t];
       if (f.done) continue;
       b.cur = t;

@@ -1,41 +1,29 @@
-// TEST INFRASTRUCTURE: the RCCL names sdk_amd/csrc/comm.cpp uses, for the host emulation (see ../hip/hip_runtime.h).  One rank
-// only: a collective over one rank is a copy.  A communicator of more ranks is refused -- several ranks on one device go through
-// the library's loopback transport (sp_comm_create_custom), which needs no RCCL.
+// TEST INFRASTRUCTURE: the RCCL names sdk_amd/csrc/comm.cpp uses, for the host emulation (see ../hip/hip_runtime.h).
+//
+// Ranks are PROCESSES on this host; a communicator is a POSIX shared-memory segment named by the unique id: a process-shared
+// barrier and one staging slot per rank.  A collective = every rank copies its send buffer into its slot, barrier, every rank
+// computes its result from all slots, barrier.  That is the SEMANTICS of ncclReduceScatter / ncclAllGather (element counts,
+// rank order, in-place forms), written independently of RCCL, so the call sequence of comm.cpp -- which so far has only met a
+// real RCCL at one rank -- is checked against it with 2 and 4 ranks (tests/test_emulated_library.py).  Nothing about xGMI,
+// rings or time.
 #pragma once
 #include <hip/hip_runtime.h>
 
-typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclInvalidArgument = 4 } ncclResult_t;
+typedef enum { ncclSuccess = 0, ncclUnhandledCudaError = 1, ncclSystemError = 2, ncclInvalidArgument = 4 } ncclResult_t;
 typedef enum { ncclUint32 = 3, ncclUint64 = 5 } ncclDataType_t;
 typedef enum { ncclSum = 0 } ncclRedOp_t;
 #define NCCL_UNIQUE_ID_BYTES 128
 struct ncclUniqueId {
-  char internal[128];
+  char internal[NCCL_UNIQUE_ID_BYTES];
 };
-struct emu_nccl_comm {
-  int nranks;
-};
+struct emu_nccl_comm;
 typedef emu_nccl_comm* ncclComm_t;
 
-inline const char* ncclGetErrorString(ncclResult_t r) { return r == ncclSuccess ? "no error" : "emulated RCCL: one rank only"; }
-inline ncclResult_t ncclGetUniqueId(ncclUniqueId* id) {
-  std::memset(id->internal, 0x5a, sizeof(id->internal));
-  return ncclSuccess;
-}
-inline ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId, int rank) {
-  if (nranks != 1 || rank != 0) return ncclInvalidArgument;
-  *c = new emu_nccl_comm{1};
-  return ncclSuccess;
-}
-inline ncclResult_t ncclCommDestroy(ncclComm_t c) {
-  delete c;
-  return ncclSuccess;
-}
-inline size_t emu_nccl_size(ncclDataType_t t) { return t == ncclUint64 ? 8 : 4; }
-inline ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t, ncclComm_t, hipStream_t) {
-  if (send != recv) std::memmove(recv, send, recvcount * emu_nccl_size(t));
-  return ncclSuccess;
-}
-inline ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t t, ncclComm_t, hipStream_t) {
-  if (send != recv) std::memmove(recv, send, sendcount * emu_nccl_size(t));
-  return ncclSuccess;
-}
+const char* ncclGetErrorString(ncclResult_t r);
+ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
+ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId id, int rank);
+ncclResult_t ncclCommDestroy(ncclComm_t c);
+// every rank sends nranks * recvcount elements; rank r receives the element-wise sum of all ranks' block r
+ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t op, ncclComm_t c, hipStream_t s);
+// every rank sends sendcount elements; every rank receives nranks * sendcount, rank k's block at k * sendcount
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t t, ncclComm_t c, hipStream_t s);
