@@ -245,7 +245,9 @@ class Comm:
 
     def __del__(self):
         try:
-            self.free()
+            from .spiral import _finalizing
+            if not _finalizing():
+                self.free()
         except Exception:
             pass
 

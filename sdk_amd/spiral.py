@@ -81,6 +81,13 @@ def lib():
     return _LIB
 
 
+def _finalizing(_is=__import__("sys").is_finalizing):
+    """Interpreter shutdown destroys objects in no particular order (a Params before the QueryRun that returns a workspace
+    to it): handles are left to the process exit then instead of being freed in the wrong order.  (Bound as a default
+    argument: module globals are already gone when the last destructors run.)"""
+    return _is()
+
+
 def _err():
     return lib().sp_last_error().decode(errors="replace")
 
@@ -126,7 +133,7 @@ class Params:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and not _finalizing():
                 lib().sp_params_free(_vp(self.h))
                 self.h = None
         except Exception:
@@ -338,7 +345,7 @@ class PublicParameters:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and not _finalizing():
                 lib().sp_pp_free(_vp(self.h))
                 self.h = None
         except Exception:
@@ -382,7 +389,7 @@ class Database:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and not _finalizing():
                 lib().sp_db_free(_vp(self.h))
                 self.h = None
         except Exception:
@@ -477,7 +484,11 @@ class QueryRun:
             raise SpiralError(_err())
 
     def __del__(self):
-        self.free()
+        try:
+            if not _finalizing():
+                self.free()
+        except Exception:
+            pass
 
     def free(self):
         try:
@@ -731,7 +742,7 @@ class Server:
 
     def __del__(self):
         try:
-            if getattr(self, "h", None):
+            if getattr(self, "h", None) and not _finalizing():
                 lib().sp_server_free(_vp(self.h))
                 self.h = None
         except Exception:
