@@ -69,6 +69,9 @@ int sp_set_device(int device);
  * expansion.  Single or double quotes are accepted (the reference's presets use single quotes and
  * `.replace("'", "\"")`, util.rs:104-120). */
 sp_params_t* sp_params_from_json(const char* json);
+/* The params handle owns the device tables and the pool of workspaces every other handle made from it borrows (spiral-rs:
+ * `&'a Params` in PublicParameters, Query, the database slice): free those first -- sp_query_t, sp_pp_t, sp_db_t, sp_server_t,
+ * a reserved sp_comm_t -- then the params. */
 void sp_params_free(sp_params_t*);
 /* Field / derived-size accessor: poly_len, crt_count, modulus, moduli0, moduli1, n, pt_modulus,
  * q2_bits, t_conv, t_exp_left, t_exp_right, t_gsw, expand_queries, db_dim_1, db_dim_2, instances,
