@@ -16,7 +16,7 @@ BUILD = os.environ.get("SPIRAL_EMU_BUILD") or os.path.join(HERE, "_build")   # (
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 PRODUCT = ["params.cpp", "ntt.hip", "fold.hip", "elementwise.hip", "sweep.hip", "db.hip", "sparse.hip", "server.cpp", "capi.cpp",
            "comm.cpp", "endpoint.cpp"]
-OWN = ["emu_runtime.cpp", "emu_library.cpp", "emu_rccl.cpp"]
+OWN = ["emu_runtime.cpp", "emu_streams.cpp", "emu_library.cpp", "emu_rccl.cpp"]
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
 

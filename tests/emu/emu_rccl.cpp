@@ -128,9 +128,17 @@ static ncclResult_t collective(ncclComm_t c, const void* send, size_t send_bytes
   return bad ? ncclInvalidArgument : ncclSuccess;
 }
 
-ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t, ncclComm_t c, hipStream_t) {
+// (a collective is an operation of its stream, like a kernel: it runs after what was enqueued before it there.  A failure
+// inside a deferred collective cannot be returned to the caller any more: it is thrown where the host waits.)
+static void deferred(hipStream_t s, std::function<ncclResult_t()> f) {
+  emu_enqueue(s, [f] {
+    if (f() != ncclSuccess) throw std::runtime_error("emulated RCCL: collective failed (message larger than the staging slot?)");
+  });
+}
+
+ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, ncclDataType_t t, ncclRedOp_t, ncclComm_t c, hipStream_t st) {
   const size_t es = elem(t);
-  return collective(c, send, recvcount * es * (size_t)c->nranks, [&] {
+  deferred(st, [=]() -> ncclResult_t { return collective(c, send, recvcount * es * (size_t)c->nranks, [&] {
     if (t == ncclUint64) {
       auto* out = (uint64_t*)recv;
       for (size_t i = 0; i < recvcount; i++) {
@@ -146,12 +154,14 @@ ncclResult_t ncclReduceScatter(const void* send, void* recv, size_t recvcount, n
         out[i] = s;
       }
     }
-  });
+  }); });
+  return ncclSuccess;
 }
 
-ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t t, ncclComm_t c, hipStream_t) {
+ncclResult_t ncclAllGather(const void* send, void* recv, size_t sendcount, ncclDataType_t t, ncclComm_t c, hipStream_t st) {
   const size_t nb = sendcount * elem(t);
-  return collective(c, send, nb, [&] {
+  deferred(st, [=]() -> ncclResult_t { return collective(c, send, nb, [&] {
     for (int k = 0; k < c->nranks; k++) std::memcpy((char*)recv + (size_t)k * nb, c->slot(k), nb);
-  });
+  }); });
+  return ncclSuccess;
 }

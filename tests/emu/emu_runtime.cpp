@@ -370,18 +370,13 @@ emu_i32x4 emu_mfma_i32_16x16x64_i8(emu_i32x4 a, emu_i32x4 bb, emu_i32x4 c) {
   return d;
 }
 
-hipError_t emu_malloc(void** p, size_t bytes) {
-  void* q = nullptr;
-  // + 16 bytes: the host compiler loads a three-dword vector (global_load_dwordx3 on the GPU: 12 bytes) as 16 bytes, so the
-  // last lane of the last PACKED unit of a buffer touches one dword past its end
-  if (posix_memalign(&q, 256, bytes + 16) != 0) return hipErrorOutOfMemory;
-  *p = q;
-  return hipSuccess;
-}
-
-void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item) {
-  if (dynamic_lds_bytes > g_dynamic_lds_limit) throw std::runtime_error("emulated launch: more dynamic LDS than a CU has");
-  if ((unsigned long)grid.x * grid.y * grid.z == 0) throw std::runtime_error("emulated launch: empty grid");
+void emu_launch(dim3 grid, dim3 block, const std::function<void()>& work_item) {
   std::lock_guard<std::mutex> g(g_launch_mutex);
   pool().launch(grid, block, work_item);
+}
+void emu_check_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes) {
+  if (dynamic_lds_bytes > g_dynamic_lds_limit) throw std::runtime_error("emulated launch: more dynamic LDS than a CU has");
+  if ((unsigned long)grid.x * grid.y * grid.z == 0) throw std::runtime_error("emulated launch: empty grid");
+  const unsigned long n = (unsigned long)block.x * block.y * block.z;
+  if (n == 0 || n > MAX_THREADS) throw std::runtime_error("emulated launch: workgroup size out of range");
 }

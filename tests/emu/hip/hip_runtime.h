@@ -182,13 +182,21 @@ inline uint32_t emu_ubfe(uint32_t src, unsigned off, unsigned width) {
 emu_i32x4 emu_mfma_i32_16x16x64_i8(emu_i32x4 a, emu_i32x4 b, emu_i32x4 c);
 #define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu_mfma_i32_16x16x64_i8((a), (b), (c))
 
-// ---- host API: everything completes before the call returns -------------------------------------------------------------
+// ---- host API ----------------------------------------------------------------------------------------------------------
+// "Device memory" is host memory.  Streams are queues of operations (emu_streams.cpp).  SPIRAL_EMU_STREAMS selects when they run:
+//   eager (default)  every operation runs when it is enqueued -- the strongest ordering there is;
+//   lazy             nothing runs until the host waits for something; the executor then prefers the stream whose next
+//                    operation was enqueued LAST among those that may run (events honoured) -- the order a correct program
+//                    must survive and a program with a missing event dependency does not;
+//   random:SEED      as lazy, choosing at random;
+//   starve:K         as lazy, but the K-th stream created (0 = the NULL stream) only runs when no other stream can: everything
+//                    the other streams do without waiting for it happens before it.  A missing dependency of stream B on
+//                    stream A shows under starve:A, every time.
 typedef int hipError_t;
 enum : int { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNotReady = 600 };
-typedef struct emu_stream* hipStream_t;
-struct emu_event {
-  std::chrono::steady_clock::time_point t;
-};
+struct emu_stream;
+typedef emu_stream* hipStream_t;
+struct emu_event;
 typedef emu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum : unsigned { hipStreamDefault = 0, hipStreamNonBlocking = 1, hipEventDefault = 0, hipEventDisableTiming = 2, hipHostMallocDefault = 0,
@@ -208,49 +216,46 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
-inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = (size_t)1 << 35; *tot = (size_t)1 << 36; return hipSuccess; }
-hipError_t emu_malloc(void** p, size_t bytes);
-template <typename T>
-inline hipError_t hipMalloc(T** p, size_t bytes) { return emu_malloc((void**)p, bytes); }
-template <typename T>
-inline hipError_t hipExtMallocWithFlags(T** p, size_t bytes, unsigned) { return emu_malloc((void**)p, bytes); }
-template <typename T>
-inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { return emu_malloc((void**)p, bytes); }
-inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
-inline hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
-inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { if (n) std::memmove(d, s, n); return hipSuccess; }
-inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t = nullptr) { return hipMemcpy(d, s, n, k); }
-inline hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind, hipStream_t = nullptr) {
-  for (size_t r = 0; r < height; r++) std::memmove((char*)d + r * dpitch, (const char*)s + r * spitch, width);
-  return hipSuccess;
-}
-inline hipError_t hipMemset(void* d, int v, size_t n) { if (n) std::memset(d, v, n); return hipSuccess; }
-inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t = nullptr) { return hipMemset(d, v, n); }
-inline hipError_t hipStreamCreate(hipStream_t* s) { *s = (hipStream_t) new char; return hipSuccess; }
-inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { return hipStreamCreate(s); }
-inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { return hipStreamCreate(s); }
-inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreate(s); }
-inline hipError_t hipStreamDestroy(hipStream_t s) { delete (char*)s; return hipSuccess; }
-inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
-inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned = 0) { return hipSuccess; }
-inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new emu_event{std::chrono::steady_clock::now()}; return hipSuccess; }
-inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
-inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
-inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
-inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
-  *ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();
-  return hipSuccess;
-}
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host);
+template <typename T>
+inline hipError_t hipMalloc(T** p, size_t bytes) { return emu_malloc((void**)p, bytes, false); }
+template <typename T>
+inline hipError_t hipExtMallocWithFlags(T** p, size_t bytes, unsigned) { return emu_malloc((void**)p, bytes, false); }
+template <typename T>
+inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned = 0) { return emu_malloc((void**)p, bytes, true); }
+hipError_t hipFree(void* p);      // waits for the device first, as the real one does
+hipError_t hipHostFree(void* p);
+hipError_t hipDeviceSynchronize();
+hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind k);  // ordered after the NULL stream only
+hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemcpy2DAsync(void* d, size_t dpitch, const void* s, size_t spitch, size_t width, size_t height, hipMemcpyKind k, hipStream_t st = nullptr);
+hipError_t hipMemset(void* d, int v, size_t n);
+hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t st = nullptr);
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
+inline hipError_t hipStreamCreate(hipStream_t* s) { return hipStreamCreateWithFlags(s, hipStreamDefault); }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned flags, int) { return hipStreamCreateWithFlags(s, flags); }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { return hipStreamCreateWithFlags(s, hipStreamNonBlocking); }
+hipError_t hipStreamDestroy(hipStream_t s);
+hipError_t hipStreamSynchronize(hipStream_t s);
+hipError_t hipStreamQuery(hipStream_t s);
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags = 0);
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);
+inline hipError_t hipEventCreate(hipEvent_t* e) { return hipEventCreateWithFlags(e, 0); }
+hipError_t hipEventDestroy(hipEvent_t e);
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);
+hipError_t hipEventSynchronize(hipEvent_t e);
+hipError_t hipEventQuery(hipEvent_t e);
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 
-// a launch: every workgroup runs to completion before this returns
-void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item);
+// an operation of the caller's own on a stream (the RCCL stand-in queues its collectives this way)
+void emu_enqueue(hipStream_t s, std::function<void()> op);
+// a launch is one operation of its stream; grid / block / LDS size are checked when it is enqueued (as hipLaunchKernelGGL
+// reports a bad configuration at once), every workgroup has run to completion when the operation ends
+void emu_enqueue_launch(hipStream_t s, dim3 grid, dim3 block, size_t dynamic_lds_bytes, std::function<void()> work_item);
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-  emu_launch(dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
+  emu_enqueue_launch((stream), dim3(grid), dim3(block), (size_t)(lds), [=]() { kernel(__VA_ARGS__); })
 
 // ---- keyword macros (last: nothing from the standard library is parsed after this point by way of this header) -----------
 // Inline assembly.  `asm volatile("" : "+v"(x))` (an optimisation barrier; the gfx950 constraints do not exist here) becomes an

@@ -41,7 +41,7 @@ def emu():
         pytest.skip("no host clang (the wave helpers use clang vector extensions)")
     os.makedirs(BUILD_DIR, exist_ok=True)
     so = os.path.join(BUILD_DIR, "libdevice_bodies_emu.so")
-    srcs = [os.path.join(EMU_DIR, "device_bodies_emu.cpp"), os.path.join(EMU_DIR, "emu_runtime.cpp"),
+    srcs = [os.path.join(EMU_DIR, "device_bodies_emu.cpp"), os.path.join(EMU_DIR, "emu_runtime.cpp"), os.path.join(EMU_DIR, "emu_streams.cpp"),
             os.path.join(ROOT, "sdk_amd", "csrc", "params.cpp")]
     deps = srcs + [os.path.join(EMU_DIR, "hip", "hip_runtime.h"), os.path.join(EMU_DIR, "emu_runtime.hpp")] + [
         os.path.join(ROOT, "sdk_amd", "csrc", f) for f in ("device_common.hpp", "wave_ntt.hpp", "bodies.hpp", "kernels.hpp",
