@@ -127,6 +127,35 @@ def test_row_sharded_query_over_process_ranks(emulated, tmp_path, world, name, s
     assert "sharded-ok" in outs[0]
 
 
+@pytest.mark.parametrize("mode", ["query", "sharded"])
+def test_c_program_on_the_emulated_device(emulated, tmp_path, oracle_mod, mode):
+    """tests/c_abi_smoke.c (plain C, no Python between the host and the library) linked against the emulated build: the same
+    run the -m gpu suite does on hardware (tests/test_c_abi_smoke.py), byte-compared with the oracle."""
+    import json
+    from conftest import FAST
+    cfg = dict(FAST, nu_2=7, db_item_size=256)
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(41)
+    idx = 4242 % o.num_items
+    q = cl.generate_query(idx, 42)
+    item, db = o.generate_random_db_and_get_item(idx)
+    files = {"params.json": json.dumps(cfg).encode(), "pp.bin": pp, "query.bin": q, "db.bin": db.tobytes(),
+             "expected.bin": o.process_query(pp, q, db)}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    exe = str(tmp_path / "c_abi_smoke_emu")
+    so_dir = os.path.dirname(emulated)
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", os.path.join(ROOT, "tests", "c_abi_smoke.c"),
+                           "-I", os.path.join(ROOT, "include"), "-L", so_dir, "-l:" + os.path.basename(emulated),
+                           "-Wl,-rpath," + so_dir, "-o", exe])
+    r = subprocess.run([exe, mode] + [str(tmp_path / f) for f in files], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    assert "== the oracle's" in r.stdout
+    if mode == "sharded":
+        assert "rccl_in_library" in r.stdout
+
+
 def test_bench_and_smoke_refuse_the_emulated_library(emulated):
     env = dict(os.environ, SPIRAL_HIP_LIB=emulated)
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True,
