@@ -160,13 +160,9 @@ void enqueue(hipStream_t st, std::function<void()> f) {
   o.run = std::move(f);
   s->q.push_back(std::move(o));
 }
-bool pinned(const void* p) {
-  auto it = g_pinned.upper_bound(p);
-  (void)it;
-  // blocks are looked up by start address only: the product copies to / from the START of its staging buffers or inside them;
-  // an interior pointer of a pinned block counts as pageable, which only makes the copy MORE synchronous
-  return g_pinned.count(p) != 0;
-}
+// blocks are looked up by START address: the product copies to / from the start of its pinned staging buffers; an interior
+// pointer of a pinned block counts as pageable, which only makes the copy MORE synchronous than the GPU's
+bool pinned(const void* p) { return g_pinned.count(p) != 0; }
 }  // namespace
 
 hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host) {
