@@ -11,7 +11,7 @@ python tests/emu/build_emulated_library.py > /dev/null || exit 1
 python tests/emu/build_emulated_library.py --asan > /dev/null || exit 1
 L=$R/tests/emu/_build/libspiral_emu.so
 LA=$R/tests/emu/_build/libspiral_emu_asan.so
-RT=/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so
+RT=$(/opt/rocm/lib/llvm/bin/clang++ -print-file-name=libclang_rt.asan-x86_64.so)
 # needs a GPU whatever the library: torch views of device pointers, bench.py, a real RCCL
 SKIP="not c2_full_size and not bench_modes and not distributed_fold_single_gpu and not column_sharded_single and not rccl_world1 and not row_sharded_partials and not sharded_c_abi_loopback and not sharded_pipelined_list and not process_query_c1"
 [ -n "$quick" ] && SKIP="$SKIP and not 256x256 and not 512x128 and not 128x128 and not 32x256"

@@ -20,7 +20,17 @@ OWN = ["emu_runtime.cpp", "emu_streams.cpp", "emu_library.cpp", "emu_rccl.cpp"]
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]
 
 
-ASAN_RUNTIME = "/opt/rocm/lib/llvm/lib/clang/22/lib/linux/libclang_rt.asan-x86_64.so"
+
+
+def _asan_runtime():
+    try:
+        out = subprocess.run([CLANG, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True).stdout.strip()
+        return out if os.path.isabs(out) and os.path.exists(out) else ""
+    except OSError:
+        return ""
+
+
+ASAN_RUNTIME = _asan_runtime()   # "" when this compiler has no shared AddressSanitizer runtime
 
 
 def library_path(asan=False):

@@ -68,9 +68,9 @@ def test_parity_subset_on_the_emulated_device(emulated):
 
 
 def test_kernels_stay_inside_their_buffers(emulated):
-    so = emu_build.build(asan=True)
-    if not os.path.exists(emu_build.ASAN_RUNTIME):
+    if not emu_build.ASAN_RUNTIME:
         pytest.skip("no AddressSanitizer runtime")
+    so = emu_build.build(asan=True)
     log = os.path.join(emu_build.BUILD, "asan_report")
     for f in os.listdir(emu_build.BUILD):
         if f.startswith("asan_report"):
