@@ -44,8 +44,17 @@ extern "C" void __sanitizer_finish_switch_fiber(void* fake_stack_save, const voi
 #endif
 #endif
 
+// the arrays behind `extern __shared__` (emu_library.cpp registers one getter per name: the address is per host thread)
+typedef unsigned char* (*emu_lds_getter)();
+static emu_lds_getter g_lds_arrays[8];
+static int g_n_lds_arrays = 0;
+void emu_register_dynamic_lds(emu_lds_getter f) {
+  if (g_n_lds_arrays < 8) g_lds_arrays[g_n_lds_arrays++] = f;
+}
+
 namespace {
 constexpr size_t STACK_BYTES = 256 * 1024;
+constexpr size_t LDS_CANARY = 64;
 constexpr unsigned MAX_THREADS = 1024;
 
 struct Fiber {
@@ -131,8 +140,10 @@ extern "C" void emu_fiber_entry() {
   f->done = true;
   for (;;) yield();  // never scheduled again
 }
-void run_block(Block& b, dim3 grid, dim3 block, unsigned bx, unsigned by, unsigned bz, const std::function<void()>& body) {
+void run_block(Block& b, dim3 grid, dim3 block, size_t lds_bytes, unsigned bx, unsigned by, unsigned bz, const std::function<void()>& body) {
   const unsigned n = block.x * block.y * block.z;
+  // a kernel may use `lds_bytes` of its dynamic LDS array: the bytes right behind them must come back untouched
+  for (int i = 0; i < g_n_lds_arrays; i++) std::memset(g_lds_arrays[i]() + lds_bytes, 0xC7, LDS_CANARY);
   if (n == 0 || n > MAX_THREADS) throw std::invalid_argument("emulated workgroup size out of range");
   if (b.stacks_for < n) {
     if (b.stacks) munmap(b.stacks, b.stacks_for * STACK_BYTES);
@@ -218,6 +229,15 @@ void run_block(Block& b, dim3 grid, dim3 block, unsigned bx, unsigned by, unsign
   }
   tl_fiber = nullptr;
   tl_block = nullptr;
+  if (b.error.empty())
+    for (int i = 0; i < g_n_lds_arrays; i++) {
+      const unsigned char* c = g_lds_arrays[i]() + lds_bytes;
+      for (size_t k = 0; k < LDS_CANARY; k++)
+        if (c[k] != 0xC7) {
+          b.error = "a workgroup wrote past the dynamic LDS size of its launch (" + std::to_string(lds_bytes) + " bytes requested)";
+          break;
+        }
+    }
   if (!b.error.empty()) throw std::runtime_error(b.error);
 }
 
@@ -230,6 +250,7 @@ struct Pool {
   // the launch in flight
   unsigned long epoch = 0;
   dim3 grid, block;
+  size_t lds_bytes = 0;
   const std::function<void()>* body = nullptr;
   std::atomic<unsigned long> next{0};
   unsigned long total = 0;
@@ -259,6 +280,7 @@ struct Pool {
       if (stop) return;
       seen = epoch;
       const dim3 g = grid, b = block;
+      const size_t lds = lds_bytes;
       const std::function<void()>* fn = body;
       lk.unlock();
       std::string err;
@@ -267,7 +289,7 @@ struct Pool {
         if (i >= total) break;
         const unsigned bx = (unsigned)(i % g.x), by = (unsigned)((i / g.x) % g.y), bz = (unsigned)(i / ((unsigned long)g.x * g.y));
         try {
-          run_block(blk, g, b, bx, by, bz, *fn);
+          run_block(blk, g, b, lds, bx, by, bz, *fn);
         } catch (const std::exception& e) {
           if (err.empty()) err = e.what();
           next.store(total);  // abandon the rest of the launch
@@ -278,10 +300,11 @@ struct Pool {
       if (--busy == 0) cv_done.notify_all();
     }
   }
-  void launch(dim3 g, dim3 b, const std::function<void()>& fn) {
+  void launch(dim3 g, dim3 b, size_t lds, const std::function<void()>& fn) {
     std::unique_lock<std::mutex> lk(m);
     grid = g;
     block = b;
+    lds_bytes = lds;
     body = &fn;
     total = (unsigned long)g.x * g.y * g.z;
     next.store(0);
@@ -370,9 +393,9 @@ emu_i32x4 emu_mfma_i32_16x16x64_i8(emu_i32x4 a, emu_i32x4 bb, emu_i32x4 c) {
   return d;
 }
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& work_item) {
+void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item) {
   std::lock_guard<std::mutex> g(g_launch_mutex);
-  pool().launch(grid, block, work_item);
+  pool().launch(grid, block, dynamic_lds_bytes, work_item);
 }
 void emu_check_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes) {
   if (dynamic_lds_bytes > g_dynamic_lds_limit) throw std::runtime_error("emulated launch: more dynamic LDS than a CU has");

@@ -10,7 +10,7 @@
 
 #include <set>
 
-void emu_launch(dim3 grid, dim3 block, const std::function<void()>& work_item);  // emu_runtime.cpp
+void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item);  // emu_runtime.cpp
 void emu_check_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes);
 
 struct emu_event {
@@ -341,5 +341,5 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) {
 void emu_enqueue(hipStream_t s, std::function<void()> op) { enqueue(s, std::move(op)); }
 void emu_enqueue_launch(hipStream_t s, dim3 grid, dim3 block, size_t dynamic_lds_bytes, std::function<void()> work_item) {
   emu_check_launch(grid, block, dynamic_lds_bytes);
-  enqueue(s, [grid, block, work_item] { emu_launch(grid, block, work_item); });
+  enqueue(s, [grid, block, dynamic_lds_bytes, work_item] { emu_launch(grid, block, dynamic_lds_bytes, work_item); });
 }
