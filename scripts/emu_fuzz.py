@@ -61,6 +61,7 @@ def main():
         if o.num_items < 1 or cfg["db_item_size"] * 8 > o.get("instances") * o.get("n") ** 2 * 2048 * int(np.log2(cfg["p"])):
             continue
         t0 = time.time()
+        print("     try  %s" % json.dumps(cfg), flush=True)   # (a parameter set the oracle aborts on is the last line then)
         cl = oracle.Client(o)
         ks, qs = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
         idx = int(rng.integers(0, o.num_items))
