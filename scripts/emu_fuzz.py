@@ -61,6 +61,10 @@ def main():
         if o.num_items < 1 or cfg["db_item_size"] * 8 > o.get("instances") * o.get("n") ** 2 * 2048 * int(np.log2(cfg["p"])):
             continue
         t0 = time.time()
+        try:
+            p = sp.Params(cfg)        # the library's own validation first: what it rejects the reference cannot run either
+        except sp.SpiralError:
+            continue
         print("     try  %s" % json.dumps(cfg), flush=True)   # (a parameter set the oracle aborts on is the last line then)
         cl = oracle.Client(o)
         ks, qs = int(rng.integers(1, 1 << 30)), int(rng.integers(1, 1 << 30))
@@ -73,7 +77,6 @@ def main():
         except Exception as e:
             print("oracle rejects", json.dumps(cfg), repr(e)[:80], flush=True)
             continue
-        p = sp.Params(cfg)
         gpp = sp.PublicParameters.deserialize(p, pp)
         gdb = sp.Database(p).load(db)
         sp.paths_taken()

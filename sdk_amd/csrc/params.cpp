@@ -246,6 +246,12 @@ Params Params::from_json(const std::string& json) {  // util.rs:224-263
   // (server.rs:566-571); the reference panics (index out of bounds) when they do not fit
   if (p.expand_queries && p.db_dim_2 > 0 && 2 * std::max(p.dim0(), p.t_gsw * p.db_dim_2) > ((size_t)1 << p.g()))
     throw std::runtime_error("params: 2*max(2^nu_1, t_gsw*nu_2) exceeds 2^g expanded ciphertexts (server.rs:566-571)");
+  // coefficient_expansion prunes the odd subtree only when stop_round > 0 (server.rs:40-47).  With stop_round = 0, i.e.
+  // t_gsw * nu_2 = 1, every round r >= 1 takes v_w_right[r] -- of which the public parameters hold stop_round + 1 = 1
+  // (client.rs:146-152, params.rs:146-167): the reference indexes out of bounds and panics; so would the expansion plan here
+  // (found by scripts/emu_fuzz.py: the multiply-accumulate of round 1 read past the public parameters)
+  if (p.expand_queries && p.db_dim_2 > 0 && p.stop_round() == 0 && p.g() > 1)
+    throw std::runtime_error("params: t_gsw * nu_2 = 1 leaves one right expansion matrix for g > 1 rounds (server.rs:40-47, 60-73)");
   return p;
 }
 

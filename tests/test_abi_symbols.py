@@ -94,6 +94,7 @@ def test_params_validation_rejects_what_the_reference_cannot_run():
     ok = dict(FAST)
     sp.Params(ok)
     for bad in (dict(FAST, nu_1=3, nu_2=7, t_gsw=8),      # 2*56 > 2^g = 64
+                dict(FAST, nu_2=1, t_gsw=1),              # stop_round = 0: one right expansion matrix, g - 1 rounds that index further
                 dict(FAST, version=2),
                 dict(FAST, version=1, n=3),
                 dict(FAST, nu_1=0, nu_2=0, t_gsw=8)):
@@ -101,5 +102,5 @@ def test_params_validation_rejects_what_the_reference_cannot_run():
             sp.Params(bad)
         except sp.SpiralError:
             continue
-        # nu_1 = 0 is legal if the reference accepts it; only the first three must raise
+        # nu_1 = 0 is legal if the reference accepts it; only the first four must raise
         assert bad.get("nu_1") == 0, bad
