@@ -90,6 +90,21 @@ def main():
             outs = sp.process_query_batch(p, gpp, lst, gdb)
             ok = all(x == want for x in outs)
             extra = " list%d" % B
+        if ok and rng.random() < 0.25 and not cfg.get("direct_upload"):
+            # lib/server's sparse bucket (SparseDb + update_item_raw; pruned expansion, present-items-only multiply, fold
+            # shortcuts) against oracle/sparse_server.cpp, a random fraction of the items present
+            sdb = oracle.SparseDb(o)
+            gsp = sp.Database.sparse(p)
+            frac = float(rng.choice([0.02, 0.2, 0.6, 1.0]))
+            present = [int(i) for i in rng.choice(o.num_items, max(1, int(frac * o.num_items)), replace=False)]
+            for i in present[:64]:
+                data = rng.integers(0, 256, cfg["db_item_size"], dtype=np.uint8).tobytes()
+                sdb.update_item_raw(i, data)
+                gsp.update_item(i, data)
+            for target in (present[0], int(rng.integers(0, o.num_items))):
+                qq = cl.generate_query(target, qs + 1)
+                ok = ok and sp.process_query(p, gpp, qq, gsp) == sdb.process_query(pp, qq)
+            extra += " sparse%d" % min(64, len(present))
         n += 1
         print("%4d %s %.1fs %s%s  %s" % (n, "ok  " if ok else "FAIL", time.time() - t0, json.dumps(cfg), extra, ",".join(paths)), flush=True)
         if not ok:
