@@ -26,7 +26,7 @@ def valid(c):
 
 def draw(rng):
     while True:
-        c = dict(n=2, nu_1=int(rng.integers(2, 8)), nu_2=int(rng.integers(0, 9)), p=int(rng.choice([4, 16, 64, 256])),
+        c = dict(n=2, nu_1=int(rng.integers(2, 8)), nu_2=int(rng.integers(0, 9)), p=int(rng.choice([4, 16, 64, 256, 256, 256])),
                  q2_bits=int(rng.integers(14, 29)), t_gsw=int(rng.choice([1, 2, 3, 4, 5, 7, 8, 9, 10, 14, 28])),
                  t_conv=int(rng.choice([1, 2, 3, 4, 5, 7, 14, 28])), t_exp_left=int(rng.choice([2, 3, 4, 5, 6, 7, 8, 14, 16, 28])),
                  t_exp_right=int(rng.choice([2, 4, 5, 8, 9, 14, 19, 28, 56])), instances=int(rng.choice([1, 1, 1, 2, 3])),
@@ -90,7 +90,7 @@ def main():
             outs = sp.process_query_batch(p, gpp, lst, gdb)
             ok = all(x == want for x in outs)
             extra = " list%d" % B
-        if ok and rng.random() < 0.25 and not cfg.get("direct_upload"):
+        if ok and rng.random() < 0.3 and not cfg.get("direct_upload") and cfg["p"] == 256:   # (lib/server stores bytes: p = 256)
             # lib/server's sparse bucket (SparseDb + update_item_raw; pruned expansion, present-items-only multiply, fold
             # shortcuts) against oracle/sparse_server.cpp, a random fraction of the items present
             sdb = oracle.SparseDb(o)

@@ -234,6 +234,9 @@ Params Params::from_json(const std::string& json) {  // util.rs:224-263
   }
   p.version = opt("version", 0);
   if (p.n == 0 || p.n > 8) throw std::runtime_error("params: n out of range");
+  // Q2_VALUES ends at index 36 (params.rs:8-46): the reference indexes out of bounds beyond (smaller values were raised to
+  // MIN_Q2_BITS above, as util.rs:230 does)
+  if (p.q2_bits > 36) throw std::runtime_error("params: q2_bits above 36 (params.rs:8-46)");
   if (p.pt_modulus < 2 || (p.pt_modulus & (p.pt_modulus - 1))) throw std::runtime_error("params: p must be a power of two");
   if (p.t_gsw == 0 || p.t_conv == 0 || p.t_exp_left == 0 || p.t_exp_right == 0) throw std::runtime_error("params: zero gadget dimension");
   if (p.db_dim_1 > 20 || p.db_dim_2 > 20) throw std::runtime_error("params: db dimensions out of range");

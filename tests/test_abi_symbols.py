@@ -93,14 +93,16 @@ def test_params_validation_rejects_what_the_reference_cannot_run():
     from conftest import FAST
     ok = dict(FAST)
     sp.Params(ok)
+    assert sp.Params(dict(FAST, q2_bits=3)).get("q2_bits") == 14      # raised to MIN_Q2_BITS as util.rs:230 does
     for bad in (dict(FAST, nu_1=3, nu_2=7, t_gsw=8),      # 2*56 > 2^g = 64
                 dict(FAST, nu_2=1, t_gsw=1),              # stop_round = 0: one right expansion matrix, g - 1 rounds that index further
                 dict(FAST, version=2),
+                dict(FAST, q2_bits=37),                   # past Q2_VALUES (params.rs:8-46)
                 dict(FAST, version=1, n=3),
                 dict(FAST, nu_1=0, nu_2=0, t_gsw=8)):
         try:
             sp.Params(bad)
         except sp.SpiralError:
             continue
-        # nu_1 = 0 is legal if the reference accepts it; only the first four must raise
+        # nu_1 = 0 is legal if the reference accepts it; only the first five must raise
         assert bad.get("nu_1") == 0, bad
