@@ -156,6 +156,36 @@ def test_c_program_on_the_emulated_device(emulated, tmp_path, oracle_mod, mode):
         assert "rccl_in_library" in r.stdout
 
 
+def test_host_threads_through_the_c_abi(emulated, tmp_path, oracle_mod):
+    """Four host threads answer queries at once on shared params / public parameters / database handles while one of them also
+    answers a list (tests/emu/host_threads_driver.cpp, no Python in the process) -- what a worker pool does to the library.
+    AddressSanitizer build where there is one: a race on the workspace pool or the device state shows as a heap error there."""
+    import json
+    from conftest import FAST
+    asan = bool(emu_build.ASAN_RUNTIME)
+    lib = emu_build.build(asan=True) if asan else emulated
+    cfg = dict(FAST, nu_2=7, db_item_size=256)
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(51)
+    idx = 4141 % o.num_items
+    q = cl.generate_query(idx, 52)
+    item, db = o.generate_random_db_and_get_item(idx)
+    files = {"params.json": json.dumps(cfg).encode(), "pp.bin": pp, "query.bin": q, "db.bin": db.tobytes(),
+             "expected.bin": o.process_query(pp, q, db)}
+    for name, data in files.items():
+        (tmp_path / name).write_bytes(data)
+    exe = str(tmp_path / "host_threads_driver")
+    so_dir = os.path.dirname(lib)
+    subprocess.check_call([emu_build.CLANG, "-std=c++17", "-O1", "-pthread"] + (["-fsanitize=address", "-shared-libasan"] if asan else []) +
+                          ["-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "emu", "host_threads_driver.cpp"),
+                           "-L", so_dir, "-l:" + os.path.basename(lib), "-Wl,-rpath," + so_dir,
+                           "-Wl,-rpath," + os.path.dirname(emu_build.ASAN_RUNTIME or so_dir), "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:detect_stack_use_after_return=0:halt_on_error=1", SPIRAL_EMU_STREAMS="random:3")
+    r = subprocess.run([exe] + [str(tmp_path / f) for f in files] + ["4", "2"], capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0 and "all equal to the oracle's" in r.stdout, (r.stdout[-1500:], r.stderr[-4000:])
+
+
 def test_bench_and_smoke_refuse_the_emulated_library(emulated):
     env = dict(os.environ, SPIRAL_HIP_LIB=emulated)
     r = subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.smoke()"], cwd=ROOT, env=env, capture_output=True,
