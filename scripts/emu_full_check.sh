@@ -22,7 +22,7 @@ LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0:detect_stack_use_after_return=0:halt_
   -m gpu -q --timeout=1800 -p no:cacheprovider -k "$SKIP" > /tmp/emu_full_check_parity.log 2>&1 || rc=1
 tail -2 /tmp/emu_full_check_parity.log
 ls /tmp/emu_full_check_asan.* 2>/dev/null && rc=1
-STREAMS="(test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_0)) or (test_ring_sweep_and_batched_tails_parity and (5-10-4-8-1-256 or 5-10-4-8-1-0)) or (test_expansion_variants_response_parity and (split-0 or launches-1)) or test_overlapped_fold or (test_process_query_batch and (narrow-3 or narrow-4 or packed)) or test_query_list_in_flight or (test_process_query_batch_matrix_core_sweep and 64x128)"
+STREAMS="(test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_0)) or (test_ring_sweep_and_batched_tails_parity and (5-10-4-8-1-256 or 5-10-4-8-1-0)) or (test_expansion_variants_response_parity and (0-split or 1-launches)) or test_overlapped_fold or (test_process_query_batch and (narrow-3 or narrow-4 or packed)) or test_query_list_in_flight or (test_process_query_batch_matrix_core_sweep and 64x128)"
 n=18; [ -n "$quick" ] && n=6
 for k in $(seq 1 $n) r1 r2 r3; do
   pol=starve:$k; case $k in r*) pol=random:${k#r};; esac

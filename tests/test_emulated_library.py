@@ -37,7 +37,7 @@ RACE_SUBSET = ("test_ntt_forward_inverse or test_to_ntt_from_ntt or test_fold_pa
                "or (test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_1)) "
                "or (test_wave_fold_kernel_gadget_widths and (0 or 13))")
 STREAM_SUBSET = ("(test_process_query_bytes_and_decode and fast56) or (test_ring_sweep_and_batched_tails_parity and 5-10-4-8-1-256) "
-                 "or (test_expansion_variants_response_parity and split-0) or (test_process_query_batch and narrow-3)")
+                 "or (test_expansion_variants_response_parity and 0-split) or (test_process_query_batch and narrow-3)")
 ASAN_SUBSET = ("(test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_0)) or test_fold_pack_encode or test_multiply "
                "or (test_wave_fold_kernel_gadget_widths and (0 or 4))")
 
