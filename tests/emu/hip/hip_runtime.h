@@ -176,9 +176,11 @@ inline uint32_t emu_ubfe(uint32_t src, unsigned off, unsigned width) {
 }
 #define __builtin_amdgcn_sbfe(src, off, width) emu_sbfe((src), (off), (width))
 #define __builtin_amdgcn_ubfe(src, off, width) emu_ubfe((src), (off), (width))
-// v_mfma_i32_16x16x64_i8 (one wave): D[16][16] = A[16][64] * B[64][16] + C, int8 operands, int32 sums.  Operand layout of the
-// instruction: lane l holds, of A, row l % 16, the 16 values k = 16 (l / 16) .. + 15 (four dwords, byte b of dword w = k offset
-// 4 w + b); of B, column l % 16, the same 16 values of k; of C / D, column l % 16, rows 4 (l / 16) .. + 3.
+// v_mfma_i32_16x16x64_i8 (one wave): D[16][16] = A[16][64] * B[64][16] + C, int8 operands, int32 sums.  What the emulation relies
+// on: lane l holds 16 bytes of row l % 16 of A and 16 bytes of column l % 16 of B, both for the SAME 16 values of k (the group
+// l / 16 selects which); byte t of a lane of A meets byte t of the lane of B in the same group.  Which k a byte stands for inside
+// its group does not change a sum over k.  Of C / D lane l holds column l % 16, rows 4 (l / 16) .. + 3.  (The kernels' own operand
+// packing was validated on the GPU against the oracle; the batched tests pass here with this statement of it.)
 emu_i32x4 emu_mfma_i32_16x16x64_i8(emu_i32x4 a, emu_i32x4 b, emu_i32x4 c);
 #define __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b, c, cbsz, abid, blgp) emu_mfma_i32_16x16x64_i8((a), (b), (c))
 
