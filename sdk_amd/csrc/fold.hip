@@ -421,7 +421,6 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
     // the 16-byte pieces made the kernel write 3.3x its algorithmic bytes, profiles/r04_final_pmc_per_kernel_unpipelined.md;
     // measured on one allocation: -1 % on the un-pipelined fold and on 8-query steps, profiles/r04_fold_park_ab_raw.txt)
     u32* park = reinterpret_cast<u32*>(out);
-    u32 rr[32];                                  // modulus-1 round: the row this wave transforms back
     const int irow = wv & 1, imod = wv < 2 ? 1 : 0;
     u32 r0[32], r1[32];
 #pragma unroll
@@ -467,13 +466,18 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
           *reinterpret_cast<u32x4w_t*>(park + wv * N + g * 256 + 4 * lt) = t4;
         }
       }
-    } else if (wv < 2) {
-#pragma unroll
-      for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
     }
     if (c == 1) {
       const ModConst mi = T.c.mod[imod];
-      if (wv >= 2) {
+      // the row this wave transforms back.  Declared HERE, where every path defines it: declared at the top of the modulus loop
+      // (as until round 4) it was undefined on the c == 0 path, the compiler carried 64 registers of zeros for it through the
+      // whole kernel and spilled them -- 316 bytes of scratch per lane, ~0.9 GB of scratch stores per C2 query, most of the
+      // kernel's measured 5x write amplification.  16 bytes now.
+      u32 rr[32];
+      if (wv < 2) {
+#pragma unroll
+        for (int k = 0; k < 32; k++) rr[k] = wv == 0 ? r0[k] : r1[k];
+      } else {
 #pragma unroll
         for (int g = 0; g < 8; g++) {
           const u32x4w_t t4 = *reinterpret_cast<const u32x4w_t*>(park + irow * N + g * 256 + 4 * lt);
