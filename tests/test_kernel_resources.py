@@ -25,7 +25,7 @@ LIMITS = {
                   "k_sweep_packed_persistE": (0, 256), "k_sweep_wideE": (0, 256),
                   # the batched passes on the matrix cores: the one-tile form is clean; the two-tile form (16 queries, one wave per
                   # SIMD, 256 VGPRs + 256 AGPRs) keeps 200 bytes of scratch outside its multiply loop -- recorded, to be looked at
-                  "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (200, 256)},
+                  "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (200, 512)},
 }
 
 
