@@ -118,7 +118,7 @@ __device__ __forceinline__ void ntt_inv_body(const DevTables& T, const InvDesc& 
       }
       v[k] = x;
     }
-    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    const u32* iw = inv_tables(T.tw, c);
     if (c == 1) __syncthreads();
     ntt_inv_block(v, tau, ldsA, ldsB, iw, iw + N, m.q, m.two_q);
 #pragma unroll

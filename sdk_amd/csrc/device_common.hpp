@@ -40,14 +40,25 @@ __device__ __forceinline__ void ct_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u3
   x = cx + qn;
   y = cx + q2 - qn;
 }
-// Gentleman-Sande butterfly with the 1/2 folded in (ntt.rs:236-249): x,y in [0,2q) -> [0,2q)
+// Gentleman-Sande butterfly, lazy: x, y in [0, 2q) -> [0, 2q).  The reference halves in every butterfly (ntt.rs:236-249:
+// (x + y) / 2 and (x - y) w / 2 with w / 2 in the table -- thirteen instructions); here w is the UNHALVED twiddle
+// (inv_tables) and the factor N^-1 = 2^-11 is applied once, in the last stage (gs_bfly_last): nine instructions.  The residues
+// mod q are the same in every position after the last stage, so the canonical results are too.
+// Shoup product w t - floor(t w' / 2^32) q: in [0, q + t q / 2^32), i.e. < 2q for any t < 2^32.
 __device__ __forceinline__ void gs_bfly(u32& x, u32& y, u32 w, u32 wp, u32 q, u32 q2) {
-  u32 tt = q2 - y + x;
-  u32 s = x + y;
-  u32 cx = s - (s >= q2 ? q2 : 0u);
-  u32 ht = __umulhi(tt, wp);
-  x = (cx + ((tt & 1u) ? q : 0u)) >> 1;
+  const u32 u = x + y;        // < 4q
+  const u32 tt = x - y + q2;  // in (0, 4q)
+  const u32 ur = u - q2;      // wraps above u when u < 2q
+  x = u < ur ? u : ur;
+  const u32 ht = __umulhi(tt, wp);
   y = w * tt - ht * q;
+}
+// last stage (distance N/2): x' = (x + y) N^-1, y' = (x - y) w N^-1; (ninv, ninvp) and (w, wp) = entries 0 and 1 of inv_tables
+__device__ __forceinline__ void gs_bfly_last(u32& x, u32& y, u32 ninv, u32 ninvp, u32 w, u32 wp, u32 q, u32 q2) {
+  const u32 u = x + y;
+  const u32 tt = x - y + q2;
+  x = ninv * u - __umulhi(u, ninvp) * q;
+  y = w * tt - __umulhi(tt, wp) * q;
 }
 
 // LDS index padding.  PAD_A keeps the {tau+256k}, {256b+o+32k} and {32b+o+4k} access patterns
@@ -107,8 +118,14 @@ __device__ __forceinline__ void inv_pass(u32 (&v)[8], int b, const u32* __restri
   if (DO_A) {
     int i = N / (8 * S) + b;
     u32 w = iw[i], wp = iwp[i];
+    if (S == 256) {  // distance N/2: the last stage (i = 1)
+      const u32 ninv = iw[0], ninvp = iwp[0];
 #pragma unroll
-    for (int k = 0; k < 4; k++) gs_bfly(v[k], v[k + 4], w, wp, q, q2);
+      for (int k = 0; k < 4; k++) gs_bfly_last(v[k], v[k + 4], ninv, ninvp, w, wp, q, q2);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) gs_bfly(v[k], v[k + 4], w, wp, q, q2);
+    }
   }
 }
 
@@ -150,7 +167,8 @@ __device__ __forceinline__ void ntt_fwd_block(u32 (&v)[8], int tau, u32* ldsA, u
   }
 }
 
-// Inverse: values in pattern {8 tau + k} (< 2q) -> pattern {tau + 256k}, canonical.
+// Inverse: values in pattern {8 tau + k} (< 2q) -> pattern {tau + 256k}, canonical.  iw / iwp: inv_tables (NOT the reference's
+// halved tables).
 __device__ __forceinline__ void ntt_inv_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ iw,
                                               const u32* __restrict__ iwp, u32 q, u32 q2) {
   inv_pass<1, false>(v, tau, iw, iwp, q, q2);
@@ -179,12 +197,7 @@ __device__ __forceinline__ void ntt_inv_block(u32 (&v)[8], int tau, u32* ldsA, u
   for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(tau + 256 * k)];
   inv_pass<256, true>(v, 0, iw, iwp, q, q2);
 #pragma unroll
-  for (int k = 0; k < 8; k++) {  // ntt.rs:253-256
-    u32 x = v[k];
-    x -= (x >= q2 ? q2 : 0u);
-    x -= (x >= q ? q : 0u);
-    v[k] = x;
-  }
+  for (int k = 0; k < 8; k++) v[k] -= (v[k] >= q ? q : 0u);  // ntt.rs:253-256, from < 2q
 }
 
 // ---- M transforms at once per thread: the twiddles, Shoup quotients and LDS addresses are computed once
@@ -242,10 +255,18 @@ __device__ __forceinline__ void inv_pass_m(u32 (&v)[M][8], int b, const u32* __r
   if (DO_A) {
     int i = N / (8 * S) + b;
     u32 w = iw[i], wp = iwp[i];
+    if (S == 256) {  // distance N/2: the last stage (i = 1)
+      const u32 ninv = iw[0], ninvp = iwp[0];
 #pragma unroll
-    for (int m = 0; m < M; m++)
+      for (int m = 0; m < M; m++)
 #pragma unroll
-      for (int k = 0; k < 4; k++) gs_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+        for (int k = 0; k < 4; k++) gs_bfly_last(v[m][k], v[m][k + 4], ninv, ninvp, w, wp, q, q2);
+    } else {
+#pragma unroll
+      for (int m = 0; m < M; m++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) gs_bfly(v[m][k], v[m][k + 4], w, wp, q, q2);
+    }
   }
 }
 template <int M>
@@ -365,12 +386,7 @@ __device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la
 #pragma unroll
   for (int m = 0; m < M; m++)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      u32 x = v[m][k];
-      x -= (x >= q2 ? q2 : 0u);
-      x -= (x >= q ? q : 0u);
-      v[m][k] = x;
-    }
+    for (int k = 0; k < 8; k++) v[m][k] -= (v[m][k] >= q ? q : 0u);  // ntt.rs:253-256, from < 2q
 }
 
 // Dword offset of unit (zp = plane*N + z, row pair jp, 128-column chunk) in the PACKED database.  The units one

@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
         acc1[4] += (u64)r1.x * v[4]; acc1[5] += (u64)r1.y * v[5]; acc1[6] += (u64)r1.z * v[6]; acc1[7] += (u64)r1.w * v[7];
       }
     }
-    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    const u32* iw = inv_tables(T.tw, c);
     u32 v0[8], v1[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused2(DevTables T, FoldDesc d)
         }
       }
     }
-    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    const u32* iw = inv_tables(T.tw, c);
     u32 vv[2][8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
@@ -484,7 +484,7 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
           rr[4 * g] = t4.x; rr[4 * g + 1] = t4.y; rr[4 * g + 2] = t4.z; rr[4 * g + 3] = t4.w;
         }
       }
-      wntt_inv(rr, lt, mybuf, T.tw + ((size_t)imod * 4 + 2) * N, mi.q, mi.two_q);  // -> coefficient 64 k + lane
+      wntt_inv(rr, lt, mybuf, inv_tables(T.tw, imod), mi.q, mi.two_q);  // -> coefficient 64 k + lane
       u32* exch = smem_fw + 4 * WBUF_WORDS;  // the table area: modulus-1 residues of both rows for Garner
       if (wv < 2) {
 #pragma unroll

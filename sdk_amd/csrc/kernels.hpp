@@ -16,9 +16,11 @@ namespace spiral {
 constexpr int N = (int)POLY_LEN;
 
 struct DevTables {
-  const u32* tw;  // [crt][4][N] twiddles (0 fwd, 1 fwd', 2 inv, 3 inv')
+  const u32* tw;  // [crt][4][N] twiddles as the reference's (0 fwd, 1 fwd', 2 inv, 3 inv'), then [crt][2][N] (inv_tables)
   DevConsts c;
 };
+// [w | w'] of modulus c for the kernels' inverse transform: unhalved psi^-i, entries 0 and 1 times N^-1 (params.cpp, finish)
+__host__ __device__ inline const u32* inv_tables(const u32* tw, int c) { return tw + (size_t)8 * N + (size_t)c * 2 * N; }
 
 // ---- which kernels / flows the calling thread's work went through (sp_paths_taken, include/spiral_hip.h) ----------
 // Every launch wrapper reports here right after its hipLaunchKernelGGL: the bit is recorded (thread-local, tests assert

@@ -156,7 +156,7 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
       }
       v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
     }
-    const u32* iw = T.tw + ((size_t)c * 4 + 2) * N;
+    const u32* iw = inv_tables(T.tw, c);
     if (c == 1) __syncthreads();
     ntt_inv_block_m<4>(v, tau, lds0, lds1, iw, iw + N, m.q, m.two_q);
     if (c == 0) {

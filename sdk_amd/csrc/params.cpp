@@ -114,7 +114,7 @@ void Params::finish() {
   modulus = moduli[0] * moduli[1];
   modulus_log2 = 0;
   while (((u128)1 << modulus_log2) < (u128)modulus) modulus_log2++;  // log2_ceil, arith.rs:13-15
-  ntt_tables.assign(CRT_COUNT * 4 * poly_len, 0);
+  ntt_tables.assign(CRT_COUNT * 6 * poly_len, 0);  // [crt][4][N] as the reference's, then [crt][2][N]: the kernels' inverse tables
   for (int c = 0; c < 2; c++) {
     u64 q = moduli[c];
     u64 psi = minimal_primitive_root(2 * poly_len, q);
@@ -123,6 +123,12 @@ void Params::finish() {
     u32* fwp = fw + poly_len;
     u32* iw = fwp + poly_len;
     u32* iwp = iw + poly_len;
+    // The kernels' inverse transform (device_common.hpp, gs_bfly) uses the UNHALVED inverse twiddles psi^-i and multiplies by
+    // N^-1 in its last stage instead of halving in every butterfly (ntt.rs:236-249): entries 0 and 1 -- the last stage's
+    // (x + y) and (x - y) factors -- carry N^-1.  Same residues, so the same canonical results.
+    u32* lw = ntt_tables.data() + (size_t)CRT_COUNT * 4 * poly_len + (size_t)c * 2 * poly_len;
+    u32* lwp = lw + poly_len;
+    const u64 n_inv = inv_mod((u64)poly_len % q, q);
     u64 pw = 1, ipw = 1;
     for (size_t i = 0; i < poly_len; i++) {
       // ntt.rs:6-17: table[bitrev(i)] = root^i; inverse table additionally halved (ntt.rs:50-53)
@@ -132,6 +138,9 @@ void Params::finish() {
       fwp[idx] = (u32)((pw << 32) / q);      // scale_powers_u32, ntt.rs:29-37
       iw[idx] = (u32)half;
       iwp[idx] = (u32)((half << 32) / q);
+      const u64 lz = idx < 2 ? mul_mod(ipw, n_inv, q) : ipw;
+      lw[idx] = (u32)lz;
+      lwp[idx] = (u32)((lz << 32) / q);
       pw = mul_mod(pw, psi, q);
       ipw = mul_mod(ipw, psi_inv, q);
     }

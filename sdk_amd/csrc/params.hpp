@@ -50,7 +50,7 @@ struct Params {
   bool expand_queries = true;
   size_t db_dim_1 = 0, db_dim_2 = 0, instances = 1, db_item_size = 0, version = 0;
   // ntt_tables[crt][which][i] as in params.rs:85-96 (0 fwd, 1 fwd', 2 inv, 3 inv')
-  std::vector<u32> ntt_tables;  // [crt][4][N]
+  std::vector<u32> ntt_tables;  // [crt][4][N], then [crt][2][N]: the kernels' lazy inverse tables (params.cpp, finish)
   DevConsts dc;
 
   // --- derived sizes (params.rs:116-200, server.rs:476-480)

@@ -364,7 +364,7 @@ __device__ __forceinline__ void wntt_fwd(u32 (&v)[32], int lane, u32* buf, const
 
 // ------------------------------------------------------------------------------------------------------------------
 // inverse: v[k] = X[32 lane + k] (values < 2q)  ->  v[k] = x[64 k + lane], canonical
-// itw: global inverse tables [w | w'] of this modulus (ntt_tables which = 2, 3).  The per-lane twiddles are all fetched
+// itw: global inverse tables [w | w'] of this modulus (inv_tables: unhalved, N^-1 in entries 0 and 1).  The per-lane twiddles are all fetched
 // up front (94 registers: the caller's accumulators are gone by the time it transforms back)
 // ------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void wntt_inv(u32 (&v)[32], int lane, u32* buf, const u32* __restrict__ itw, u32 q, u32 q2) {
@@ -464,17 +464,15 @@ __device__ __forceinline__ void wntt_inv(u32 (&v)[32], int lane, u32* buf, const
     for (int k = 0; k < 32; k++) {
       if (((k / Tk) & 1) == 0) {
         const int ti = (1 << mm) + k / (2 * Tk);
-        gs_bfly(v[k], v[k + Tk], sw[ti], sw[N + ti], q, q2);
+        if (mm == 0)  // distance N/2: the last stage carries N^-1
+          gs_bfly_last(v[k], v[k + Tk], sw[0], sw[N], sw[1], sw[N + 1], q, q2);
+        else
+          gs_bfly(v[k], v[k + Tk], sw[ti], sw[N + ti], q, q2);
       }
     }
   }
 #pragma unroll
-  for (int k = 0; k < 32; k++) {  // ntt.rs:253-256
-    u32 x = v[k];
-    x -= (x >= q2 ? q2 : 0u);
-    x -= (x >= q ? q : 0u);
-    v[k] = x;
-  }
+  for (int k = 0; k < 32; k++) v[k] -= (v[k] >= q ? q : 0u);  // ntt.rs:253-256, from < 2q
 }
 
 // (wave_layout_word -- the word of coefficient n = 32 L + k of a polynomial stored in "wave layout", where lane L reads its

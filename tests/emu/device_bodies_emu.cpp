@@ -57,7 +57,7 @@ int emu_ntt_block(void* h, int c, int inverse, uint32_t* data) {
   return guarded([&] {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
-    const u32* tw = E.T.tw + ((size_t)c * 4 + (inverse ? 2 : 0)) * N;
+    const u32* tw = inverse ? inv_tables(E.T.tw, c) : E.T.tw + (size_t)c * 4 * N;  // the kernels' inverse tables are unhalved (kernels.hpp)
     emu::run_block(256, [&] {
       const int tau = threadIdx.x;
       u32 v[8];
@@ -81,7 +81,7 @@ int emu_ntt_block_m2(void* h, int c, int inverse, uint32_t* data) {
   return guarded([&] {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
-    const u32* tw = E.T.tw + ((size_t)c * 4 + (inverse ? 2 : 0)) * N;
+    const u32* tw = inverse ? inv_tables(E.T.tw, c) : E.T.tw + (size_t)c * 4 * N;  // the kernels' inverse tables are unhalved (kernels.hpp)
     emu::run_block(256, [&] {
       const int tau = threadIdx.x;
       u32 v[2][8];
@@ -109,7 +109,7 @@ int emu_wave_ntt_inv(void* h, int c, uint32_t* data) {
   return guarded([&] {
     const EmuParams& E = *(EmuParams*)h;
     const ModConst m = E.T.c.mod[c];
-    const u32* itw = E.T.tw + ((size_t)c * 4 + 2) * N;
+    const u32* itw = inv_tables(E.T.tw, c);
     emu::run_block(256, [&] {
       const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
       u32* poly = data + (size_t)wv * N;
