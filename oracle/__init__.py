@@ -29,6 +29,22 @@ def build(force=False):
     return so
 
 
+class avx2_bodies:
+    """Context manager: inside it the restatement runs the reference's `cfg(target_feature = "avx2")` bodies (ntt.rs:115-210,
+    260-365; poly.rs:407-426, 460-481) instead of the scalar ones.  Process-wide switch, restored on exit."""
+
+    def __init__(self, on=True):
+        self.on = 1 if on else 0
+
+    def __enter__(self):
+        self.prev = lib().orc_set_avx2_bodies(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        lib().orc_set_avx2_bodies(self.prev)
+        return False
+
+
 def lib():
     global _LIB
     if _LIB is None:

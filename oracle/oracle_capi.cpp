@@ -122,6 +122,13 @@ void orc_fill_words_first_touch(uint64_t* p, uint64_t nz, uint64_t words_per_z, 
     }
   }
 }
+// Which of the reference's bodies the restatement runs (spiral_oracle.h: set_avx2_bodies): 0 = cfg(not(avx2)), 1 = the AVX2
+// bodies of ntt.rs / poly.rs.  Returns the previous setting.
+int orc_set_avx2_bodies(int on) {
+  const int prev = get_avx2_bodies();
+  set_avx2_bodies(on);
+  return prev;
+}
 // OpenMP team size for the parallel sections that follow (cpu_baseline scans it); returns the previous maximum
 int orc_set_threads(int n) {
 #ifdef _OPENMP

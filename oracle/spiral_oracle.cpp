@@ -5,6 +5,8 @@
 // ============================================================================
 #include "spiral_oracle.h"
 
+#include <immintrin.h>  // the reference's AVX2 bodies, restated with the same intrinsics (set_avx2_bodies)
+
 #include <algorithm>
 #include <cassert>
 #include <cmath>
@@ -260,8 +262,23 @@ std::vector<std::vector<std::vector<u64>>> build_ntt_tables(size_t poly_len, con
   return output;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Which of the reference's two sets of bodies runs.  spiral-rs selects at COMPILE time (`cfg(target_feature = "avx2")`,
+// ntt.rs:66/115/212/260, poly.rs:407/437/460); here it is a run-time switch so that one test process can compare the two:
+// 0 = the `cfg(not(target_feature = "avx2"))` bodies (default), 1 = the AVX2 bodies restated with the same `_mm256_*`
+// intrinsics (ntt_forward_avx2 / ntt_inverse_avx2 / multiply_avx2 below).  The two differ in representatives, not in
+// residues: the AVX2 forward transform corrects with strict compares (`_mm256_cmpgt_epi64`), so it can leave q where the
+// scalar body leaves 0, and the AVX2 multiply accumulates unreduced and reduces once.
+// ---------------------------------------------------------------------------------------------------------------------
+static int g_avx2_bodies = 0;
+void set_avx2_bodies(int on) { g_avx2_bodies = on ? 1 : 0; }
+int get_avx2_bodies() { return g_avx2_bodies; }
+static void ntt_forward_avx2(const Params& params, u64* operand_overall);
+static void ntt_inverse_avx2(const Params& params, u64* operand_overall);
+
 // ntt.rs:67-113 (scalar body)
 void ntt_forward(const Params& params, u64* operand_overall) {
+  if (g_avx2_bodies) return ntt_forward_avx2(params, operand_overall);
   size_t log_n = params.poly_len_log2;
   size_t n = (size_t)1 << log_n;
   for (size_t coeff_mod = 0; coeff_mod < params.crt_count; coeff_mod++) {
@@ -297,6 +314,7 @@ void ntt_forward(const Params& params, u64* operand_overall) {
 
 // ntt.rs:212-258 (scalar body)
 void ntt_inverse(const Params& params, u64* operand_overall) {
+  if (g_avx2_bodies) return ntt_inverse_avx2(params, operand_overall);
   for (size_t coeff_mod = 0; coeff_mod < params.crt_count; coeff_mod++) {
     size_t n = params.poly_len;
     u64* operand = operand_overall + coeff_mod * n;
@@ -325,6 +343,148 @@ void ntt_inverse(const Params& params, u64* operand_overall) {
       }
     }
     for (size_t i = 0; i < n; i++) {
+      operand[i] -= (u64)(operand[i] >= two_times_modulus) * two_times_modulus;
+      operand[i] -= (u64)(operand[i] >= modulus) * modulus;
+    }
+  }
+}
+
+
+// ---- the reference's AVX2 bodies (`cfg(target_feature = "avx2")`), intrinsic for intrinsic.  The reference's buffers are
+// 64-byte aligned (AlignedMemory64) and it uses the aligned load / store forms; the restatement's buffers are std::vectors, so
+// the unaligned forms stand in for them (same values).  `_mm256_cmpgt_epi64` is a SIGNED compare, as in the reference; every
+// operand here is far below 2^63.
+// ntt.rs:115-210
+static void ntt_forward_avx2(const Params& params, u64* operand_overall) {
+  size_t log_n = params.poly_len_log2;
+  size_t n = (size_t)1 << log_n;
+  for (size_t coeff_mod = 0; coeff_mod < params.crt_count; coeff_mod++) {
+    u64* operand = operand_overall + coeff_mod * n;
+    const u64* forward_table = params.get_ntt_forward_table(coeff_mod);
+    const u64* forward_table_prime = params.get_ntt_forward_prime_table(coeff_mod);
+    u32 modulus_small = (u32)params.moduli[coeff_mod];
+    u32 two_times_modulus_small = 2 * modulus_small;
+    for (size_t mm = 0; mm < log_n; mm++) {
+      size_t m = (size_t)1 << mm;
+      size_t t = n >> (mm + 1);
+      for (size_t i = 0; i < m; i++) {
+        u64 w = forward_table[m + i];
+        u64 w_prime = forward_table_prime[m + i];
+        u64* op = operand + i * 2 * t;
+        if (t < 4) {  // ntt.rs:142-154: the scalar butterfly for the last two stages
+          for (size_t j = 0; j < t; j++) {
+            u32 x = (u32)op[j];
+            u32 y = (u32)op[t + j];
+            u32 curr_x = x - (two_times_modulus_small * (u32)(x >= two_times_modulus_small));
+            u64 q_tmp = ((u64)y * w_prime) >> 32;
+            u64 q_new = w * (u64)y - q_tmp * (u64)modulus_small;
+            op[j] = (u64)curr_x + q_new;
+            op[t + j] = (u64)curr_x + ((u64)two_times_modulus_small - q_new);
+          }
+        } else {      // ntt.rs:156-188
+          for (size_t j = 0; j < t; j += 4) {
+            __m256i* p_x = (__m256i*)&op[j];
+            __m256i* p_y = (__m256i*)&op[j + t];
+            __m256i x = _mm256_loadu_si256(p_x);
+            __m256i y = _mm256_loadu_si256(p_y);
+            __m256i cmp_val = _mm256_set1_epi64x((long long)two_times_modulus_small);
+            __m256i gt_mask = _mm256_cmpgt_epi64(x, cmp_val);
+            __m256i to_subtract = _mm256_and_si256(gt_mask, cmp_val);
+            __m256i curr_x = _mm256_sub_epi64(x, to_subtract);
+            __m256i w_prime_vec = _mm256_set1_epi64x((long long)w_prime);
+            __m256i product = _mm256_mul_epu32(y, w_prime_vec);
+            __m256i q_val = _mm256_srli_epi64(product, 32);
+            __m256i w_vec = _mm256_set1_epi64x((long long)w);
+            __m256i w_times_y = _mm256_mul_epu32(y, w_vec);
+            __m256i modulus_small_vec = _mm256_set1_epi64x((long long)modulus_small);
+            __m256i q_scaled = _mm256_mul_epu32(q_val, modulus_small_vec);
+            __m256i q_final = _mm256_sub_epi64(w_times_y, q_scaled);
+            __m256i new_x = _mm256_add_epi64(curr_x, q_final);
+            __m256i q_final_inverted = _mm256_sub_epi64(cmp_val, q_final);
+            __m256i new_y = _mm256_add_epi64(curr_x, q_final_inverted);
+            _mm256_storeu_si256(p_x, new_x);
+            _mm256_storeu_si256(p_y, new_y);
+          }
+        }
+      }
+    }
+    for (size_t i = 0; i < n; i += 4) {  // ntt.rs:193-208: strict compares -- 2q and q stay where the scalar body yields 0
+      __m256i* p_x = (__m256i*)&operand[i];
+      __m256i cmp_val1 = _mm256_set1_epi64x((long long)two_times_modulus_small);
+      __m256i x = _mm256_loadu_si256(p_x);
+      __m256i gt_mask = _mm256_cmpgt_epi64(x, cmp_val1);
+      __m256i to_subtract = _mm256_and_si256(gt_mask, cmp_val1);
+      x = _mm256_sub_epi64(x, to_subtract);
+      __m256i cmp_val2 = _mm256_set1_epi64x((long long)modulus_small);
+      gt_mask = _mm256_cmpgt_epi64(x, cmp_val2);
+      to_subtract = _mm256_and_si256(gt_mask, cmp_val2);
+      x = _mm256_sub_epi64(x, to_subtract);
+      _mm256_storeu_si256(p_x, x);
+    }
+  }
+}
+
+// ntt.rs:260-365
+static void ntt_inverse_avx2(const Params& params, u64* operand_overall) {
+  for (size_t coeff_mod = 0; coeff_mod < params.crt_count; coeff_mod++) {
+    size_t n = params.poly_len;
+    u64* operand = operand_overall + coeff_mod * n;
+    const u64* inverse_table = params.get_ntt_inverse_table(coeff_mod);
+    const u64* inverse_table_prime = params.get_ntt_inverse_prime_table(coeff_mod);
+    u64 modulus = params.moduli[coeff_mod];
+    u64 two_times_modulus = 2 * modulus;
+    for (size_t mm = params.poly_len_log2; mm-- > 0;) {
+      size_t h = (size_t)1 << mm;
+      size_t t = n >> (mm + 1);
+      for (size_t i = 0; i < h; i++) {
+        u64 w = inverse_table[h + i];
+        u64 w_prime = inverse_table_prime[h + i];
+        u64* op = operand + i * 2 * t;
+        if (t < 4) {  // ntt.rs:283-296
+          for (size_t j = 0; j < t; j++) {
+            u64 x = op[j];
+            u64 y = op[t + j];
+            u64 t_tmp = two_times_modulus - y + x;
+            u64 curr_x = x + y - (two_times_modulus * (u64)((x << 1) >= t_tmp));
+            u64 h_tmp = (t_tmp * w_prime) >> 32;
+            u64 res_x = (curr_x + (modulus * (u64)(t_tmp & 1))) >> 1;
+            u64 res_y = w * t_tmp - h_tmp * modulus;
+            op[j] = res_x;
+            op[t + j] = res_y;
+          }
+        } else {      // ntt.rs:298-338
+          for (size_t j = 0; j < t; j += 4) {
+            __m256i* p_x = (__m256i*)&op[j];
+            __m256i* p_y = (__m256i*)&op[j + t];
+            __m256i x = _mm256_loadu_si256(p_x);
+            __m256i y = _mm256_loadu_si256(p_y);
+            __m256i modulus_vec = _mm256_set1_epi64x((long long)modulus);
+            __m256i two_times_modulus_vec = _mm256_set1_epi64x((long long)two_times_modulus);
+            __m256i t_tmp = _mm256_set1_epi64x((long long)two_times_modulus);
+            t_tmp = _mm256_sub_epi64(t_tmp, y);
+            t_tmp = _mm256_add_epi64(t_tmp, x);
+            __m256i gt_mask = _mm256_cmpgt_epi64(_mm256_slli_epi64(x, 1), t_tmp);
+            __m256i to_subtract = _mm256_and_si256(gt_mask, two_times_modulus_vec);
+            __m256i curr_x = _mm256_add_epi64(x, y);
+            curr_x = _mm256_sub_epi64(curr_x, to_subtract);
+            __m256i w_prime_vec = _mm256_set1_epi64x((long long)w_prime);
+            __m256i h_tmp = _mm256_mul_epu32(t_tmp, w_prime_vec);
+            h_tmp = _mm256_srli_epi64(h_tmp, 32);
+            __m256i and_mask = _mm256_set_epi64x(1, 1, 1, 1);
+            __m256i eq_mask = _mm256_cmpeq_epi64(_mm256_and_si256(t_tmp, and_mask), and_mask);
+            __m256i to_add = _mm256_and_si256(eq_mask, modulus_vec);
+            __m256i new_x = _mm256_srli_epi64(_mm256_add_epi64(curr_x, to_add), 1);
+            __m256i w_vec = _mm256_set1_epi64x((long long)w);
+            __m256i w_times_t_tmp = _mm256_mul_epu32(t_tmp, w_vec);
+            __m256i h_tmp_times_modulus = _mm256_mul_epu32(h_tmp, modulus_vec);
+            __m256i new_y = _mm256_sub_epi64(w_times_t_tmp, h_tmp_times_modulus);
+            _mm256_storeu_si256(p_x, new_x);
+            _mm256_storeu_si256(p_y, new_y);
+          }
+        }
+      }
+    }
+    for (size_t i = 0; i < n; i++) {  // ntt.rs:343-346 (the vector form of this loop is commented out in the reference)
       operand[i] -= (u64)(operand[i] >= two_times_modulus) * two_times_modulus;
       operand[i] -= (u64)(operand[i] >= modulus) * modulus;
     }
@@ -531,7 +691,41 @@ static void automorph_poly(const Params& params, u64* res, const u64* a, size_t 
 }
 
 // poly.rs:437-458 (scalar)
-void multiply(PolyMatrixNTT& res, const PolyMatrixNTT& a, const PolyMatrixNTT& b) {
+// poly.rs:407-426: products of the low 32-bit halves accumulated WITHOUT reduction
+static void multiply_add_poly_avx(const Params& params, u64* res, const u64* a, const u64* b) {
+  for (size_t c = 0; c < params.crt_count; c++)
+    for (size_t i = 0; i < params.poly_len; i += 4) {
+      const __m256i* p_x = (const __m256i*)&a[c * params.poly_len + i];
+      const __m256i* p_y = (const __m256i*)&b[c * params.poly_len + i];
+      __m256i* p_z = (__m256i*)&res[c * params.poly_len + i];
+      __m256i x = _mm256_loadu_si256(p_x);
+      __m256i y = _mm256_loadu_si256(p_y);
+      __m256i z = _mm256_loadu_si256(p_z);
+      __m256i product = _mm256_mul_epu32(x, y);
+      __m256i out = _mm256_add_epi64(z, product);
+      _mm256_storeu_si256(p_z, out);
+    }
+}
+static void modular_reduce(const Params& params, u64* res) {  // poly.rs:428-435
+  for (size_t c = 0; c < params.crt_count; c++)
+    for (size_t i = 0; i < params.poly_len; i++) {
+      size_t idx = c * params.poly_len + i;
+      res[idx] = barrett_coeff_u64(params, res[idx], c);
+    }
+}
+static void multiply_avx2(PolyMatrixNTT& res, const PolyMatrixNTT& a, const PolyMatrixNTT& b) {  // poly.rs:460-481
+  ORACLE_CHECK(res.rows == a.rows && res.cols == b.cols && a.cols == b.rows);
+  const Params& params = *res.params;
+  for (size_t i = 0; i < a.rows; i++)
+    for (size_t j = 0; j < b.cols; j++) {
+      u64* res_poly = res.get_poly(i, j);
+      for (size_t z = 0; z < params.poly_len * params.crt_count; z++) res_poly[z] = 0;
+      for (size_t k = 0; k < a.cols; k++) multiply_add_poly_avx(params, res_poly, a.get_poly(i, k), b.get_poly(k, j));
+      modular_reduce(params, res_poly);
+    }
+}
+void multiply(PolyMatrixNTT& res, const PolyMatrixNTT& a, const PolyMatrixNTT& b) {  // poly.rs:437-458 (scalar body)
+  if (g_avx2_bodies) return multiply_avx2(res, a, b);
   ORACLE_CHECK(res.rows == a.rows && res.cols == b.cols && a.cols == b.rows);
   const Params& params = *res.params;
   for (size_t i = 0; i < a.rows; i++)

@@ -2,8 +2,9 @@
 // oracle/spiral_oracle.h -- TEST INFRASTRUCTURE ONLY. NOT PART OF THE PRODUCT.
 //
 // A scalar CPU restatement (C++17, unsigned __int128) of the Spiral PIR answer
-// path of blyssprivacy/sdk `lib/spiral-rs` (the `cfg(not(target_feature="avx2"))`
-// bodies), written function-for-function so that the HIP path in
+// path of blyssprivacy/sdk `lib/spiral-rs` -- the `cfg(not(target_feature="avx2"))`
+// bodies by default, the AVX2 bodies of ntt.rs / poly.rs (same `_mm256_*`
+// intrinsics) behind set_avx2_bodies() -- written function-for-function so that the HIP path in
 // `sdk_amd/csrc` can be checked bit-for-bit against it.  Only `tests/`,
 // `__graft_entry__.smoke()` and `bench.py`'s `cpu_baseline` leg may load this
 // code, and only as the checker / the CPU baseline.  The product library
@@ -23,6 +24,11 @@
 //    (no rustc/cargo, crates not vendored).  These are pinned the way the
 //    reference's own tests pin them: decrypt-and-compare after every stage
 //    (mirror of server.rs:788-1043) -- see tests/test_oracle_protocol.py.
+//  * scalar == AVX2: the reference is two programs (compile-time `cfg`); both sets
+//    of bodies are restated and tests/test_oracle_avx2_bodies.py pins that they
+//    differ in representatives only (q for 0 after the AVX2 forward transform) and
+//    that every serialized byte and every response is identical in all
+//    client / loader / server combinations.
 //  * rand_chacha 0.3.1 boundary (public randomness regenerated from a 32-byte
 //    seed, client.rs:47-49, 68-80): **parity unpinned** inside the reference
 //    (no fixed-seed test).  Pinned here to the RFC 8439 ChaCha20 block-function
@@ -147,6 +153,11 @@ struct PolyMatrixNTT {  // poly.rs:66-71
   PolyMatrixNTT pad_top(size_t pad_rows) const;                             // poly.rs:296-300
 };
 
+// Which of the reference's bodies run: 0 (default) the `cfg(not(target_feature = "avx2"))` ones, 1 the AVX2 ones
+// (ntt.rs:115-210, 260-365; poly.rs:407-426, 460-481), restated with the same intrinsics.  Process-wide; set it before the
+// threads of a parallel section start.
+void set_avx2_bodies(int on);
+int get_avx2_bodies();
 void ntt_forward(const Params& params, u64* operand_overall);  // ntt.rs:67-113 (scalar)
 void ntt_inverse(const Params& params, u64* operand_overall);  // ntt.rs:212-258 (scalar)
 

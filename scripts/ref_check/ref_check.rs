@@ -17,8 +17,12 @@
 // Run it twice:
 //     REF_CHECK_DIR=... cargo test --release --features server --test ref_check -- --nocapture
 //     REF_CHECK_DIR=... RUSTFLAGS="-C target-feature=+avx2" cargo test --release --features server --test ref_check -- --nocapture
-// The scalar and the AVX2 builds must both agree with the dump (the AVX2 multiply keeps its sums
-// in a different order and reduces at other points; residues and response bytes must not differ).
+// The scalar and the AVX2 builds must both agree with the dump.  The AVX2 bodies differ from the scalar ones in
+// REPRESENTATIVES, not in residues: `ntt_forward` corrects with strict compares (ntt.rs:163, 193-207) and leaves q where the
+// scalar body leaves 0, `multiply` accumulates unreduced (poly.rs:407-426, 460-481).  The stage outputs of expand_query are
+// therefore reduced limb by limb before they are compared (`canon_word`, `canon_ntt`); multiply_reg_by_database and the
+// response are compared raw (both builds reduce them).  This repository's oracle restates both sets of bodies and checks
+// exactly these equalities (tests/test_oracle_avx2_bodies.py), so both runs are expected to pass.
 use std::fs::{self, File};
 use std::path::{Path, PathBuf};
 
@@ -31,6 +35,19 @@ fn read_words(p: &Path) -> Vec<u64> {
     let b = fs::read(p).unwrap();
     assert_eq!(b.len() % 8, 0, "{:?}: not a whole number of u64 words", p);
     b.chunks_exact(8).map(|c| u64::from_ne_bytes(c.try_into().unwrap())).collect()
+}
+
+// both limbs of a packed word lo | hi << 32 (server.rs:262-270, util.rs:343-350) reduced mod their prime
+fn canon_word(w: u64, q0: u64, q1: u64) -> u64 {
+    ((w & 0xFFFF_FFFF) % q0) | (((w >> 32) % q1) << 32)
+}
+
+// an NTT-form polynomial matrix [poly][crt][z]: every residue reduced mod its prime
+fn canon_ntt(words: &mut [u64], poly_len: usize, moduli: &[u64]) {
+    let per_poly = poly_len * moduli.len();
+    for (i, w) in words.iter_mut().enumerate() {
+        *w %= moduli[(i % per_poly) / poly_len];
+    }
 }
 
 fn first_diff(a: &[u64], b: &[u64]) -> Option<usize> {
@@ -77,13 +94,16 @@ fn reference_process_query_matches_dumped_responses() {
         if params.expand_queries && d.join("v_reg.bin").is_file() {
             let (v_reg, v_folding) = expand_query(&params, &pp, &query);
             let want_reg = read_words(&d.join("v_reg.bin"));
-            let diff = first_diff(v_reg.as_slice(), &want_reg);
+            let (q0, q1) = (params.moduli[0], params.moduli[1]);
+            let got_reg: Vec<u64> = v_reg.as_slice().iter().map(|&w| canon_word(w, q0, q1)).collect();
+            let diff = first_diff(&got_reg, &want_reg);
             assert!(diff.is_none(), "{}: STAGE expand_query: v_reg_reoriented differs at word {:?}", name, diff);
             let want_fold = read_words(&d.join("v_folding.bin"));
             let mut got_fold: Vec<u64> = Vec::with_capacity(want_fold.len());
             for m in v_folding.iter() {
                 got_fold.extend_from_slice(m.as_slice());
             }
+            canon_ntt(&mut got_fold, params.poly_len, &params.moduli[0..params.crt_count]);
             let diff = first_diff(&got_fold, &want_fold);
             assert!(diff.is_none(), "{}: STAGE expand_query: v_folding differs at word {:?}", name, diff);
             // ---- stage 2: multiply_reg_by_database on the first (instance 0, trial 0) slice
