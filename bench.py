@@ -81,22 +81,34 @@ def sweep_moved_bytes(cfg, shards, db_device_bytes):
     return db_device_bytes + T * N * (dim0 // shards) * 16 + T * num_per * 4 * N * 4
 
 
-def pmc_traffic(cfg_name, world, launches):
+def pmc_traffic(cfg_name, world, launches, lib_path=None):
     """HBM bytes per sweep launch from the rocprofv3 PMC passes kept under profiles/ (FETCH_SIZE doubled per the
     gfx950 correction + WRITE_SIZE).  bench.py cannot collect counters itself: the figure is REPLAYED from the newest
-    tracked record and `traffic_source` says so.  (None, None) when no matching record exists."""
+    tracked record and `traffic_source` says so.  A record is only replayed into a library whose sweep kernel is, byte for
+    byte, the kernel that was profiled (`kernel_signature`: sha256 of its machine code, sdk_amd/kernel_signature.py); with a
+    different kernel -- or a record without a signature -- the traffic is null and `traffic_source` says why.
+    (None, reason) when no matching record exists."""
     if cfg_name != "c2" or world != 1:
         return None, None
-    for name in ("r04_final_pmc_sweep_c2.json", "r03_final_pmc_sweep_c2.json", "r02_pmc_sweep_c2.json", "r01_pmc_sweep_c2_packed.json"):
-        path = os.path.join(ROOT, "profiles", name)
+    from sdk_amd.kernel_signature import SWEEP_C2, kernel_signature
+    try:
+        loaded, _ = kernel_signature(lib_path, SWEEP_C2)
+    except Exception as e:
+        return None, "not replayed: no signature of the loaded library's sweep kernel (%s)" % (repr(e)[:100])
+    refused = []
+    for name in sorted((n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("pmc_sweep_c2.json")), reverse=True):
         try:
-            rec = json.load(open(path))
+            rec = json.load(open(os.path.join(ROOT, "profiles", name)))
+            if rec.get("kernel_signature") != loaded:
+                refused.append(name)
+                continue
             return (rec["hbm_bytes_per_launch"] * rec.get("launches_per_query", 1) / launches,
-                    "replayed from profiles/%s (separate rocprofv3 --pmc passes on the builder's box; not measured in "
-                    "this run)" % name)
+                    "replayed from profiles/%s (separate rocprofv3 --pmc passes on the builder's box; not measured in this run; "
+                    "the record's kernel signature %s equals the loaded library's)" % (name, loaded))
         except Exception:
             continue
-    return None, None
+    return None, ("not replayed: the loaded library's sweep kernel (signature %s) is not the kernel any record under profiles/ "
+                  "was measured on (%s)" % (loaded, ", ".join(refused) or "no records"))
 
 
 def torchrun_command(n_gpus, argv, port=None):
@@ -695,7 +707,7 @@ def main():
 
     if rank == 0:
         q_per_step = batch * (world if replicas else 1) if mode in ("single", "replicas") else 1
-        traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches)
+        traffic, traffic_source = pmc_traffic(args.config, world if sharded else 1, launches, sp.library_path())
         # the roofline block describes the kernel sp_bench_sweep / the stage events time: the single-query sweep; batched
         # steps add roofline.batched_pass (the pass kernel of the group, timed by sp_bench_sweep_batch)
         npairs_local = (1 << cfg["nu_1"]) // (2 * (world if sharded and mode != "columns" else 1))

@@ -3,8 +3,12 @@
 trace only) -> the JSON record bench.py reads for roofline.traffic.  gfx950 correction per
 /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE counts half of a wide streaming read."""
 import json
+import os
 import sqlite3
 import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from sdk_amd.kernel_signature import SWEEP_C2, kernel_signature  # noqa: E402
 
 
 def mean_counter(db, counter, kernel_substr):
@@ -18,7 +22,12 @@ def mean_counter(db, counter, kernel_substr):
 def main(fetch_db, write_db, out, kernel="k_sweep_packed_", launches_per_query=4, alg_bytes_per_query=69323456512):
     f, nf = mean_counter(fetch_db, "FETCH_SIZE", kernel)
     w, nw = mean_counter(write_db, "WRITE_SIZE", kernel)
+    so = os.environ.get("SPIRAL_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "sdk_amd", "libspiral_hip.so")
+    sig, mangled = kernel_signature(so, SWEEP_C2)
     rec = {
+        # identity of the profiled kernel: bench.py replays this record only into a library whose kernel has the same machine code
+        "kernel_signature": sig,
+        "kernel_signature_of": mangled,
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py "
                 "--steps 1 --warmup 0 --sweep-iters 2 --no-cpu-baseline`, config c2, kernel %s (7-byte PACKED "
                 "database, one launch per plane), %d / %d dispatches" % (kernel, nf, nw),

@@ -1591,14 +1591,21 @@ int sp_fold_ciphertexts_fused(const sp_params_t* h, uint64_t* cts, size_t num_pe
     HIP_CHECK(hipMemcpyAsync(W->foldX.p, cts, num_per * 2 * POLY_LEN * 8, hipMemcpyHostToDevice, W->stream));
     const long saved = W->fused_min_pairs;
     if (fused_min_pairs > 0) W->fused_min_pairs = fused_min_pairs;
+    // the caller's ciphertexts: below Q (what the reference's invariants give, and what lets the kernels skip the dead top
+    // digit) only if every coefficient says so -- checked here, on the host copy
+    bool below_q = true;
+    for (size_t i = 0; i < num_per * 2 * POLY_LEN && below_q; i++) below_q = cts[i] < p.modulus;
+    W->fold_inputs_below_q = below_q;
     u64* res = nullptr;
     try {
       res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
     } catch (...) {
       W->fused_min_pairs = saved;
+      W->fold_inputs_below_q = true;
       throw;
     }
     W->fused_min_pairs = saved;
+    W->fold_inputs_below_q = true;
     download_raw(*W, res, 2 * POLY_LEN, cts);
   });
 }

@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
   const int tau = threadIdx.x;
   const int i = (int)blockIdx.x, plane = blockIdx.y;
   const int two_t = 2 * d.t, four_t = 4 * d.t;
+  const int t_live = d.t_live > 0 && d.t_live < d.t ? d.t_live : d.t;
   const u64* ct0 = d.X + ((size_t)plane * d.cur + i) * 2 * N;
   const u64* ct1 = ct0 + (size_t)d.half * 2 * N;
   const u64 mask = (1ULL << d.bits) - 1ULL;
@@ -63,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_fused(DevTables T, FoldDesc d) 
         x1[k] = ct1[(size_t)j * N + tau + 256 * k];
       }
 #pragma unroll 1
-      for (int kd = 0; kd < d.t; kd++) {
+      for (int kd = 0; kd < t_live; kd++) {   // (the digits above t_live are identically zero: FoldDesc::t_live)
         const int sh = kd * d.bits;
         u32 v[8];
 #pragma unroll
@@ -301,8 +302,10 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
   extern __shared__ __attribute__((aligned(16))) u32 smem_fw[];
   u32* wbuf = smem_fw;                      // transposes (one region per wave) ...
   u32* ltw = smem_fw + 4 * WBUF_WORDS;      // forward tables of the current modulus (swizzled, wtw_stage)
+  // live digits only (FoldDesc::t_live): plane li = j * t_live + kd holds digit kd of row j
+  const int t_live = d.t_live > 0 && d.t_live < d.t ? d.t_live : d.t;
   unsigned char* dig = reinterpret_cast<unsigned char*>(ltw + 2 * N);
-  unsigned char* sgn = dig + (size_t)2 * d.t * (N * ES);  // sign bits: digit dg, lane l -> one dword, bit k = coefficient 64k + l
+  unsigned char* sgn = dig + (size_t)2 * t_live * (N * ES);  // sign bits: plane li, lane l -> one dword, bit k = coefficient 64k + l
   constexpr int E = 16 / ES;                // digit differences per 16-byte vector
   const int tau = threadIdx.x, lane = tau & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);  // wave-uniform: digit index and row pointers stay scalar
@@ -313,6 +316,10 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
   u64* out = d.Y + ((size_t)plane * d.half + i) * 2 * N;
   if (d.zero_shortcuts && fold_zero_shortcut(ct0, ct1, out, tau)) return;
   u32* mybuf = wbuf + wv * WBUF_WORDS;
+  // which planes a wave transforms: wv0, wv0 + 4, ...  When 2 t_live is not a multiple of 4 (14 live digits of t_gsw = 8) some
+  // waves get one transform less; the assignment is rotated by the workgroup's parity so that the two workgroups sharing a CU
+  // do not put their short waves on the same pair of SIMDs
+  const int wv0 = (wv + 2 * ((int)blockIdx.x & 1)) & 3;
   {  // digit differences of coefficients 64k + lane, k = 8 wv .. 8 wv + 7, both rows.  Element (digit, n = 64k + lane) lives
      // at byte (digit * 2048 * ES) + (k / E) * 1024 + lane * 16 + (k % E) * ES: a lane's 32 values are 2 ES vectors of
      // 16 bytes, vector h of all lanes one contiguous KiB (conflict-free b128 reads)
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
         x1[j][e] = ct1[n];
       }
 #pragma unroll 1
-    for (int kd = 0; kd < d.t; kd++) {
+    for (int kd = 0; kd < t_live; kd++) {
       const int sh = (kd * d.bits) & 63;
       const u64 dmask = kd * d.bits >= 64 ? 0ULL : mask;
 #pragma unroll
@@ -335,11 +342,11 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
         u32 df[8];
 #pragma unroll
         for (int e = 0; e < 8; e++) df[e] = (u32)((x1[j][e] >> sh) & dmask) - (u32)((x0[j][e] >> sh) & dmask);
-        unsigned char* base = dig + (size_t)(j * d.t + kd) * (N * ES);
+        unsigned char* base = dig + (size_t)(j * t_live + kd) * (N * ES);
         u32 sb = 0;
 #pragma unroll
         for (int e = 0; e < 8; e++) sb |= (df[e] >> 31) << e;
-        sgn[(j * d.t + kd) * 256 + lane * 4 + wv] = (unsigned char)sb;
+        sgn[(j * t_live + kd) * 256 + lane * 4 + wv] = (unsigned char)sb;
         if (ES == 1) {
           u32x2w_t o;
           o.x = (df[0] & 0xff) | ((df[1] & 0xff) << 8) | ((df[2] & 0xff) << 16) | (df[3] << 24);
@@ -371,8 +378,8 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
 #pragma unroll
     for (int k = 0; k < 32; k++) acc0[k] = acc1[k] = 0;
 #pragma unroll 1
-    for (int dg = wv; dg < two_t; dg += 4) {
-      const int j = dg / d.t, kd = dg - j * d.t;
+    for (int dg = wv0; dg < 2 * t_live; dg += 4) {   // dg: plane index (live digits of row 0, then of row 1)
+      const int j = dg / t_live, kd = dg - j * t_live;
       // everything derived from the lane id or the table pointer is loop invariant; left alone the compiler hoists some
       // sixty addresses and as many scalar twiddles out of this loop and spills the accumulators to make room for them
       int ln = lane;
@@ -530,7 +537,8 @@ void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   const dim3 grid(d.half, d.planes), block(256);
   if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)
     const int es = d.bits <= 8 ? 1 : d.bits <= 16 ? 2 : 4;
-    const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * d.t * (N * es + 256);
+    const int t_live = d.t_live > 0 && d.t_live < d.t ? d.t_live : d.t;
+    const size_t lds = FOLD_WAVE_FIXED_LDS + (size_t)2 * t_live * (N * es + 256);
     if (lds <= 80 * 1024) {  // two workgroups per CU; with one the barrier-synchronised kernels are the faster ones
       // (> 64 KiB of dynamic LDS needs no opt-in on gfx950, scripts/ubench/dyn_lds.hip)
       if (es == 1)

@@ -170,6 +170,11 @@ struct FoldDesc {
   const u32* mats;
   int cur, half, planes;
   int t, bits;
+  // digits that can be non-zero: a coefficient below Q < 2^modulus_log2 has only ceil(modulus_log2 / bits) of them (8-bit digits
+  // of a 56-bit Q: 7 of t_gsw = 8 -- the top digit polynomial of G^-1 (gadget.rs:34-60) is identically zero, its transform is
+  // zero and adds nothing to the products).  The query flows, whose ciphertexts are from_ntt / fold outputs and therefore < Q,
+  // set it; with caller-supplied ciphertexts (stage-level entry points) it equals t.  0 means t.
+  int t_live;
   // lib/server semantics (lib/server/src/compute/fold.rs:38-44): an all-zero ct_i is replaced by ct_{i+half}, an
   // all-zero ct_{i+half} leaves ct_i as it is -- no external product in either case
   int zero_shortcuts;

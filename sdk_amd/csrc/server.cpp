@@ -1076,6 +1076,9 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
       fd.planes = np;
       fd.t = (int)p.t_gsw;
       fd.bits = (int)p.bits_per(p.t_gsw);
+      // digits kd with kd * bits >= modulus_log2 are zero for coefficients below Q (t_gsw = 8: 7 live 8-bit digits of 56 bits)
+      fd.t_live = W.fold_inputs_below_q && tunable("fold_skip_dead_digits", 1)
+                      ? (int)std::min<size_t>(p.t_gsw, (p.modulus_log2 + fd.bits - 1) / fd.bits) : fd.t;
       launch_fold_fused(D.T, fd, s);
       std::swap(X, Y);
       cur = half;

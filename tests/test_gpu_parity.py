@@ -1267,9 +1267,17 @@ def test_wave_fold_kernel_gadget_widths(sp, oracle_mod, monkeypatch, ci):
     gdb = sp.Database(p).load(db)
     sp.paths_taken()
     resp = sp.process_query(p, gpp, q, gdb)
-    # the kernel is used while two workgroups fit a CU: 34 KiB + 2 t (2048 ES + 256) bytes of LDS <= 80 KiB
-    es = 1 if o.get_bits_per(cfg["t_gsw"]) <= 8 else 2 if o.get_bits_per(cfg["t_gsw"]) <= 16 else 4
-    fits = 34816 + 2 * cfg["t_gsw"] * (2048 * es + 256) <= 80 * 1024
+    # the kernel is used while two workgroups fit a CU: 34 KiB + 2 t_live (2048 ES + 256) bytes of LDS <= 80 KiB, t_live = the
+    # digits that can be non-zero below Q (56 bits): 7 of t_gsw = 8, 8 of 9, 12 of 14 (FoldDesc::t_live)
+    bits = o.get_bits_per(cfg["t_gsw"])
+    es = 1 if bits <= 8 else 2 if bits <= 16 else 4
+    t_live = min(cfg["t_gsw"], -(-56 // bits))
+    fits = 34816 + 2 * t_live * (2048 * es + 256) <= 80 * 1024
     taken = sp.paths_taken()
     assert ("fold_wave" in taken) == fits, (taken, es, fits)
-    assert resp == o.process_query(pp, q, db)
+    expect = o.process_query(pp, q, db)
+    assert resp == expect
+    if t_live < cfg["t_gsw"]:        # the same query with the dead digits transformed as well (what rounds 2-4 did)
+        monkeypatch.setenv("SPIRAL_FOLD_SKIP_DEAD_DIGITS", "0")
+        p0 = sp.Params(cfg)
+        assert sp.process_query(p0, sp.PublicParameters.deserialize(p0, pp), q, sp.Database(p0).load(db)) == expect
