@@ -293,9 +293,8 @@ size_t sp_server_private_read_json_bound(const sp_server_t*, int n_queries); /* 
 /* Stand-alone timed sweep for the roofline measurement: issues the db-sweep launches of one query over `db`
  * (the same kernel and launch shapes sp_process_query uses) `iters` times with the query slice of `q`, HIP events
  * on the launch stream around the whole batch; returns average milliseconds per kernel launch in *ms_per_launch.
- * sp_sweep_launches() = kernel launches per query sweep (a wide single-GPU database is swept one launch per plane --
- * with SPIRAL_PIPE_SPLIT one per half plane: the 128-column chunks of even and of odd index -- so that the from_ntt and
- * the fold of what has been swept overlap the rest of the sweep; 1 otherwise). */
+ * sp_sweep_launches() = kernel launches per query sweep (a wide single-GPU database is swept one launch per plane, so
+ * that the from_ntt and the fold of what has been swept overlap the rest of the sweep; 1 otherwise). */
 int sp_sweep_launches(const sp_params_t*, const sp_db_t*);
 int sp_bench_sweep(sp_query_t* q, const sp_db_t* db, int iters, float* ms_per_launch);
 /* per_plane_launches: 1 = one launch per plane (what sp_query_sweep_scatter_plane issues), 0 = one launch,

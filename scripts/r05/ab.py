@@ -56,8 +56,21 @@ def main():
         for k in names:
             sp.lib().sp_debug_set(k.encode(), C.c_long(over.get(k, v.get(k, DEFAULTS.get(k, 0)))))
 
+    only_batch = os.environ.get("ONLY_BATCH") == "1"
     for v in variants:
         set_all(v)
+        if only_batch:
+            outs = sp.process_query_batch(p, pp, qs, db)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(6):
+                sp.process_query_batch(p, pp, qs, db)
+            torch.cuda.synchronize()
+            bt = (time.perf_counter() - t0) / 6
+            shab = hashlib.sha256(outs[0]).hexdigest()[:12]
+            ref = ref or shab
+            print("%-36s | batch%d %.2f ms = %.1f q/s | %s" % (v or "baseline", B, bt * 1e3, B / bt, "ok" if shab == ref else "RESPONSE CHANGED"), flush=True)
+            continue
         qps, st, sha = single(p, pp, qs, db, steps)
         set_all(v, pipeline=0)
         qps0, st0, sha0 = single(p, pp, qs, db, 6)

@@ -188,7 +188,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
-                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles"};
+                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -1001,16 +1001,24 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     drained += count;
   };
   size_t prev_group = 0;
-  int rc = guarded([&] {
+  int start = 0;   // first query not yet answered (a retry after an out-of-memory resumes here)
+  auto run_groups = [&] {
     check_device(db->device);
-    for (int g0 = 0; g0 < batch; g0 += group_max) {
+    for (int g0 = start; g0 < batch; g0 += group_max) {
       const int B = std::min(group_max, batch - g0);
       if (all_qs.size() > prev_group) drain(all_qs.size() - prev_group);  // keep only the previous group in flight
-      // 1. expand every query of the group on its own stream
+      // 1. expand every query of the group on its own stream.  (r05: the sixteen expansions of a group are 8-10 of a step's 49 ms
+      // and looked like a launch-rate problem -- 1,600 small launches, 1.5 kernels in flight.  They are not: enqueued by 1, 2, 4 or
+      // 8 host threads, on 4, 8 or 16 hardware queues, or recorded and issued as ONE chain of ~100 table launches for the whole
+      // group, they take the same time -- 0.5 ms of a query's expansion is transforms that fill the chip (320 k forward NTTs, more
+      // than its fold has).  profiles/r05_batch16_step_timeline.md, r05_batch_expand.md; scripts/archive/r05_batch_expand/.)
       const size_t first = all_qs.size();
       for (int i = 0; i < B; i++) {
         sp_query_t* q = sp_query_begin(h, pps[g0 + i], queries[g0 + i], query_lens[g0 + i]);
-        if (!q) throw ArgError(g_last_error);
+        if (!q) {
+          if (g_last_rc == SP_E_OOM) throw OomError(g_last_error);   // (reported by status: the caller retries in smaller groups)
+          throw ArgError(g_last_error);
+        }
         all_qs.push_back(q);
         q->ws->ensure_sweep();
       }
@@ -1055,9 +1063,28 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       prev_group = (size_t)B;
     }
     drain(all_qs.size());
-  });
-  if (rc != SP_OK) {  // let whatever was queued drain before the workspaces go back to the pool
+  };
+  auto abandon = [&] {  // let whatever was queued drain before the workspaces go back to the pool
     for (auto* q : all_qs) (void)hipStreamSynchronize(q->ws->stream);
+    for (auto* q : all_qs) sp_query_free(q);
+    all_qs.clear();
+    prev_group = 0;
+    prev_pass = nullptr;
+  };
+  int rc = guarded(run_groups);
+  if (rc == SP_E_OOM && group_max > SWEEP_BATCH_MAX) {
+    // no memory for the workspaces of two groups of 16 beside the database (the hipMemGetInfo estimate above is rough): give
+    // the in-flight queries' workspaces back and answer the rest in groups of 8.  Responses already copied out stay.
+    abandon();
+    (void)hipGetLastError();
+    start = (int)drained;
+    group_max = SWEEP_BATCH_MAX;
+    rc = guarded(run_groups);
+  }
+  if (rc != SP_OK) {
+    const std::string first_error = g_last_error;
+    abandon();
+    g_last_error = first_error;
   }
   for (auto* q : all_qs) sp_query_free(q);
   return rc;

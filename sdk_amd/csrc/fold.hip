@@ -532,7 +532,12 @@ void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   // fold_variant: 5 (default) = k_fold_wave where two workgroups fit a CU's LDS, else the cooperative kernels;
-  // 3 = k_fold_fused2 (two cooperative transforms in flight, even t_gsw); 0 = k_fold_fused (one)
+  // 3 = k_fold_fused2 (two cooperative transforms in flight, even t_gsw); 0 = k_fold_fused (one).
+  // (r05 built and removed a variant 6, k_fold_wave8: TWO steps per eight-wave workgroup, the work of a step split by (modulus,
+  // ciphertext row) -- 7 forward transforms per wave instead of 8, one reduction and five barriers per step instead of two and
+  // twelve, nothing parked in global memory.  6 % fewer vector instructions, 43 % fewer LDS instructions, byte-identical -- and
+  // exactly as fast alone (241.1 vs 242.5 us per launch), slower beside the sweep, whose resident wave per SIMD leaves no room
+  // for an eight-wave workgroup: profiles/r05_fold_wave8.md, scripts/archive/r05_fold_wave8/.)
   const int variant = (int)tunable("fold_variant", FOLD_VARIANT_DEFAULT);
   const dim3 grid(d.half, d.planes), block(256);
   if (variant == 5 && d.mats_w && d.bits <= 28) {  // (wider digits never reach a fused kernel: fused_fold_supported)

@@ -56,7 +56,8 @@ enum PathBit : u64 {
   PATH_FROM_SWEEP_WAVE = 1ull << 26,  // (retired: k_from_sweep_wave)
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
   PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
-  PATH_SWEEP_MFMA2 = 1ull << 29       // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
+  PATH_SWEEP_MFMA2 = 1ull << 29,      // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
+  PATH_FOLD_WAVE8 = 1ull << 30        // (retired in the round that built it: k_fold_wave8, profiles/r05_fold_wave8.md)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).

@@ -468,7 +468,16 @@ bool sweep_batch_wants_mfma(const SweepBatchDesc& d) {
          (d.batch <= SWEEP_BATCH_MAX || tunable("batch_mfma_tiles", 2) >= 2);
 }
 int sweep_batch_group_max(int num_per, int nj) {
-  return mfma_shape_ok(num_per, nj) && tunable("batch_mfma_tiles", 2) >= 2 ? SWEEP_GROUP_MAX : SWEEP_BATCH_MAX;
+  // groups of 9 .. 16 exist only as the two-tile matrix-core pass: with batch_mfma_min above 8 a group of 9 would take the
+  // VALU kernel, which stops at 8; and the device has to offer both tiles' z-rows of LDS to one workgroup
+  if (!mfma_shape_ok(num_per, nj) || tunable("batch_mfma_tiles", 2) < 2 || tunable("batch_mfma_min", 4) > SWEEP_BATCH_MAX + 1)
+    return SWEEP_BATCH_MAX;
+  int dev = 0, lds_optin = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds_optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return SWEEP_BATCH_MAX;
+  }
+  return (size_t)lds_optin >= (size_t)nj * 128 * 2 ? SWEEP_GROUP_MAX : SWEEP_BATCH_MAX;
 }
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
   d.use_mfma = 0;
@@ -524,12 +533,11 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
     const int steps = d.nj >> 4;
 #define SP_MFMA2(NB_)                                                                                                  \
   {                                                                                                                    \
-    static thread_local size_t allowed = 0;  /* (more than 64 KiB of dynamic LDS: raised once per thread and size) */   \
-    if (lds2 > allowed) {                                                                                              \
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB_, 1, 0, 2>),                      \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);                                \
-      allowed = lds2;                                                                                                  \
-    }                                                                                                                  \
+    /* more than 64 KiB of dynamic LDS: the limit belongs to the function ON THE CURRENT DEVICE, so it is raised on every */ \
+    /* launch (a cached "already raised" would be wrong after sp_set_device; the call costs a microsecond) and checked    */ \
+    if (lds2 > 65536)                                                                                                  \
+      HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB_, 1, 0, 2>),                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                           \
     hipLaunchKernelGGL((k_sweep_mfma_batch<NB_, 1, 0, 2>), grid, dim3(256), lds2, s, T, m);                            \
   }
     if (steps % 8 == 0) SP_MFMA2(8) else if (steps % 4 == 0) SP_MFMA2(4) else SP_MFMA2(2)
@@ -539,7 +547,7 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
   }
   const size_t lds = (size_t)d.nj * 128;  // one z-row of the group's query digit table
   if (lds > 65536)
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<2, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   // ring of 2 load buffers (one 16-row step ahead, 180 VGPRs); a ring of 4 measured the same +-2 % at 236 VGPRs (r03)
   hipLaunchKernelGGL((k_sweep_mfma_batch<2, 2>), grid, dim3(256), lds, s, T, m);
   launched(PATH_SWEEP_BATCH | PATH_SWEEP_MFMA, "k_sweep_mfma_batch");

@@ -220,6 +220,8 @@ inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
 inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = (size_t)1 << 35; *tot = (size_t)1 << 36; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
+enum hipDeviceAttribute_t { hipDeviceAttributeSharedMemPerBlockOptin = 97 };
+inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }  // gfx950: 160 KiB of LDS per workgroup
 hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host);
 template <typename T>
 inline hipError_t hipMalloc(T** p, size_t bytes) { return emu_malloc((void**)p, bytes, false); }
