@@ -147,30 +147,62 @@ def cpu_model():
     return "unknown"
 
 
+def cpu_quota_cpus():
+    """CPUs' worth of time the cgroup grants this process per period (cgroup v2 cpu.max, v1 cfs quota); None = unlimited.
+    The GPU boxes of round 5 show 256 logical CPUs and allow 16: a team of 128 runs for a fraction of each scheduler period
+    and is parked for the rest, which is what made 32 threads "faster" than 64 in round 4's scan."""
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else q / per
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(cfg_name, cfg):
     """CPU restatement of the reference (oracle/, kind "port") timed on this host, bounded sample, two modes:
     faithful = spiral-rs's own threading (server.rs:682-694: the sweep and the fold of an instance run on ONE thread,
                expansion uses the rayon loops); all_core = lib/server's shape (AVX2 u64-lane sweep,
                lib/server/src/compute/dot_product.rs:59-95, every core offered: z-rows of the sweep and subtrees of the
                fold spread over the threads, lib/server/src/server.rs:53-55).  C1 (configs[0]) is also timed in full.
-    EVERY STAGE is timed with its own best team out of {all logical CPUs, 1/2, 1/4, 1/8} (`team_per_stage`; r03 chose
-    one team by the sweep alone and ran the expansion and the fold 2x slower than r02 with it): the all_core value is the
-    sum of the per-stage minima, `cores` the largest team any stage used."""
+    EVERY STAGE is timed with its own best team (`team_per_stage`); the all_core value is the sum of the per-stage minima,
+    `cores` the largest team any stage used.  r05: (1) the candidates are built around what the process is ALLOWED to use --
+    the cgroup's CPU quota (`cpu_quota_cpus`), not the count of logical CPUs it may be scheduled on; (2) every candidate runs
+    for at least 0.6 s of wall clock, i.e. several scheduler periods: a 5-ms trial of 128 threads fits into one period's
+    quota and measures a burst the process cannot sustain (611 GB/s of sweep on these boxes, profiles/r05_cpu_baseline.md);
+    (3) threads are bound one per core and spread over the sockets (OMP_PLACES=cores, OMP_PROC_BIND=spread, set before the
+    OpenMP runtime loads) and the restatement's large temporaries come from malloc arenas instead of mmap/munmap per call
+    (oracle.orc_tune_allocator)."""
     import oracle
     max_threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    quota = cpu_quota_cpus()
     N = 2048
-    cands = sorted({max(1, max_threads // d) for d in (8, 4, 2, 1)}) if max_threads >= 8 else [max_threads]
+    if quota is not None and quota < max_threads:
+        qn = max(1, int(np.ceil(quota)))
+        cands = sorted({t for t in (max(1, qn // 2), qn, 2 * qn, 4 * qn) if t <= max_threads})
+    else:
+        cands = sorted({max(1, max_threads // d) for d in (8, 4, 2, 1)}) if max_threads >= 8 else [max_threads]
     rng = np.random.default_rng(5)
+    MIN_TRIAL_S = float(os.environ.get("SPIRAL_CPU_TRIAL_SECONDS", "0.6"))
 
     def scan(fn):
-        """fn(team) timed under every candidate team, ascending; stops once a larger team is 1.5x slower than the best
-        so far (256 threads are 40x slower than 128 on the sweep of a 2 x 64-core SMT host).  -> (best team, {team: s})"""
+        """fn(team) under every candidate team, ascending, each repeated until MIN_TRIAL_S of wall clock have passed (the
+        sustained rate under a CPU quota, not a burst); stops once a larger team is 1.5x slower than the best so far.
+        -> (best team, {team: seconds per call})"""
         times, best = {}, None
         for t in cands:
             oracle.set_threads(t)
-            t0 = time.time()
-            fn(t)
-            times[t] = time.time() - t0
+            fn(t)                                   # thread-pool warm-up at this team size (not timed)
+            calls, t0 = 0, time.time()
+            while calls == 0 or time.time() - t0 < MIN_TRIAL_S:
+                fn(t)
+                calls += 1
+            times[t] = (time.time() - t0) / calls
             if best is None or times[t] < times[best]:
                 best = t
             elif times[t] > 1.5 * times[best]:
@@ -224,10 +256,11 @@ def cpu_baseline(cfg_name, cfg):
         oracle.set_threads(team_s)
         if team_s != max_threads:      # re-place the pages for the team that will actually run
             dbs = oracle.words_first_touch(nz, num_per * dim0)
-        t0 = time.time()
-        for _ in range(reps):
+        passes, t0 = 0, time.time()
+        while passes < reps or (not full and time.time() - t0 < MIN_TRIAL_S):   # sampled: several scheduler periods' worth
             oracle.sweep_rows_avx2(dbs, v_reg[:nz * dim0 * 2], nz, dim0, num_per)
-        t_sweep_all = (time.time() - t0) * (1 if full else (N / nz) * planes)
+            passes += 1
+        t_sweep_all = (time.time() - t0) / passes * (reps if full else (N / nz) * planes)
         del dbs
         # ---- fold: a 2^k-leaf subtree (from_ntt of the leaves + 2^k - 1 fold steps), scaled by step count
         k1 = o.db_dim_2 if full else min(o.db_dim_2, 5)
@@ -245,6 +278,20 @@ def cpu_baseline(cfg_name, cfg):
                 o.from_ntt_fold_parallel(cts, v_fold[:ka * w], v_neg[:ka * w], nu=ka, classes=t)
         team_f, scan_f = scan(fold_all)
         t_fold_all = scan_f[team_f] * (1 if full else (num_per / (1 << ka)) * planes)
+        # the same two transform-heavy stages with the reference's AVX2 bodies of ntt_forward / ntt_inverse / multiply
+        # (ntt.rs:115-210, 260-365; poly.rs:407-481; oracle.avx2_bodies: what a `-C target-cpu=native` build of spiral-rs
+        # runs -- same residues, tests/test_oracle_avx2_bodies.py), each at its best team
+        def timed(fn, team):
+            oracle.set_threads(team)
+            fn(team)
+            calls, t0 = 0, time.time()
+            while calls == 0 or time.time() - t0 < MIN_TRIAL_S:
+                fn(team)
+                calls += 1
+            return (time.time() - t0) / calls
+        with oracle.avx2_bodies():
+            t_expand_avx2 = timed(expand, team_e)
+            t_fold_avx2 = timed(fold_all, team_f) * (1 if full else (num_per / (1 << ka)) * planes)
         oracle.set_threads(max_threads)
         if full:
             how = ("every z-row of all %d planes and the whole fold tree of every plane executed (random residues as "
@@ -257,26 +304,36 @@ def cpu_baseline(cfg_name, cfg):
         return {"config": name, "sampled": not full,
                 "faithful_qps": 1.0 / (t_expand + t_sweep_1 + t_fold_1),
                 "all_core_qps": 1.0 / (t_expand + t_sweep_all + t_fold_all),
+                "all_core_avx2_ntt_qps": 1.0 / (t_expand_avx2 + t_sweep_all + t_fold_avx2),
                 "seconds": {"expand": t_expand, "sweep_1thread": t_sweep_1, "fold_1thread": t_fold_1,
-                            "sweep_all_core": t_sweep_all, "fold_all_core": t_fold_all},
+                            "sweep_all_core": t_sweep_all, "fold_all_core": t_fold_all,
+                            "expand_avx2_ntt": t_expand_avx2, "fold_all_core_avx2_ntt": t_fold_avx2},
                 "team_per_stage": {"expand": team_e, "sweep": team_s, "fold": team_f},
                 "team_scan_seconds": {"expand": {str(k): v for k, v in sorted(scan_e.items())},
                                       "sweep_1GiB_trial": {str(k): v for k, v in sorted(scan_s.items())},
                                       "fold": {str(k): v for k, v in sorted(scan_f.items())}},
                 "sample": how}
 
+    def cands_global():
+        return list(cands)
+
     main = one(cfg_name, cfg, full=False)
     extra = [one(k, CONFIGS[k], full=True) for k in ("c1", "p2")] if cfg_name not in ("c1", "p2", "fast") else []
     return {
-        "value": main["all_core_qps"], "unit": "queries/s", "cores": max(main["team_per_stage"].values()), "kind": "port",
+        "value": max(main["all_core_qps"], main["all_core_avx2_ntt_qps"]), "unit": "queries/s", "cores": max(main["team_per_stage"].values()), "kind": "port",
         "host_cpus": os.cpu_count(), "cpu_model": cpu_model(),
+        # what the cgroup lets the process use (CPUs' worth of time per scheduler period; None = no quota), and the teams tried
+        "cpu_quota_cpus": cpu_quota_cpus(), "teams_tried": cands_global(),
         "team_per_stage": main["team_per_stage"], "team_scan_seconds": main["team_scan_seconds"],
-        "modes": {"all_core": main["all_core_qps"], "faithful": main["faithful_qps"]},
+        "modes": {"all_core": main["all_core_qps"], "all_core_avx2_ntt": main["all_core_avx2_ntt_qps"],
+                  "faithful": main["faithful_qps"]},
         "seconds_per_query": main["seconds"],
-        "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = all_core mode (AVX2 u64-lane sweep over "
-                  "z-rows as lib/server's dot_product.rs:59-95, fold subtrees in parallel; each stage with the team size "
-                  "that is fastest for it, team_per_stage); faithful mode = spiral-rs threading (sweep + fold on one thread "
-                  "per instance, server.rs:682-694). %s" % (cfg_name, main["sample"]),
+        "sample": "C++ restatement of spiral-rs (oracle/), config %s; value = the faster of all_core (AVX2 u64-lane sweep "
+                  "over z-rows as lib/server's dot_product.rs:59-95, fold subtrees in parallel, scalar transform bodies; each "
+                  "stage with the team size that sustains the best rate under this process's CPU quota, team_per_stage, "
+                  "threads bound one per core) and all_core_avx2_ntt (the same with the reference's AVX2 bodies of ntt_forward "
+                  "/ ntt_inverse / multiply, i.e. a target-cpu=native build); faithful mode = spiral-rs threading (sweep + fold "
+                  "on one thread per instance, server.rs:682-694). %s" % (cfg_name, main["sample"]),
         "unsampled": extra,
     }
 
@@ -462,6 +519,14 @@ def main():
     except (AttributeError, OSError):
         n_cpus = os.cpu_count() or 1
     os.environ.setdefault("OMP_NUM_THREADS", str(n_cpus))
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        # cpu_baseline's OpenMP teams: one place per core, threads spread over the sockets and kept there (read when an OpenMP
+        # runtime loads; binding also pins THIS thread to the first place, so never with several ranks on one host -- every
+        # rank's main thread and the RCCL helpers it spawns would share one core)
+        os.environ.setdefault("OMP_PLACES", "cores")
+        os.environ.setdefault("OMP_PROC_BIND", "spread")
+    else:
+        os.environ.setdefault("OMP_PROC_BIND", "false")
     import torch
     import torch.distributed as dist
     import sdk_amd as sp

@@ -52,11 +52,16 @@ def lib():
         # parallel loops of the restatement slower, not faster
         os.environ.setdefault("OMP_NUM_THREADS", str(min(16, os.cpu_count() or 1)))
         os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+        # (thread binding -- OMP_PLACES=cores, OMP_PROC_BIND=spread, what keeps a team's first-touched pages local on a
+        # two-socket host -- is the CALLER's choice: bench.py's cpu_baseline sets it for a single-rank run; binding pins the
+        # loading thread to one core, which a multi-rank launch or a test process must not inherit)
         so = os.path.join(_HERE, "liboracle.so")
         if not os.path.exists(so):
             build()
         _LIB = C.CDLL(so)
         L = _LIB
+        if os.environ.get("ORACLE_TUNE_ALLOCATOR", "1") != "0":
+            L.orc_tune_allocator()       # large temporaries from the arenas, not mmap / munmap per call (oracle_capi.cpp)
         L.orc_last_error.restype = C.c_char_p
         L.orc_params_new.restype = C.c_void_p
         L.orc_params_new.argtypes = [C.c_uint64] * 12 + [C.c_int]

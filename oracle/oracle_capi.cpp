@@ -6,6 +6,7 @@
 // rows*cols*crt*N u64, poly.rs:31-35, 263-265).
 // ============================================================================
 #include <immintrin.h>
+#include <malloc.h>
 #include <omp.h>
 
 #include <chrono>
@@ -128,6 +129,17 @@ int orc_set_avx2_bodies(int on) {
   const int prev = get_avx2_bodies();
   set_avx2_bodies(on);
   return prev;
+}
+// glibc hands every block above 128 KiB to mmap and gives it back with munmap: the restatement's per-call temporaries (a digit
+// matrix of 56 polynomials is 1.8 MiB) then cost a round of page faults and a trip through the process's mm lock on EVERY call,
+// which is what kept the parallel expansion and fold from scaling past 32 threads on the 256-thread host (cpu_baseline, VERDICT
+// r04).  A server would not run that way: keep large blocks in the (per-thread) arenas.  Process-wide; called once by oracle.lib().
+int orc_tune_allocator() {
+  int ok = 1;
+  ok &= mallopt(M_MMAP_THRESHOLD, 32 << 20);     // the largest value glibc accepts
+  ok &= mallopt(M_TRIM_THRESHOLD, 1 << 30);      // do not return freed arena memory to the kernel between calls
+  ok &= mallopt(M_TOP_PAD, 64 << 20);
+  return ok;
 }
 // OpenMP team size for the parallel sections that follow (cpu_baseline scans it); returns the previous maximum
 int orc_set_threads(int n) {
