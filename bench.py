@@ -769,6 +769,24 @@ def main():
         dist.all_gather(allr, pr)
         per_rank = {"step_ms": [float(x[0]) for x in allr], "sweep_standalone_ms_per_query": [float(x[1]) for x in allr],
                     "sweep_in_situ_ms_per_query": [float(x[2]) for x in allr]}
+        # what a first run on a multi-GPU node needs in its log to be diagnosable: per rank, the
+        # library's own account of its communicator (transport, RCCL version, bytes per collective, the last query's exposed
+        # exchange) in the sharded mode, the batched pass's own time and HBM fraction in the replicas mode
+        mine = {"rank": rank, "device": torch.cuda.current_device(),
+                "env": {k: v for k, v in os.environ.items() if k.startswith(("NCCL_", "RCCL_", "HSA_", "GPU_MAX_HW_QUEUES", "HIP_VISIBLE"))}}
+        if mode == "lib":
+            try:
+                mine["comm"] = comm.describe()
+            except Exception as e:          # diagnostics only
+                mine["comm"] = {"error": repr(e)[:200]}
+        if batch_pass is not None:
+            mine["batched_pass"] = {k: batch_pass[k] for k in ("kernel", "queries_per_pass", "ms_per_pass", "achieved", "frac")}
+        gathered = [None] * world
+        try:
+            dist.all_gather_object(gathered, mine)
+            per_rank["ranks"] = gathered
+        except Exception as e:
+            per_rank["ranks"] = [mine, {"error": "all_gather_object: " + repr(e)[:200]}]
 
     if rank == 0:
         q_per_step = batch * (world if replicas else 1) if mode in ("single", "replicas") else 1

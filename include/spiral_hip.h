@@ -257,10 +257,14 @@ int sp_process_queries_sharded(sp_comm_t*, const sp_params_t*, const sp_pp_t* co
 /* Allocates the communicator's exchange buffers and events for `params` now, so that no sharded query allocates
  * anything (otherwise the first query with new params does).  Not a collective. */
 int sp_comm_reserve(sp_comm_t*, const sp_params_t* params);
-/* milliseconds of the last sharded query on this rank (HIP events on the query stream): [0] the per-plane sweep
- * launches (the exchanges of the earlier planes run beside them), [1] exchange tail + local fold + all-gather,
- * [2] reserved */
+/* milliseconds of the last sharded query on this rank (HIP events): [0] the per-plane sweep launches (the exchanges of
+ * the earlier planes run beside them), [1] exchange tail + local fold + all-gather, [2] the part of the exchange that is NOT
+ * hidden behind the sweeps: last sweep launch done -> last plane's reduce-scatter done (exchange stream) */
 int sp_comm_timings(const sp_comm_t*, float* ms3);
+/* One line of JSON into buf: transport ("rccl" / "custom"), RCCL version, rank / world / device, bytes one rank sends and
+ * receives per plane reduce-scatter and in the all-gather, the three sp_comm_timings values.  For the logs of a first run on a
+ * multi-GPU node (the reference has no multi-device code; bench.py --gpus N prints it per rank). */
+int sp_comm_describe(const sp_comm_t*, char* buf, size_t cap);
 
 /* ------------------------------------------------------ request layer (lib/server's binary without the HTTP transport)
  * ServerState of lib/server/src/bin/server.rs:21-28: the params, the resident database and the

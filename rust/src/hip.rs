@@ -134,6 +134,7 @@ pub mod sys {
                                           out_len: *mut usize) -> c_int;
         pub fn sp_comm_reserve(c: *mut sp_comm_t, p: *const sp_params_t) -> c_int;
         pub fn sp_comm_timings(c: *const sp_comm_t, ms3: *mut f32) -> c_int;
+        pub fn sp_comm_describe(c: *const sp_comm_t, buf: *mut c_char, cap: usize) -> c_int;
         // ---- request layer: lib/server/src/bin/server.rs ServerState, /setup, /private-read (no HTTP)
         pub fn sp_server_create(params: *const sp_params_t, db: *const sp_db_t) -> *mut sp_server_t;
         pub fn sp_server_free(s: *mut sp_server_t);

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -59,6 +60,8 @@ struct sp_comm {
   hipStream_t stream = nullptr;   // the exchange stream: collectives are enqueued here, in the same order on every rank
   std::vector<hipEvent_t> ev_plane;
   hipEvent_t ev_x = nullptr, ev_f = nullptr, ev_g = nullptr, ev_t[3] = {nullptr, nullptr, nullptr};
+  hipEvent_t ev_rs = nullptr;     // (timing) the last plane's reduce-scatter is done, on the exchange stream
+  size_t rs_recv_bytes = 0, ag_send_bytes = 0, planes_last = 0;   // sizes of the last sharded query's collectives (sp_comm_describe)
   void* mine = nullptr;           // this rank's summed chunk of every plane: [plane][r][crt][z][ii / G] u32
   size_t mine_bytes = 0;
   void* gathered = nullptr;       // [g][plane][2][N] u64
@@ -93,7 +96,7 @@ struct sp_comm {
     if (nccl) (void)ncclCommDestroy(nccl);
     for (auto e : ev_plane)
       if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {ev_x, ev_f, ev_g, ev_t[0], ev_t[1], ev_t[2]})
+    for (hipEvent_t e : {ev_x, ev_f, ev_g, ev_t[0], ev_t[1], ev_t[2], ev_rs})
       if (e) (void)hipEventDestroy(e);
     if (mine) (void)hipFree(mine);
     if (gathered) (void)hipFree(gathered);
@@ -126,6 +129,7 @@ static sp_comm_t* comm_new(int rank, int world) {
     hip_ok(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking), "hipStreamCreate");
     for (hipEvent_t* e : {&c->ev_x, &c->ev_f, &c->ev_g}) hip_ok(hipEventCreateWithFlags(e, hipEventDisableTiming), "hipEventCreate");
     for (auto& e : c->ev_t) hip_ok(hipEventCreate(&e), "hipEventCreate");
+    hip_ok(hipEventCreate(&c->ev_rs), "hipEventCreate");
   } catch (...) {
     delete c;
     throw;
@@ -179,6 +183,25 @@ void sp_comm_free(sp_comm_t* c) { delete c; }
 int sp_comm_rank(const sp_comm_t* c) { return c ? c->rank : -1; }
 int sp_comm_world(const sp_comm_t* c) { return c ? c->world : 0; }
 void* sp_comm_stream(sp_comm_t* c) { return c ? (void*)c->stream : nullptr; }
+
+// One line of JSON about the communicator and the last sharded query's collectives, for the first run on a multi-GPU node to be
+// diagnosable from its log: transport, RCCL version, what one rank sends and receives per plane and per query.
+int sp_comm_describe(const sp_comm_t* c, char* buf, size_t cap) {
+  if (!c || !buf || cap == 0) return SP_E_ARG;
+  int ver = 0;
+  if (!c->custom && ncclGetVersion(&ver) != ncclSuccess) ver = -1;
+  const int G = c->world;
+  const int n = snprintf(buf, cap,
+                         "{\"transport\": \"%s\", \"rccl_version\": %d, \"rank\": %d, \"world\": %d, \"device\": %d, "
+                         "\"planes\": %zu, \"reduce_scatter_u32\": {\"per_plane_send_bytes\": %zu, \"per_plane_recv_bytes\": %zu, "
+                         "\"per_query_link_bytes_ring\": %zu}, \"all_gather_u64\": {\"send_bytes\": %zu, \"recv_bytes\": %zu}, "
+                         "\"last_query_ms\": {\"sweeps_with_overlapped_exchange\": %.4f, \"tail_fold_gather\": %.4f, "
+                         "\"exposed_exchange_after_last_sweep\": %.4f}}",
+                         c->custom ? "custom" : "rccl", ver, c->rank, G, c->device, c->planes_last, c->rs_recv_bytes * (size_t)G,
+                         c->rs_recv_bytes, c->planes_last * c->rs_recv_bytes * (size_t)(G - 1), c->ag_send_bytes,
+                         c->ag_send_bytes * (size_t)G, (double)c->ms[0], (double)c->ms[1], (double)c->ms[2]);
+  return n > 0 && (size_t)n < cap ? SP_OK : SP_E_ARG;
+}
 
 int sp_comm_timings(const sp_comm_t* c, float* ms3) {
   if (!c || !ms3) return SP_E_ARG;
@@ -250,6 +273,10 @@ void sharded_sweeps(sp_comm_t* c, const sp_db_t* shard, ShardedRun& r, bool time
       throw Fail{SP_E_HIP, "custom reduce_scatter_u32 failed"};
   }
   if (timed) hip_ok(hipEventRecord(c->ev_t[1], r.main), "hipEventRecord");
+  if (timed) hip_ok(hipEventRecord(c->ev_rs, c->stream), "hipEventRecord");
+  c->rs_recv_bytes = chunk * sizeof(uint32_t);
+  c->ag_send_bytes = r.local_words * sizeof(uint64_t);
+  c->planes_last = r.planes;
   hip_ok(hipEventRecord(c->ev_x, c->stream), "hipEventRecord");
   hip_ok(hipStreamWaitEvent(r.main, c->ev_x, 0), "hipStreamWaitEvent");
 }
@@ -299,6 +326,8 @@ int sp_process_query_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* 
     // [0] sweep launches incl. the exchanges overlapped with them, [1] exchange tail + local fold + all-gather
     (void)hipEventElapsedTime(&c->ms[0], c->ev_t[0], c->ev_t[1]);
     (void)hipEventElapsedTime(&c->ms[1], c->ev_t[1], c->ev_t[2]);
+    // [2] what of the exchange is NOT hidden behind the sweeps: last sweep launch done -> last plane's reduce-scatter done
+    if (hipEventElapsedTime(&c->ms[2], c->ev_t[1], c->ev_rs) != hipSuccess || c->ms[2] < 0) c->ms[2] = 0;
     note_transport(c);
   });
   if (r.q) {
@@ -342,6 +371,7 @@ int sp_process_queries_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t
     cur = ShardedRun{};
     (void)hipEventElapsedTime(&c->ms[0], c->ev_t[0], c->ev_t[1]);
     (void)hipEventElapsedTime(&c->ms[1], c->ev_t[1], c->ev_t[2]);
+    if (hipEventElapsedTime(&c->ms[2], c->ev_t[1], c->ev_rs) != hipSuccess || c->ms[2] < 0) c->ms[2] = 0;
     note_transport(c);
   });
   for (ShardedRun* r : {&cur, &nxt})

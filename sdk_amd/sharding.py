@@ -263,6 +263,15 @@ class Comm:
         _chk(lib().sp_comm_timings(C.c_void_p(self.h), t))
         return list(t)
 
+    def describe(self):
+        """sp_comm_describe: transport, RCCL version, collective sizes and the last query's timings, as a dict"""
+        import ctypes as C
+        import json
+        from .spiral import _chk, lib
+        buf = C.create_string_buffer(2048)
+        _chk(lib().sp_comm_describe(C.c_void_p(self.h), buf, C.c_size_t(len(buf))))
+        return json.loads(buf.value.decode())
+
     def process_query(self, params, pp, query, shard):
         """sp_process_query_sharded: the response bytes on rank 0, b"" elsewhere"""
         import ctypes as C

@@ -49,6 +49,11 @@ def main():
     sp.paths_taken()
     outs = [comm.process_query(p, gpp, qq, shard) for qq in (q, q2, q)]
     assert "rccl_in_library" in sp.paths_taken()
+    info = comm.describe()      # sp_comm_describe: what bench.py --gpus N logs per rank
+    assert info["world"] == world and info["rank"] == rank and info["transport"] == "rccl" and info["planes"] == o.instances * o.n * o.n
+    assert info["reduce_scatter_u32"]["per_plane_recv_bytes"] == 4 * 2048 * o.num_per // world * 4
+    assert info["all_gather_u64"]["send_bytes"] == info["planes"] * 2 * 2048 * 8
+    assert info["last_query_ms"]["exposed_exchange_after_last_sweep"] >= 0
     listed = comm.process_queries(p, gpp, [q, q2, q, q2], shard)
     comm.barrier()
     comm.free()

@@ -67,6 +67,10 @@ def main():
     assert "rccl_in_library" in sp.paths_taken()
     comm.barrier()
     assert len(comm.timings()) == 3
+    info = comm.describe()      # sp_comm_describe: the real RCCL's version, the sizes of this query's collectives
+    assert info["transport"] == "rccl" and info["rccl_version"] > 20000 and info["world"] == 1, info
+    assert info["reduce_scatter_u32"]["per_plane_recv_bytes"] > 0 and info["last_query_ms"]["sweeps_with_overlapped_exchange"] > 0, info
+    print("comm:", info)
     comm.free()
 
     # reduce: sweep -> dist.reduce -> finish

@@ -31,6 +31,10 @@ struct emu_nccl_comm {
 
 static size_t elem(ncclDataType_t t) { return t == ncclUint64 ? 8 : 4; }
 
+ncclResult_t ncclGetVersion(int* version) {
+  *version = 0;   // the stand-in: not an RCCL
+  return ncclSuccess;
+}
 const char* ncclGetErrorString(ncclResult_t r) {
   switch (r) {
     case ncclSuccess: return "no error";

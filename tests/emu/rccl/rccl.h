@@ -20,6 +20,7 @@ struct emu_nccl_comm;
 typedef emu_nccl_comm* ncclComm_t;
 
 const char* ncclGetErrorString(ncclResult_t r);
+ncclResult_t ncclGetVersion(int* version);
 ncclResult_t ncclGetUniqueId(ncclUniqueId* id);
 ncclResult_t ncclCommInitRank(ncclComm_t* c, int nranks, ncclUniqueId id, int rank);
 ncclResult_t ncclCommDestroy(ncclComm_t c);

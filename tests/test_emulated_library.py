@@ -117,15 +117,16 @@ def test_host_pipeline_survives_adversarial_stream_orders(emulated, policy):
     _run(emulated, STREAM_SUBSET, {"SPIRAL_EMU_STREAMS": policy}, at_least=4)
 
 
-@pytest.mark.parametrize("world,name,streams", [(2, "narrow", "starve:2"), pytest.param(4, "packed", "eager", marks=long_only)])
+@pytest.mark.parametrize("world,name,streams", [(2, "narrow", "starve:2"), (4, "packed", "eager"), (8, "narrow", "eager")])
 def test_row_sharded_query_over_process_ranks(emulated, tmp_path, world, name, streams):
     """The library's own multi-GPU path (sp_comm_create / sp_process_query_sharded / sp_process_queries_sharded: comm.cpp's
     reduce-scatter per plane, distributed fold, all-gather) with the ranks as PROCESSES: RCCL is replaced by an independent
     statement of its two collectives over shared memory (tests/emu/emu_rccl.cpp).  On hardware this call sequence has only ever
-    met a real RCCL at world size 1.  (`streams`: the order in which the queued operations of a rank's streams run, see
+    met a real RCCL at world size 1.  Eight ranks -- the north star's G -- and the PACKED database at four are part of the default
+    suite since round 5 (~20 s each).  (`streams`: the order in which the queued operations of a rank's streams run, see
     test_host_pipeline_survives_adversarial_stream_orders -- comm.cpp orders its two streams with five events per query.)"""
     id_file = str(tmp_path / "comm_id")
-    env = dict(os.environ, SPIRAL_HIP_LIB=emulated, SPIRAL_EMU_THREADS="2", SPIRAL_EMU_STREAMS=streams)
+    env = dict(os.environ, SPIRAL_HIP_LIB=emulated, SPIRAL_EMU_THREADS="2" if world <= 4 else "1", SPIRAL_EMU_STREAMS=streams)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_emu_sharded_rank.py"), str(r), str(world), id_file, name],
                               cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
