@@ -739,10 +739,15 @@ def main():
         for r in runs:
             r.free()
         N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
-        pass_bytes = db.device_bytes() + len(runs) * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
-        batch_pass = {"kernel": "k_sweep_mfma_batch<8, 1, 0, 2> (two query tiles)" if "sweep_batch_mfma_two_tiles" in taken else
+        # the 9 .. 16-query pass reads the digit-planar copy of the database where it exists: 8 bytes per word instead of 7
+        planar = "sweep_batch_planar" in taken
+        pass_db_bytes = db.device_bytes() * 8 // 7 if planar else db.device_bytes()
+        pass_bytes = pass_db_bytes + len(runs) * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
+        batch_pass = {"kernel": "k_sweep_planar<4, 2, 0, 1, 8> (two query tiles, digit-planar database)" if planar else
+                                "k_sweep_mfma_batch<8, 1, 0, 2> (two query tiles)" if "sweep_batch_mfma_two_tiles" in taken else
                                 "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % len(runs),
                       "queries_per_pass": len(runs), "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
+                      "database_format": "digit-planar copy, 8 bytes per word (sweep_planar.hpp)" if planar else "PACKED, 7 bytes per word",
                       "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                       "note": "one pass over the whole resident database for the whole group (sp_bench_sweep_batch, HIP events "
                               "on the launch stream): PACKED database + %d query slices + %d x u32 outputs; the outputs "

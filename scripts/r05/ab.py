@@ -16,7 +16,7 @@ import torch
 import bench
 import sdk_amd as sp
 
-DEFAULTS = {"pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256, "fold_skip_dead_digits": 1, "fold_variant": 5,
+DEFAULTS = {"batch_planar": 1, "pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256, "fold_skip_dead_digits": 1, "fold_variant": 5,
             "batch_in_flight": 3, "expand_split": -1}
 
 

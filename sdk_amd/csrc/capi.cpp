@@ -128,6 +128,39 @@ void check_device(int dev) {
 
 }  // namespace
 
+// The digit-planar copy of a PACKED, unsharded database (sweep_planar.hpp): what the 9 .. 16-query pass reads.  Built on first
+// use (one gather pass over the PACKED units), only when the device has the room for a second copy (8 bytes per word) beside
+// the workspaces of two groups; nullptr = keep to the PACKED kernels.
+const unsigned char* sp_db::ensure_planar(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(mu);
+  if (tunable("batch_planar", 1) == 0) return nullptr;   // (run-time switch: an existing copy is kept, not used)
+  if (planar_state == 1) return reinterpret_cast<const unsigned char*>(planar.p);
+  if (planar_state < 0) return nullptr;
+  const Params& p = params->p;
+  planar_state = -1;
+  if (!packed || sparse || num_shards != 1 || col_G != 1 || !sweep_planar_shape_ok(np_local, nj)) return nullptr;
+  const size_t bytes = sweep_planar_bytes((int)p.planes(), np_local, nj);
+  if (planar.n * sizeof(u64) < bytes) {
+    size_t fr = 0, tot = 0;
+    // room for the copy + the workspaces of two groups of 16 (three times the first-dimension output each, as the group planner
+    // estimates) + 4 GiB
+    const size_t per_ws = (size_t)3 * p.planes() * 4 * POLY_LEN * (size_t)np_local * sizeof(u32);
+    if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + 32 * per_ws + ((size_t)4 << 30)) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    try {
+      planar.alloc((bytes + 7) / 8);
+    } catch (const OomError&) {
+      return nullptr;
+    }
+  }
+  launch_packed_to_planar(reinterpret_cast<unsigned char*>(planar.p), words.p, (int)p.planes(), np_local, nj, s);
+  HIP_CHECK(hipStreamSynchronize(s));
+  planar_state = 1;
+  return reinterpret_cast<const unsigned char*>(planar.p);
+}
+
 // present items by column + the expansion schedule pruned to the rows that hold items: rebuilt when a NEW key has been
 // added (the plan only when a new row became occupied); overwrites keep the snapshot
 std::shared_ptr<const sp_db::SparseIndex> sp_db::ensure_sparse_index() {
@@ -188,7 +221,7 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
-                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8"};
+                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8", "sweep_batch_planar"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -340,6 +373,7 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     need(plane >= 0 && (size_t)plane < p.planes() && z0 >= 0 && nz >= 0 && (size_t)(z0 + nz) <= POLY_LEN, "bad plane / z range");
     check_device(d->device);
     std::lock_guard<std::mutex> lk(d->mu);
+    d->drop_planar();
     const size_t row_words = p.num_per() * p.dim0();
     const size_t max_stage = ((size_t)64 << 20) / 8;  // 64 MiB staging
     const int zs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, max_stage / row_words));
@@ -377,6 +411,7 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
     need(d && (file || file_len == 0), "null argument");
     need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
+    d->drop_planar();
     sp_params* h = const_cast<sp_params*>(d->params);
     const Params& p = h->p;
     DeviceState& D = h->device_state();
@@ -435,6 +470,7 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
   return guarded([&] {
     need(d && (data || len == 0), "null argument");
     check_device(d->device);
+    d->drop_planar();
     sp_params* h = const_cast<sp_params*>(d->params);
     const Params& p = h->p;
     need(item_idx < p.num_items(), "item index out of range");
@@ -523,6 +559,7 @@ int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
     need(d != nullptr, "null db");
     need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
+    d->drop_planar();
     const Params& p = d->params->p;
     launch_db_synth(d->words.p, seed, (int)p.planes(), d->np_local, (int)p.dim0(), d->j0, d->nj, d->packed, d->colmap(), 0);
     HIP_CHECK(hipDeviceSynchronize());
@@ -1044,6 +1081,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       if (sweep_batch_wants_mfma(d)) {
         W0.batch_rq.ensure(sweep_batch_rq_words(d.nj, sweep_batch_tiles(d.batch)));
         d.rq = W0.batch_rq.p;
+        if (sweep_batch_tiles(d.batch) == 2) d.planar = const_cast<sp_db_t*>(db)->ensure_planar(W0.stream);
       }
       sweep_batch_prepare(W0.D->T, d, W0.stream);
       // (a per-plane form of the pass with every query folding plane p beside the pass of plane p + 1 was measured in rounds
@@ -1150,6 +1188,7 @@ int sp_bench_sweep_batch(sp_query_t* const* qs, int batch, const sp_db_t* db, in
     if (sweep_batch_wants_mfma(d)) {
       W0.batch_rq.ensure(sweep_batch_rq_words(d.nj, sweep_batch_tiles(d.batch)));
       d.rq = W0.batch_rq.p;
+      if (sweep_batch_tiles(d.batch) == 2) d.planar = const_cast<sp_db_t*>(db)->ensure_planar(W0.stream);
     }
     TimingEvents ev;   // destroyed on every path out of here (launches and HIP_CHECK throw)
     auto pass = [&] {

@@ -57,7 +57,8 @@ enum PathBit : u64 {
   PATH_FOLD_TAIL_BATCHED = 1ull << 27,// pipelined query: the planes' small fold levels deferred and run as one batch
   PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
   PATH_SWEEP_MFMA2 = 1ull << 29,      // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
-  PATH_FOLD_WAVE8 = 1ull << 30        // (retired in the round that built it: k_fold_wave8, profiles/r05_fold_wave8.md)
+  PATH_FOLD_WAVE8 = 1ull << 30,       // (retired in the round that built it: k_fold_wave8, profiles/r05_fold_wave8.md)
+  PATH_SWEEP_PLANAR = 1ull << 31      // k_sweep_planar: the 9 .. 16-query pass over the digit-planar copy of the database
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -328,7 +329,16 @@ struct SweepBatchDesc {
   // filled by sweep_batch_prepare; use_mfma is set by it.  rq == nullptr: VALU kernel.
   u32* rq;
   int use_mfma;
+  // digit-planar copy of the same database (sweep_planar.hpp; sp_db::planar, built on the first group of more than 8 queries):
+  // the two-tile pass then runs k_sweep_planar.  nullptr: the PACKED kernels.
+  const unsigned char* planar;
 };
+// does this shape have a digit-planar form (whole 64-row blocks, the z-row's query planes in LDS, whole 128-column chunks)?
+bool sweep_planar_shape_ok(int num_per, int nj);
+size_t sweep_planar_bytes(int planes, int num_per, int nj);
+// PACKED database -> digit-planar copy (one-time, per database; planes * N * num_per * nj * 8 bytes)
+void launch_packed_to_planar(unsigned char* planar, const u64* packed, int planes, int num_per, int nj, hipStream_t s);
+void launch_sweep_planar(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);   // sweep_planar.hip
 // does this shape / group size run on the matrix cores (switch batch_mfma, default on from batch_mfma_min = 4 queries)?
 // Groups of more than SWEEP_BATCH_MAX queries exist only there.
 bool sweep_batch_wants_mfma(const SweepBatchDesc& d);

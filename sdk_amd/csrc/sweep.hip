@@ -494,14 +494,22 @@ void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
     q.dim0 = d.dim0;
     q.j0 = d.j0;
     q.nj = d.nj;
-    hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
-    launched(0, "k_query_digits");
+    if (d.planar && tiles == 2) {   // same size, planar order (sweep_planar.hip)
+      launch_query_digits_planar(q, entries, s);
+    } else {
+      hipLaunchKernelGGL(k_query_digits, dim3((unsigned)((entries + 255) / 256)), dim3(256), 0, s, q);
+      launched(0, "k_query_digits");
+    }
     hipLaunchKernelGGL(k_query_offset_terms, dim3(N), dim3(256), 0, s, T, q, d.rq + (size_t)tiles * entries * 4 + (size_t)t * N * 32);
     launched(0, "k_query_offset_terms");
   }
   d.use_mfma = 1;
 }
 static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
+  if (d.planar && sweep_batch_tiles(d.batch) == 2) {
+    launch_sweep_planar(T, d, s);   // sweep_planar.hip
+    return;
+  }
   SweepMfmaDesc m{};
   m.db = d.db;
   const int tiles = sweep_batch_tiles(d.batch);

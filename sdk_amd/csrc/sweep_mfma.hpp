@@ -59,7 +59,10 @@ struct QueryDigitsDesc {
   u32* rq;
   int batch, dim0, j0, nj;
 };
-__global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
+// the same table in the order of the digit-planar pass (sweep_planar.hpp / sweep_planar.hip)
+void launch_query_digits_planar(const QueryDigitsDesc& q, size_t entries, hipStream_t s);
+// (internal linkage: this header is included by sweep.hip and, through sweep_planar.hpp, by sweep_planar.hip)
+static __global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
   const int steps = d.nj >> 4;
   const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (size_t)N * steps * 128) return;
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
 // Offset terms of the database-side digit form: off[z][crt][n] = DIGIT_OFFSET * (sum_j y_j) mod q over the nj rows of query
 // column n = 2 b + r (zero for b >= batch).  One workgroup per z: 8 threads per (crt, n) add up strided rows, then a
 // shuffle reduction; the row sum (< 2^37) and the product with DIGIT_OFFSET mod q (< 2^28) are exact in 64 bits.
-__global__ __launch_bounds__(256) void k_query_offset_terms(DevTables T, QueryDigitsDesc d, u32* off) {
+static __global__ __launch_bounds__(256) void k_query_offset_terms(DevTables T, QueryDigitsDesc d, u32* off) {
   const int z = blockIdx.x, t = threadIdx.x;
   const int combo = t >> 3, part = t & 7;      // combo = crt * 16 + n
   const int crt = combo >> 4, n = combo & 15, b = n >> 1, r = n & 1;

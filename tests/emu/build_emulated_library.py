@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 CSRC = os.path.join(ROOT, "sdk_amd", "csrc")
 BUILD = os.environ.get("SPIRAL_EMU_BUILD") or os.path.join(HERE, "_build")   # (another directory: a second tree state side by side)
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
-PRODUCT = ["params.cpp", "ntt.hip", "fold.hip", "elementwise.hip", "sweep.hip", "db.hip", "sparse.hip", "server.cpp", "capi.cpp",
+PRODUCT = ["params.cpp", "ntt.hip", "fold.hip", "elementwise.hip", "sweep.hip", "sweep_planar.hip", "db.hip", "sparse.hip", "server.cpp", "capi.cpp",
            "comm.cpp", "endpoint.cpp"]
 OWN = ["emu_runtime.cpp", "emu_streams.cpp", "emu_library.cpp", "emu_rccl.cpp"]
 FLAGS = ["-std=c++17", "-O2", "-fPIC", "-pthread", "-I" + HERE, "-I" + CSRC, "-I" + os.path.join(ROOT, "include")]

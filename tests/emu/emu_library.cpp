@@ -11,6 +11,7 @@ alignas(16) thread_local uint32_t smem_fw[LDS_ARRAY / 4];
 alignas(16) thread_local unsigned char smem_q[LDS_ARRAY];
 alignas(16) thread_local unsigned char smem[LDS_ARRAY];
 alignas(16) thread_local unsigned char smem_rq[LDS_ARRAY];
+alignas(16) thread_local unsigned char smem_pl[LDS_ARRAY];
 }  // namespace spiral
 
 typedef unsigned char* (*emu_lds_getter)();
@@ -22,6 +23,7 @@ struct RegisterLds {
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem_q; });
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem; });
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem_rq; });
+    emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem_pl; });
   }
 } g_register_lds;
 }  // namespace

@@ -1121,7 +1121,27 @@ def test_process_query_batch_two_query_tiles(sp, oracle_mod, nu_1, nu_2, B, chec
     qs = [cls[i % 2].generate_query(idxs[i], 700 + i) for i in range(B)]
     sp.paths_taken()
     resp = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
-    assert "sweep_batch_mfma_two_tiles" in sp.paths_taken()
+    taken = sp.paths_taken()
+    assert "sweep_batch_mfma_two_tiles" in taken
+    # r05: where the first dimension is whole 64-row blocks the two-tile pass reads the DIGIT-PLANAR copy of the database
+    # (k_sweep_planar, built from the PACKED words on this first call); the same call on the PACKED words must agree
+    planar = (1 << nu_1) % 64 == 0
+    assert ("sweep_batch_planar" in taken) == planar, taken
+    if planar:
+        sp.lib().sp_debug_set(b"batch_planar", C.c_long(0))
+        try:
+            gdb2 = sp.Database(p).load(db)          # (a database that has never been given a planar copy)
+            sp.paths_taken()
+            packed = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb2)
+            assert "sweep_batch_planar" not in sp.paths_taken()
+        finally:
+            sp.lib().sp_debug_set(b"batch_planar", C.c_long(1))
+        assert resp == packed
+        # a writer drops the planar copy; the next group rebuilds it from the new words
+        gdb.load(db)
+        sp.paths_taken()
+        assert sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb) == resp
+        assert "sweep_batch_planar" in sp.paths_taken()
     sp.lib().sp_debug_set(b"batch_group", C.c_long(8))
     try:
         sp.paths_taken()

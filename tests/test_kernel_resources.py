@@ -28,6 +28,10 @@ LIMITS = {
                   # the batched passes on the matrix cores: the one-tile form is clean; the two-tile form (16 queries, one wave per
                   # SIMD, 256 VGPRs + 256 AGPRs) keeps 200 bytes of scratch outside its multiply loop -- recorded, to be looked at
                   "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (200, 512)},
+    # r05: the 9 .. 16-query pass over the digit-planar copy -- one modulus per pass keeps its accumulators in the vector
+    # registers: no scratch, and the eight-wave form (two waves per SIMD) stays under 256
+    "sweep_planar.hip": {"k_sweep_planarILi4ELi2ELi0ELi1ELi8E": (0, 256), "k_sweep_planarILi2ELi2ELi0ELi1ELi8E": (0, 256),
+                         "k_sweep_planarILi4ELi2ELi0ELi1ELi4E": (0, 512), "k_sweep_planarILi2ELi2ELi0ELi1ELi4E": (0, 512)},
 }
 
 
