@@ -25,8 +25,10 @@ LIMITS = {
     "ntt.hip": {"k_from_sweep4E": (0, 256), "k_ntt_invE": (0, 128), "k_ntt_fwdE": (0, 128), "k_ntt_fwd3E": (0, 128)},
     "sweep.hip": {"k_sweep_packed_ringILi8E": (0, 256), "k_sweep_packed_ringILi4E": (0, 256), "k_sweep_packed_ringILi2E": (0, 256),
                   "k_sweep_packed_persistE": (0, 256), "k_sweep_wideE": (0, 256),
-                  # the batched passes on the matrix cores: the one-tile form is clean; the two-tile form (16 queries, one wave per
-                  # SIMD, 256 VGPRs + 256 AGPRs) keeps 200 bytes of scratch outside its multiply loop -- recorded, to be looked at
+                  # the batched passes on the matrix cores over the PACKED words: the one-tile form is clean; the two-tile form (16
+                  # queries, one wave per SIMD, 256 VGPRs + 256 AGPRs) keeps 200 bytes of scratch outside its multiply loop.  Since
+                  # r05 it is the FALLBACK of groups of 9 .. 16 (no room for the digit-planar copy, or a first dimension that is not
+                  # whole 64-row blocks); the planar pass below has none
                   "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (200, 512)},
     # r05: the 9 .. 16-query pass over the digit-planar copy -- one modulus per pass keeps its accumulators in the vector
     # registers: no scratch, and the eight-wave form (two waves per SIMD) stays under 256
