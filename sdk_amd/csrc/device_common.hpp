@@ -61,6 +61,67 @@ __device__ __forceinline__ void gs_bfly_last(u32& x, u32& y, u32 ninv, u32 ninvp
   y = w * tt - __umulhi(tt, wp) * q;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Software pipelining: with 128 accumulator registers next to a transform only two waves fit a SIMD, so nothing but
+// the code itself hides latencies.  Every table read is therefore issued one stage (or one group of butterflies)
+// before its use and pinned there with a scheduling barrier; the caller can hook its own loads and arithmetic into the
+// last stages (the fold kernel fetches its multiply-accumulate operands there and consumes finished quarters).
+// ------------------------------------------------------------------------------------------------------------------
+#define SP_SB() __builtin_amdgcn_sched_barrier(0)
+
+// B independent Cooley-Tukey butterflies issued phase by phase: left to itself the compiler emits one butterfly after
+// the other, each a chain of dependent multiplies (v_mul_hi -> v_mul_lo -> v_sub -> v_add) that a wave can only issue at
+// the dependent-operation latency; phase-wise every instruction's operands are B issue slots old.
+// LAZY range reduction: the Shoup product w y - floor(w' y / 2^32) q lies in [0, 2q) for ANY y < 2^32, so only the
+// operand that is added (x) has to be kept small enough for x + 2q not to wrap -- and with q < 2^28 a 32-bit word holds
+// 16q.  Both outputs are < x + 2q: values grow by 2q per stage.  Instead of the reference's conditional subtraction of
+// 2q in every butterfly (ntt.rs:92-103; two of nine instructions) x is reduced by 8q in two of the eleven stages only
+// (CORR; see wntt_fwd for the bounds).  The residues mod q are the same, so every canonical result is too.
+// Five instructions per butterfly instead of seven: with NEGATED twiddles nw = -w (mod 2^32; the LDS copy and the scalar
+// entries are negated once, wtw_stage / wntt_scalar_tw) the Shoup product comes out negated,
+//     nl = floor(w' y / 2^32) q - w y   (mod 2^32)   = -(w y mod q, lazily in [0, 2q)),
+// as two chained v_mad_u64_u32 (nw * y, then + qt * q; only the low 32 bits of the sum are used -- the second one is inline
+// assembly because the compiler would narrow it to v_mul_lo + v_add) in place of v_mul_lo, v_mul_lo, v_sub, and the
+// two outputs are
+//     y' = x + 2q + nl  (v_add3_u32)      x' = x - nl
+// in place of add, sub, add.  Same residues as before in every register (all arithmetic is mod 2^32).
+template <int B, bool CORR>
+__device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&nw)[B], const u32 (&wp)[B], u32 q, u32 q2) {
+  u32 qt[B], t[B];
+  u64 nl[B];
+#pragma unroll
+  for (int b = 0; b < B; b++) qt[b] = __umulhi(y[b], wp[b]);
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) nl[b] = (u64)nw[b] * y[b];
+  SP_SB();
+  if (CORR) {
+#pragma unroll
+    for (int b = 0; b < B; b++) t[b] = x[b] - 4 * q2;
+    SP_SB();
+  }
+  // (one assembly statement per four: between separate statements the compiler puts an s_nop each)
+  static_assert(B % 4 == 0, "butterfly batches come in fours");
+#pragma unroll
+  for (int b = 0; b < B; b += 4)
+    asm("v_mad_u64_u32 %0, vcc, %4, %8, %0\n\tv_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
+        "v_mad_u64_u32 %2, vcc, %6, %8, %2\n\tv_mad_u64_u32 %3, vcc, %7, %8, %3"
+        : "+v"(nl[b]), "+v"(nl[b + 1]), "+v"(nl[b + 2]), "+v"(nl[b + 3])
+        : "v"(qt[b]), "v"(qt[b + 1]), "v"(qt[b + 2]), "v"(qt[b + 3]), "s"(q)
+        : "vcc");
+  SP_SB();
+  if (CORR) {
+#pragma unroll
+    for (int b = 0; b < B; b++) x[b] = x[b] < t[b] ? x[b] : t[b];  // x - (x >= 8q ? 8q : 0)
+    SP_SB();
+  }
+#pragma unroll
+  for (int b = 0; b < B; b++) y[b] = x[b] + q2 + (u32)nl[b];
+  SP_SB();
+#pragma unroll
+  for (int b = 0; b < B; b++) x[b] = x[b] - (u32)nl[b];
+  SP_SB();
+}
 // LDS index padding.  PAD_A keeps the {tau+256k}, {256b+o+32k} and {32b+o+4k} access patterns
 // conflict-free for 4-byte accesses; PAD_B does the same for {32b+o+4k} and {8tau+k}.
 #define PAD_A(a) ((a) + (((a) >> 5) << 2))
@@ -129,42 +190,107 @@ __device__ __forceinline__ void inv_pass(u32 (&v)[8], int b, const u32* __restri
   }
 }
 
+// ---- lazy forward passes (r05): the cooperative transform with the wave transform's five-instruction butterfly ----------------
+// ct_bfly_batch keeps only the added operand small: values grow by 2q per stage and are cut back by 8q in stages 7 (distance
+// 16) and 10 (distance 2) -- bounds as in wntt_fwd: < 2q in, < 14q before either cut, < 12q after stage 11 -- and every residue
+// equals the reference's.  One pass = the three stages (two in the last pass) on the 8 elements a thread holds, for M
+// polynomials at once: the butterflies of a stage that share nothing go out as one phase-ordered batch of 4 M.
+// nw = 0 - w (negated twiddles, computed here: one instruction per twiddle, shared by M polynomials).
+template <int S, bool DO_A, int M>
+__device__ __forceinline__ void fwd_pass_lazy_m(u32 (&v)[M][8], int b, const u32* __restrict__ fw, const u32* __restrict__ fwp,
+                                                u32 q, u32 q2) {
+  constexpr bool CORR_A = (S == 4);     // stage 7: distance 4 S = 16
+  constexpr bool CORR_MID = (S == 1);   // stage 10: distance 2 S = 2
+  if (DO_A) {
+    const int i = N / (8 * S) + b;
+    const u32 nw1 = 0u - fw[i], wp1 = fwp[i];
+    u32 x[4 * M], y[4 * M], nw[4 * M], wp[4 * M];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        x[4 * m + k] = v[m][k]; y[4 * m + k] = v[m][k + 4]; nw[4 * m + k] = nw1; wp[4 * m + k] = wp1;
+      }
+    ct_bfly_batch<4 * M, CORR_A>(x, y, nw, wp, q, q2);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        v[m][k] = x[4 * m + k]; v[m][k + 4] = y[4 * m + k];
+      }
+  }
+  {
+    u32 nwh[2], wph[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int i = N / (4 * S) + 2 * b + h;
+      nwh[h] = 0u - fw[i];
+      wph[h] = fwp[i];
+    }
+    u32 x[4 * M], y[4 * M], nw[4 * M], wp[4 * M];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {   // butterfly k: h = k / 2, elements 4 h + (k % 2) and + 2
+        const int h = k >> 1, e = 4 * h + (k & 1);
+        x[4 * m + k] = v[m][e]; y[4 * m + k] = v[m][e + 2]; nw[4 * m + k] = nwh[h]; wp[4 * m + k] = wph[h];
+      }
+    ct_bfly_batch<4 * M, CORR_MID>(x, y, nw, wp, q, q2);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int h = k >> 1, e = 4 * h + (k & 1);
+        v[m][e] = x[4 * m + k]; v[m][e + 2] = y[4 * m + k];
+      }
+  }
+  {
+    u32 nwh[4], wph[4];
+#pragma unroll
+    for (int h = 0; h < 4; h++) {
+      const int i = N / (2 * S) + 4 * b + h;
+      nwh[h] = 0u - fw[i];
+      wph[h] = fwp[i];
+    }
+    u32 x[4 * M], y[4 * M], nw[4 * M], wp[4 * M];
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        x[4 * m + h] = v[m][2 * h]; y[4 * m + h] = v[m][2 * h + 1]; nw[4 * m + h] = nwh[h]; wp[4 * m + h] = wph[h];
+      }
+    ct_bfly_batch<4 * M, false>(x, y, nw, wp, q, q2);
+#pragma unroll
+    for (int m = 0; m < M; m++)
+#pragma unroll
+      for (int h = 0; h < 4; h++) {
+        v[m][2 * h] = x[4 * m + h]; v[m][2 * h + 1] = y[4 * m + h];
+      }
+  }
+}
+// < 12q (after the last lazy stage) -> canonical (ntt.rs:107-111 from the reference's < 4q)
+__device__ __forceinline__ u32 canon_from_12q(u32 x, u32 q, u32 q2) {
+  x -= (x >= 4 * q2 ? 4 * q2 : 0u);
+  x -= (x >= 2 * q2 ? 2 * q2 : 0u);
+  x -= (x >= q2 ? q2 : 0u);
+  x -= (x >= q ? q : 0u);
+  return x;
+}
+
 // Forward 2048-point negacyclic NTT of the 8 values per thread held in pattern {tau + 256k}
 // (natural order in), leaving the result in pattern {8 tau + k} (reference output order).
+template <int M>
+__device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb, const u32* __restrict__ fw,
+                                                const u32* __restrict__ fwp, u32 q, u32 q2);
+// inputs < 2q (residues, or digits of at most 28 bits); r05: the lazy passes above (fwd_pass / ct_bfly remain for reference)
 __device__ __forceinline__ void ntt_fwd_block(u32 (&v)[8], int tau, u32* ldsA, u32* ldsB, const u32* __restrict__ fw,
                                               const u32* __restrict__ fwp, u32 q, u32 q2) {
-  fwd_pass<256, true>(v, 0, fw, fwp, q, q2);
+  u32 w[1][8];
 #pragma unroll
-  for (int k = 0; k < 8; k++) ldsA[PAD_A(tau + 256 * k)] = v[k];
-  __syncthreads();
-  {
-    int b = tau >> 5, o = tau & 31;
+  for (int k = 0; k < 8; k++) w[0][k] = v[k];
+  ntt_fwd_block_m<1>(w, tau, ldsA, ldsB, fw, fwp, q, q2);
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_A(256 * b + o + 32 * k)];
-    fwd_pass<32, true>(v, b, fw, fwp, q, q2);
-#pragma unroll
-    for (int k = 0; k < 8; k++) ldsB[PAD_A(256 * b + o + 32 * k)] = v[k];
-  }
-  __syncthreads();
-  {
-    int b = tau >> 2, o = tau & 3;
-#pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = ldsB[PAD_A(32 * b + o + 4 * k)];
-    fwd_pass<4, true>(v, b, fw, fwp, q, q2);
-#pragma unroll
-    for (int k = 0; k < 8; k++) ldsA[PAD_B(32 * b + o + 4 * k)] = v[k];
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = ldsA[PAD_B(8 * tau + k)];
-  fwd_pass<1, false>(v, tau, fw, fwp, q, q2);
-#pragma unroll
-  for (int k = 0; k < 8; k++) {  // ntt.rs:107-111
-    u32 x = v[k];
-    x -= (x >= q2 ? q2 : 0u);
-    x -= (x >= q ? q : 0u);
-    v[k] = x;
-  }
+  for (int k = 0; k < 8; k++) v[k] = w[0][k];
 }
 
 // Inverse: values in pattern {8 tau + k} (< 2q) -> pattern {tau + 256k}, canonical.  iw / iwp: inv_tables (NOT the reference's
@@ -272,7 +398,7 @@ __device__ __forceinline__ void inv_pass_m(u32 (&v)[M][8], int b, const u32* __r
 template <int M>
 __device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,
                                                 const u32* __restrict__ fw, const u32* __restrict__ fwp, u32 q, u32 q2) {
-  fwd_pass_m<256, true, M>(v, 0, fw, fwp, q, q2);
+  fwd_pass_lazy_m<256, true, M>(v, 0, fw, fwp, q, q2);
 #pragma unroll
   for (int k = 0; k < 8; k++) {
     const int a = PAD_A(tau + 256 * k);
@@ -288,7 +414,7 @@ __device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la
 #pragma unroll
       for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
     }
-    fwd_pass_m<32, true, M>(v, b, fw, fwp, q, q2);
+    fwd_pass_lazy_m<32, true, M>(v, b, fw, fwp, q, q2);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int a = PAD_A(256 * b + o + 32 * k);
@@ -305,7 +431,7 @@ __device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la
 #pragma unroll
       for (int m = 0; m < M; m++) v[m][k] = lb[m * LDS_WORDS + a];
     }
-    fwd_pass_m<4, true, M>(v, b, fw, fwp, q, q2);
+    fwd_pass_lazy_m<4, true, M>(v, b, fw, fwp, q, q2);
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       const int a = PAD_B(32 * b + o + 4 * k);
@@ -320,16 +446,11 @@ __device__ __forceinline__ void ntt_fwd_block_m(u32 (&v)[M][8], int tau, u32* la
 #pragma unroll
     for (int m = 0; m < M; m++) v[m][k] = la[m * LDS_WORDS + a];
   }
-  fwd_pass_m<1, false, M>(v, tau, fw, fwp, q, q2);
+  fwd_pass_lazy_m<1, false, M>(v, tau, fw, fwp, q, q2);
 #pragma unroll
   for (int m = 0; m < M; m++)
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      u32 x = v[m][k];
-      x -= (x >= q2 ? q2 : 0u);
-      x -= (x >= q ? q : 0u);
-      v[m][k] = x;
-    }
+    for (int k = 0; k < 8; k++) v[m][k] = canon_from_12q(v[m][k], q, q2);
 }
 template <int M>
 __device__ __forceinline__ void ntt_inv_block_m(u32 (&v)[M][8], int tau, u32* la, u32* lb,

@@ -55,67 +55,8 @@ __device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// Software pipelining: with 128 accumulator registers next to a transform only two waves fit a SIMD, so nothing but
-// the code itself hides latencies.  Every table read is therefore issued one stage (or one group of butterflies)
-// before its use and pinned there with a scheduling barrier; the caller can hook its own loads and arithmetic into the
-// last stages (the fold kernel fetches its multiply-accumulate operands there and consumes finished quarters).
-// ------------------------------------------------------------------------------------------------------------------
-#define SP_SB() __builtin_amdgcn_sched_barrier(0)
-
-// B independent Cooley-Tukey butterflies issued phase by phase: left to itself the compiler emits one butterfly after
-// the other, each a chain of dependent multiplies (v_mul_hi -> v_mul_lo -> v_sub -> v_add) that a wave can only issue at
-// the dependent-operation latency; phase-wise every instruction's operands are B issue slots old.
-// LAZY range reduction: the Shoup product w y - floor(w' y / 2^32) q lies in [0, 2q) for ANY y < 2^32, so only the
-// operand that is added (x) has to be kept small enough for x + 2q not to wrap -- and with q < 2^28 a 32-bit word holds
-// 16q.  Both outputs are < x + 2q: values grow by 2q per stage.  Instead of the reference's conditional subtraction of
-// 2q in every butterfly (ntt.rs:92-103; two of nine instructions) x is reduced by 8q in two of the eleven stages only
-// (CORR; see wntt_fwd for the bounds).  The residues mod q are the same, so every canonical result is too.
-// Five instructions per butterfly instead of seven: with NEGATED twiddles nw = -w (mod 2^32; the LDS copy and the scalar
-// entries are negated once, wtw_stage / wntt_scalar_tw) the Shoup product comes out negated,
-//     nl = floor(w' y / 2^32) q - w y   (mod 2^32)   = -(w y mod q, lazily in [0, 2q)),
-// as two chained v_mad_u64_u32 (nw * y, then + qt * q; only the low 32 bits of the sum are used -- the second one is inline
-// assembly because the compiler would narrow it to v_mul_lo + v_add) in place of v_mul_lo, v_mul_lo, v_sub, and the
-// two outputs are
-//     y' = x + 2q + nl  (v_add3_u32)      x' = x - nl
-// in place of add, sub, add.  Same residues as before in every register (all arithmetic is mod 2^32).
-template <int B, bool CORR>
-__device__ __forceinline__ void ct_bfly_batch(u32 (&x)[B], u32 (&y)[B], const u32 (&nw)[B], const u32 (&wp)[B], u32 q, u32 q2) {
-  u32 qt[B], t[B];
-  u64 nl[B];
-#pragma unroll
-  for (int b = 0; b < B; b++) qt[b] = __umulhi(y[b], wp[b]);
-  SP_SB();
-#pragma unroll
-  for (int b = 0; b < B; b++) nl[b] = (u64)nw[b] * y[b];
-  SP_SB();
-  if (CORR) {
-#pragma unroll
-    for (int b = 0; b < B; b++) t[b] = x[b] - 4 * q2;
-    SP_SB();
-  }
-  // (one assembly statement per four: between separate statements the compiler puts an s_nop each)
-  static_assert(B % 4 == 0, "butterfly batches come in fours");
-#pragma unroll
-  for (int b = 0; b < B; b += 4)
-    asm("v_mad_u64_u32 %0, vcc, %4, %8, %0\n\tv_mad_u64_u32 %1, vcc, %5, %8, %1\n\t"
-        "v_mad_u64_u32 %2, vcc, %6, %8, %2\n\tv_mad_u64_u32 %3, vcc, %7, %8, %3"
-        : "+v"(nl[b]), "+v"(nl[b + 1]), "+v"(nl[b + 2]), "+v"(nl[b + 3])
-        : "v"(qt[b]), "v"(qt[b + 1]), "v"(qt[b + 2]), "v"(qt[b + 3]), "s"(q)
-        : "vcc");
-  SP_SB();
-  if (CORR) {
-#pragma unroll
-    for (int b = 0; b < B; b++) x[b] = x[b] < t[b] ? x[b] : t[b];  // x - (x >= 8q ? 8q : 0)
-    SP_SB();
-  }
-#pragma unroll
-  for (int b = 0; b < B; b++) y[b] = x[b] + q2 + (u32)nl[b];
-  SP_SB();
-#pragma unroll
-  for (int b = 0; b < B; b++) x[b] = x[b] - (u32)nl[b];
-  SP_SB();
-}
+// (SP_SB and ct_bfly_batch -- the lazy five-instruction Cooley-Tukey butterfly, issued phase by phase -- live in device_common.hpp
+// since round 5: the cooperative forward transform uses them too.)
 // butterflies (v[ia], v[ib]) with twiddles (w, wp), ia / ib / twiddle index given by the functors, in batches of 8
 #define SP_BFLY_STAGE(COUNT, IA, IB, W, WP, CORR)                                                \
   _Pragma("unroll") for (int b0_ = 0; b0_ < (COUNT); b0_ += 8) {                                 \
