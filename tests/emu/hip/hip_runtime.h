@@ -117,6 +117,10 @@ inline unsigned atomicMax(unsigned* p, unsigned v) {
   return o;
 }
 inline unsigned atomicExch(unsigned* p, unsigned v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
+// scoped atomic loads (k_fold_cluster reads the other workgroups' sums with device scope): host memory is coherent
+#define __HIP_MEMORY_SCOPE_AGENT 4
+#define __hip_atomic_load(PTR, ORDER, SCOPE) __atomic_load_n((PTR), (ORDER))
+#define __hip_atomic_store(PTR, VAL, ORDER, SCOPE) __atomic_store_n((PTR), (VAL), (ORDER))
 
 // ---- wave-level operations (a wave = 64 consecutive work-items of the workgroup) -----------------------------------------
 typedef uint32_t emu_u32x2 __attribute__((ext_vector_type(2)));
