@@ -17,7 +17,7 @@ import bench
 import sdk_amd as sp
 
 DEFAULTS = {"batch_planar": 1, "pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256, "fold_skip_dead_digits": 1, "fold_variant": 5,
-            "batch_in_flight": 3, "expand_split": -1}
+            "batch_in_flight": 3, "expand_split": -1, "sweep_prio": 1, "pipe_ring": 8, "pipe_ring_wgs": 1, "from_sweep_xcd": 1, "sweep_nt_store": 1}
 
 
 def single(p, pp, qs, db, steps):
@@ -72,6 +72,10 @@ def main():
             print("%-36s | batch%d %.2f ms = %.1f q/s | %s" % (v or "baseline", B, bt * 1e3, B / bt, "ok" if shab == ref else "RESPONSE CHANGED"), flush=True)
             continue
         qps, st, sha = single(p, pp, qs, db, steps)
+        if os.environ.get("ONLY_SINGLE") == "1":
+            ref = ref or sha
+            print("%-36s | %6.2f q/s expand %.3f sweep %.3f fold %.3f | %s" % (v or "baseline", qps, st[0], st[1], st[2], "ok" if sha == ref else "RESPONSE CHANGED"), flush=True)
+            continue
         set_all(v, pipeline=0)
         qps0, st0, sha0 = single(p, pp, qs, db, 6)
         set_all(v)
