@@ -1,6 +1,7 @@
 """GPU parity: every stage of the HIP answer path, called through the C ABI, against the CPU oracle on
 identical seeded inputs -- bit-exact (integer arithmetic).  Mirrors the reference's test ladder
 (SURVEY.md App. F): L0 kernels, stage functions, end-to-end response bytes, then decrypt."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -1026,6 +1027,24 @@ def test_ring_sweep_and_batched_tails_parity(sp, oracle_mod, monkeypatch, nu_1, 
     assert resp == c["resp"]
     if t_gsw >= 4:  # (fewer gadget digits: the noise is too large to decode, the bytes still have to agree)
         assert cl.decode_response(resp) == o.item_to_vec(item)
+    if (nu_1, nu_2, ring, defer) == (5, 10, "8", "256"):
+        # two and three queries in flight on separate workspaces (begin + sweep of the next before the previous one is waited
+        # for; their sweeps may overlap on the device): each answer is the single query's
+        qs = [q, cl.generate_query(5, 77), cl.generate_query(1234 % o.num_items, 78)]
+        single = [resp] + [sp.process_query(p, gpp, x, gdb) for x in qs[1:]]
+        for depth in (2, 3):
+            runs, got = [], []
+            for x in qs + qs:
+                r = sp.QueryRun(p, gpp, x, db=gdb)
+                r.sweep(gdb)
+                runs.append(r)
+                if len(runs) == depth:
+                    got.append(runs[0].finish())
+                    runs.pop(0).free()
+            while runs:
+                got.append(runs[0].finish())
+                runs.pop(0).free()
+            assert got == single + single, depth
 
 
 def test_process_query_batch_lds_staged(sp, oracle_mod):
