@@ -1,5 +1,7 @@
 // Fused fold step of fold_ciphertexts (server.rs:388-427) for gfx950: digits -> NTT -> multiply-accumulate -> iNTT -> CRT
 // in registers / LDS.  See DESIGN.md section 3 for the algebra and the roofline.
+#include <type_traits>
+
 #include "device_common.hpp"
 #include "wave_ntt.hpp"
 #include "bodies.hpp"
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(256, 2) void k_fold_wave(DevTables T, FoldDesc d, c
     const ModConst m = T.c.mod[c];
     const u32* fw = T.tw + (size_t)c * 4 * N;
     if (c == 1) __syncthreads();  // the reduction scratch of modulus 0 overlapped the table area
-    wtw_stage(ltw, fw, tau);
+    wtw_stage(ltw, wave_fwd_image(T.tw, c), tau);
     __syncthreads();              // tables (and, the first time, the digit differences) are in place
     u64 acc0[32], acc1[32];
 #pragma unroll
@@ -491,30 +493,51 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
           rr[4 * g] = t4.x; rr[4 * g + 1] = t4.y; rr[4 * g + 2] = t4.z; rr[4 * g + 3] = t4.w;
         }
       }
+      // compose + add ct_i + store: each of the four waves does HALF a row (waves 0 / 2 share row 0, waves 1 / 3 row 1; the
+      // modulus-1 waves 0, 1 take coefficients 64 k + lane with k < 16, the modulus-0 waves 2, 3 those with k >= 16) -- with
+      // waves 2 and 3 doing whole rows this phase was 11.7 % of the kernel (profiles/r05_fold_dissection.md).  The ct_i words
+      // are requested before the inverse transform.
+      const int khalf = wv >> 1;
+      const u64* crow = ct0 + (size_t)irow * N + (size_t)khalf * 1024;
+      u64 cpre[16];
+#pragma unroll
+      for (int kk = 0; kk < 16; kk++) cpre[kk] = crow[64 * kk + lt];
       wntt_inv(rr, lt, mybuf, inv_tables(T.tw, imod), mi.q, mi.two_q);  // -> coefficient 64 k + lane
-      u32* exch = smem_fw + 4 * WBUF_WORDS;  // the table area: modulus-1 residues of both rows for Garner
+      u32* exch = smem_fw + 4 * WBUF_WORDS;  // the table area: region (row, modulus) holds the 16 x 64 residues its partner needs
+      u32* mine_out = exch + (irow * 2 + imod) * (N / 2);
       if (wv < 2) {
 #pragma unroll
-        for (int k = 0; k < 32; k++) exch[irow * N + 64 * k + lt] = rr[k];
+        for (int kk = 0; kk < 16; kk++) mine_out[64 * kk + lt] = rr[16 + kk];
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < 16; kk++) mine_out[64 * kk + lt] = rr[kk];
       }
       __syncthreads();  // (also: waves 2 and 3 have read their parked rows before anybody overwrites the output slot)
-      if (wv >= 2) {
-        u64* orow = out + (size_t)irow * N;
-        const u64* crow = ct0 + (size_t)irow * N;
+      {
+        const u32* theirs = exch + (irow * 2 + (1 - imod)) * (N / 2);
+        u64* orow = out + (size_t)irow * N + (size_t)khalf * 1024;
         const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
+        // (two copies of the loop with compile-time register indices: a run-time choice between rr[kk] and rr[16 + kk] turns rr
+        // into an indexed array in scratch memory)
+        auto compose = [&](auto mod1_wave) {
+          constexpr bool M1 = decltype(mod1_wave)::value;
 #pragma unroll
-        for (int k = 0; k < 32; k++) {
-          const size_t zi = 64 * k + lt;
-          const u32 x = rr[k], y = exch[irow * N + zi];
-          const u32 xm = x >= q1 ? x - q1 : x;
-          const u32 dd = y >= xm ? y - xm : y + q1 - xm;
-          const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
-          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
-          e = e >= q1 ? e - q1 : e;
-          const u64 val = (u64)x + (u64)q0 * (u64)e + crow[zi];
-          const u64 res = val >= T.c.Q ? val - T.c.Q : val;
-          orow[zi] = res;
-        }
+          for (int kk = 0; kk < 16; kk++) {
+            const u32 other = theirs[64 * kk + lt];
+            const u32 own = rr[M1 ? kk : 16 + kk];
+            const u32 x = M1 ? other : own, y = M1 ? own : other;   // residues mod q0, q1
+            const u32 xm = x >= q1 ? x - q1 : x;
+            const u32 dd = y >= xm ? y - xm : y + q1 - xm;
+            const u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
+            u32 e = dd * T.c.q0_inv_q1 - qt * q1;
+            e = e >= q1 ? e - q1 : e;
+            const u64 val = (u64)x + (u64)q0 * (u64)e + cpre[kk];
+            const u64 res = val >= T.c.Q ? val - T.c.Q : val;
+            orow[64 * kk + lt] = res;
+          }
+        };
+        if (wv < 2) compose(std::true_type{});
+        else compose(std::false_type{});
       }
     }
   }

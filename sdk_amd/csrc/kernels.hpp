@@ -16,11 +16,29 @@ namespace spiral {
 constexpr int N = (int)POLY_LEN;
 
 struct DevTables {
-  const u32* tw;  // [crt][4][N] twiddles as the reference's (0 fwd, 1 fwd', 2 inv, 3 inv'), then [crt][2][N] (inv_tables)
+  const u32* tw;  // [crt][4][N] twiddles as the reference's (0 fwd, 1 fwd', 2 inv, 3 inv'), then [crt][2][N] (inv_tables), then [crt][2][N] (wave_fwd_image)
   DevConsts c;
 };
 // [w | w'] of modulus c for the kernels' inverse transform: unhalved psi^-i, entries 0 and 1 times N^-1 (params.cpp, finish)
 __host__ __device__ inline const u32* inv_tables(const u32* tw, int c) { return tw + (size_t)8 * N + (size_t)c * 2 * N; }
+// The forward tables of modulus c as the wave-per-transform NTT keeps them in LDS (wave_ntt.hpp): [ -w | w' ] with the entries
+// of the last two stages rotated per lane group (wtw_phys), 2N words -- a workgroup stages them with plain 16-byte copies
+// (wtw_stage) instead of negating and permuting 16 KiB per fold step and modulus (7.7 % of k_fold_wave: profiles/r05_fold_dissection.md)
+__host__ __device__ inline const u32* wave_fwd_image(const u32* tw, int c) { return tw + (size_t)12 * N + (size_t)c * 2 * N; }
+// physical word of twiddle-table entry idx in that image: the ranges a lane reads as b128 vectors in stages t = 2
+// (entries 512 + 8L + 0..7) and t = 1 (1024 + 16L + 0..15) are rotated per lane group so that the 16 lanes of a b128
+// service group hit 16 different bank quads
+__host__ __device__ inline int wtw_phys(int idx) {
+  if (idx >= 1024) {
+    const int L = (idx - 1024) >> 4, r = (idx - 1024) & 15;
+    return 1024 + 16 * L + 4 * (((r >> 2) + (L >> 2)) & 3) + (r & 3);
+  }
+  if (idx >= 512) {
+    const int L = (idx - 512) >> 3, r = (idx - 512) & 7;
+    return 512 + 8 * L + 4 * (((r >> 2) + (L >> 3)) & 1) + (r & 3);
+  }
+  return idx;
+}
 
 // ---- which kernels / flows the calling thread's work went through (sp_paths_taken, include/spiral_hip.h) ----------
 // Every launch wrapper reports here right after its hipLaunchKernelGGL: the bit is recorded (thread-local, tests assert

@@ -1,6 +1,7 @@
 // Host-side scheme parameters (see params.hpp).  Reference: lib/spiral-rs/src/params.rs,
 // ntt.rs:6-65 (table construction), number_theory.rs:41-96, util.rs:219-263 (JSON keys).
 #include "params.hpp"
+#include "kernels.hpp"   // N, wtw_phys: the wave transform's table image is built here
 
 #include <cctype>
 #include <cmath>
@@ -114,7 +115,8 @@ void Params::finish() {
   modulus = moduli[0] * moduli[1];
   modulus_log2 = 0;
   while (((u128)1 << modulus_log2) < (u128)modulus) modulus_log2++;  // log2_ceil, arith.rs:13-15
-  ntt_tables.assign(CRT_COUNT * 6 * poly_len, 0);  // [crt][4][N] as the reference's, then [crt][2][N]: the kernels' inverse tables
+  // [crt][4][N] as the reference's, then [crt][2][N]: the kernels' inverse tables, then [crt][2][N]: the wave transform's LDS image
+  ntt_tables.assign(CRT_COUNT * 8 * poly_len, 0);
   for (int c = 0; c < 2; c++) {
     u64 q = moduli[c];
     u64 psi = minimal_primitive_root(2 * poly_len, q);
@@ -143,6 +145,16 @@ void Params::finish() {
       lwp[idx] = (u32)((lz << 32) / q);
       pw = mul_mod(pw, psi, q);
       ipw = mul_mod(ipw, psi_inv, q);
+    }
+    // the wave transform's LDS image of the forward tables (kernels.hpp, wave_fwd_image): [ -w | w' ] at wtw_phys(idx); only
+    // defined for the transform length the kernels are built for
+    if (poly_len == (size_t)N) {
+      u32* img = ntt_tables.data() + (size_t)CRT_COUNT * 6 * poly_len + (size_t)c * 2 * poly_len;
+      for (size_t i = 0; i < poly_len; i++) {
+        const int ph = wtw_phys((int)i);
+        img[ph] = 0u - fw[i];
+        img[poly_len + ph] = fwp[i];
+      }
     }
     dc.mod[c].q = (u32)q;
     dc.mod[c].two_q = (u32)(2 * q);

@@ -30,29 +30,13 @@ constexpr int WBUF_WORDS = 32 * 36;  // padded transpose buffer of one wave: HAL
 
 __device__ __forceinline__ int wave_h(int lane) { return lane < 32 ? lane : lane + 40; }
 
-// physical word of twiddle-table entry idx in the LDS copy: the ranges a lane reads as b128 vectors in stages t = 2
-// (entries 512 + 8L + 0..7) and t = 1 (1024 + 16L + 0..15) are rotated per lane group so that the 16 lanes of a b128
-// service group hit 16 different bank quads
-__device__ __forceinline__ int wtw_phys(int idx) {
-  if (idx >= 1024) {
-    const int L = (idx - 1024) >> 4, r = (idx - 1024) & 15;
-    return 1024 + 16 * L + 4 * (((r >> 2) + (L >> 2)) & 3) + (r & 3);
-  }
-  if (idx >= 512) {
-    const int L = (idx - 512) >> 3, r = (idx - 512) & 7;
-    return 512 + 8 * L + 4 * (((r >> 2) + (L >> 3)) & 1) + (r & 3);
-  }
-  return idx;
-}
-// stage the forward tables [w | w'] (2N words at tw) of one modulus into ltw (2N words) -- whole workgroup, 256 threads
-__device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ tw, int tau) {
+// (wtw_phys -- where entry idx of the tables lives in the LDS copy -- is in kernels.hpp: the host builds the image with it)
+// stage the forward tables of one modulus into ltw (2N words) -- whole workgroup, 256 threads; img = wave_fwd_image(tw, c),
+// already negated and rotated: four 16-byte copies per thread
+__device__ __forceinline__ void wtw_stage(u32* ltw, const u32* __restrict__ img, int tau) {
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    const int idx = tau + 256 * k;
-    const int ph = wtw_phys(idx);
-    ltw[ph] = 0u - tw[idx];   // negated (ct_bfly_batch)
-    ltw[N + ph] = tw[N + idx];
-  }
+  for (int k = 0; k < 4; k++)
+    reinterpret_cast<u32x4w_t*>(ltw)[tau + 256 * k] = reinterpret_cast<const u32x4w_t*>(img)[tau + 256 * k];
 }
 
 // (SP_SB and ct_bfly_batch -- the lazy five-instruction Cooley-Tukey butterfly, issued phase by phase -- live in device_common.hpp

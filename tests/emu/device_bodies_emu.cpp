@@ -132,7 +132,7 @@ int emu_wave_ntt_fwd(void* h, int c, int canon, uint32_t* data) {
     emu::run_block(256, [&] {
       const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
       u32* poly = data + (size_t)wv * N;
-      wtw_stage(g_ltw, tw, threadIdx.x);
+      wtw_stage(g_ltw, wave_fwd_image(E.T.tw, c), threadIdx.x);
       WaveScalarTw s;
       wntt_scalar_tw(s, tw);
       u32 v[32];

@@ -18,7 +18,9 @@ CSRC = os.path.join(ROOT, "sdk_amd", "csrc")
 # kernel name fragment -> (max scratch bytes per lane, max VGPRs).  The limits are what the round-4 tree compiles to, with a little
 # room: a change that crosses one should be a decision, not an accident.
 LIMITS = {
-    "fold.hip": {"k_fold_waveILi1E": (32, 256), "k_fold_waveILi2E": (32, 256), "k_fold_waveILi4E": (32, 256),
+    # (k_fold_wave: no scratch at all since the round-5 compose phase; a run-time choice between two halves of a register array
+    # there once put the whole array into scratch -- 144 bytes per lane -- and took the change's gain with it)
+    "fold.hip": {"k_fold_waveILi1E": (8, 256), "k_fold_waveILi2E": (8, 256), "k_fold_waveILi4E": (8, 256),
                  # k_fold_fused2 (fallback for gadget widths the wave kernel does not take): 12 bytes since the lazy inverse butterfly
                  # (r05, timed: profiles/r05_call1_ab.md), three dwords outside its transform loops
                  "k_fold_fusedE": (0, 256), "k_fold_fused2E": (16, 256)},
