@@ -23,6 +23,16 @@ def sub(text, old, new, count=1):
 def patch(d, name):
     fold = open(os.path.join(d, "fold.hip")).read()
     wave = open(os.path.join(d, "wave_ntt.hpp")).read()
+    ntt = open(os.path.join(d, "ntt.hip")).read()
+    # k_from_sweep4 (from_ntt of the sweep output): fs_*
+    if name == "fs_no_store":   # one store in 64 kept
+        ntt = sub(ntt, "          out[tau + 256 * k] = val;", "          if ((tau & 63) == 0 && k == 0) out[tau + 256 * k] = val; else if (val == 0x123456789ULL) out[1] = val;")
+    if name == "fs_no_load":    # computed values instead of the strided 16-byte loads
+        ntt = sub(ntt, "      uint4 x = *reinterpret_cast<const uint4*>(sp + (size_t)(8 * tau + k) * np);",
+                  "      uint4 x = make_uint4((u32)(8 * tau + k) * 2654435761u >> 5, (u32)(tau + k) * 40503u, (u32)g * 97u + k, (u32)tau * 7u + c);")
+    if name == "fs_no_inv":     # the four cooperative inverse transforms of a workgroup
+        ntt = sub(ntt, "    ntt_inv_block_m<4>(v, tau, lds0, lds1, iw, iw + N, m.q, m.two_q);", "    v[0][0] += (u32)(size_t)iw + lds0[tau];")
+    open(os.path.join(d, "ntt.hip"), "w").write(ntt)
     if name in ("no_operands", "all"):
         fold = sub(fold, "    m0[g] = a0[64 * g];\n    m1[g] = a1[64 * g];",
                    "    m0[g] = u32x4w_t{(u32)g + 11u, (u32)g + 12u, (u32)g + 13u, (u32)g + 14u};\n    m1[g] = u32x4w_t{(u32)g + 21u, (u32)g + 22u, (u32)g + 23u, (u32)g + 24u};")
@@ -72,12 +82,15 @@ def main():
                 shutil.copy(os.path.join(SRC, f), d)
         os.makedirs(os.path.join(d, "..", "include"), exist_ok=True)
         patch(d, name)
-        obj = os.path.join(d, "fold.hip.o")
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
-                               "-I", os.path.join(R, "sdk_amd", "csrc"), "-c", os.path.join(d, "fold.hip"), "-o", obj], cwd=d)
+        mine = []
+        for f in ("fold.hip", "ntt.hip"):
+            obj = os.path.join(d, f + ".o")
+            subprocess.check_call(["/opt/rocm/bin/hipcc", "-x", "hip", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-Wall", "-Wno-unused-result",
+                                   "-I", os.path.join(R, "sdk_amd", "csrc"), "-c", os.path.join(d, f), "-o", obj], cwd=d)
+            mine.append(obj)
         out = os.path.join(R, "sdk_amd", "variants", "libspiral_hip_tv_%s.so" % name)
-        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out, obj] +
-                              [os.path.join(SRC, "build", o) for o in objs] + ["-L/opt/rocm/lib", "-lrccl"])
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-shared", "-o", out] + mine +
+                              [os.path.join(SRC, "build", o) for o in objs if o != "ntt.hip.o"] + ["-L/opt/rocm/lib", "-lrccl"])
         print(out)
 
 

@@ -143,14 +143,21 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
   const int ii0 = gl * 4;
   const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
   u32 res0[4][8];
-#pragma unroll 1
+  // both moduli's operands are requested up front (16 strided 16-byte loads per thread: the loads are 43 % of this kernel's time
+  // when each modulus waits for its own, profiles/r05_from_sweep_dissection.md); modulus 1's arrive under modulus 0's transforms
+  uint4 xin[2][8];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+      xin[c][k] = *reinterpret_cast<const uint4*>(src + base + (size_t)c * N * np + (size_t)(8 * tau + k) * np);
+#pragma unroll
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
-    const u32* sp = src + base + (size_t)c * N * np;
     u32 v[4][8];
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      uint4 x = *reinterpret_cast<const uint4*>(sp + (size_t)(8 * tau + k) * np);
+      uint4 x = xin[c][k];
       if (premod) {
         x.x %= m.q; x.y %= m.q; x.z %= m.q; x.w %= m.q;
       }
