@@ -16,6 +16,7 @@ bash scripts/box_fingerprint.sh > $O/${T}_box.txt 2>&1
 ( time timeout 800 python -m pytest tests -x -q -m gpu --durations=10 ) > $O/${T}_pytest.log 2>&1
 tail -4 $O/${T}_pytest.log
 grep -q " passed" $O/${T}_pytest.log || { echo "suite did not pass: stopping"; tail -30 $O/${T}_pytest.log; exit 1; }
+( timeout 200 python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' ) > $O/${T}_smoke.txt 2>&1; tail -1 $O/${T}_smoke.txt
 ( time timeout 600 python bench.py --steps 20 --warmup 5 ) > $O/${T}_bench_c2.json 2> $O/${T}_bench_c2.err || { echo "default bench failed"; tail -5 $O/${T}_bench_c2.err; exit 1; }
 cd /tmp; export TMPDIR=/tmp
 rm -rf /tmp/p1 /tmp/p2 /tmp/p3 /tmp/p4 /tmp/p5 /tmp/p6 /tmp/p7 /tmp/q2 /tmp/q3
