@@ -32,6 +32,17 @@ def patch(d, name):
                   "      uint4 x = make_uint4((u32)(8 * tau + k) * 2654435761u >> 5, (u32)(tau + k) * 40503u, (u32)g * 97u + k, (u32)tau * 7u + c);")
     if name == "fs_no_inv":     # the four cooperative inverse transforms of a workgroup
         ntt = sub(ntt, "    ntt_inv_block_m<4>(v, tau, lds0, lds1, iw, iw + N, m.q, m.two_q);", "    v[0][0] += (u32)(size_t)iw + lds0[tau];")
+    bodies = open(os.path.join(d, "bodies.hpp")).read()
+    # k_ntt_fwd / k_ntt_fwd3 (digit transforms of the expansion): fw_*
+    if name == "fw_no_load":
+        bodies = sub(bodies, "    u64 x = src[tau + 256 * k];\n    u64 piece = (sh >= 64) ? 0ULL : ((x >> sh) & mask);  // gadget.rs:48-53",
+                     "    u64 x = ((u64)(tau + 256 * k + o) * 0x9E3779B97F4A7C15ULL) >> 8;\n    u64 piece = (sh >= 64) ? 0ULL : ((x >> sh) & mask);  // gadget.rs:48-53")
+    if name == "fw_no_store":
+        bodies = sub(bodies, "  dst[0] = make_uint4(v[0], v[1], v[2], v[3]);\n  dst[1] = make_uint4(v[4], v[5], v[6], v[7]);",
+                     "  if (v[0] == 0x12345u && v[5] == 77u) { dst[0] = make_uint4(v[0], v[1], v[2], v[3]); dst[1] = make_uint4(v[4], v[5], v[6], v[7]); }")
+    if name == "fw_no_transform":
+        bodies = sub(bodies, "  ntt_fwd_block(v, tau, ldsA, ldsB, fw, fw + N, m.q, m.two_q);\n  uint4* dst", "  v[0] += ldsA[tau] + (u32)(size_t)fw;\n  uint4* dst")
+    open(os.path.join(d, "bodies.hpp"), "w").write(bodies)
     open(os.path.join(d, "ntt.hip"), "w").write(ntt)
     if name in ("no_operands", "all"):
         fold = sub(fold, "    m0[g] = a0[64 * g];\n    m1[g] = a1[64 * g];",
