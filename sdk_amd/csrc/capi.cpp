@@ -218,7 +218,7 @@ const char* sp_path_name(int bit) {
   static const char* names[] = {"sweep_packed_persist", "sweep_packed", "sweep_wide", "sweep_narrow", "sweep_batch",
                                 "from_sweep4", "from_sweep1", "fold_fused", "fold_tail_delta", "fold_tail_literal",
                                 "pipelined_fold_overlap", "expand_pruned", "pack_v1", "direct_upload", "scatter_out",
-                                "from_sweep4_xcd_order", "fold_tail_persistent", "expand_head_fused", "sweep_sparse",
+                                "from_sweep4_xcd_order", "fold_tail_persistent", "expand_round_one_launch", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
                                 "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8", "sweep_batch_planar"};

@@ -62,7 +62,7 @@ enum PathBit : u64 {
   PATH_SCATTER_OUT = 1ull << 14,      // column-interleaved sweep output (multi-GPU reduce-scatter layout)
   PATH_SWEEP_XCD_FROM = 1ull << 15,   // k_from_sweep4 with the XCD-aware block order
   PATH_FOLD_TAIL_PERSIST = 1ull << 16,// (retired: k_fold_tail of round 1)
-  PATH_EXPAND_FUSED = 1ull << 17,     // (retired: one-launch expansion experiments of rounds 2 and 4)
+  PATH_EXPAND_FUSED = 1ull << 17,     // k_expand_round: a large expansion round's digit transforms and products in one launch (r05)
   PATH_SWEEP_SPARSE = 1ull << 18,     // presence-aware sweep (absent units skipped)
   PATH_RCCL = 1ull << 19,             // RCCL collectives issued by the library itself (sp_comm_create)
   PATH_FOLD_WAVE = 1ull << 20,        // k_fold_wave (wave-per-transform NTT, no workgroup barriers inside a transform)
@@ -179,6 +179,23 @@ struct MacDesc {
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s);
 // two descriptors in ONE launch (both must have batch_outer == 1)
 void launch_mac2(const DevTables& T, const MacDesc& d0, const MacDesc& d1, hipStream_t s);
+
+// ---- one expansion round's digit transforms AND their products in one launch (server.rs:89-102) ------------------------------
+// For each ciphertext b of a side: v[out_idx[b] + r] += sum_k A[r][k] * NTT(digit_k(raw[pos[b] * 2])) (+ NTT(raw[pos[b] * 2 + 1])
+// for r = 1), r = 0, 1 -- what launch_ntt_fwd3 + launch_mac2 compute through the digit buffer, as ONE workgroup per (ciphertext,
+// modulus): the source polynomial is read once, its digits are transformed four at a time and multiplied into the two rows' sums
+// in registers; nothing is written but the two result polynomials.  Same residues (exact sums), so the same bytes.
+// A round's latency is then t / 4 + 1 transform passes in sequence: for rounds large enough to fill the chip (expand_round_min).
+struct ExpandSideDesc {
+  const u64* raw;      // the round's automorphed ciphertexts, raw: polys [pos * 2 + row]
+  const int* pos;      // [cnt] position of ciphertext b in that list
+  const int* out_idx;  // [cnt] poly index of the output row 0 in v (row 1 follows)
+  const u32* A;        // 2 x t NTT polys (the side's expansion key of this round)
+  u32* v;              // NTT polys, read (addend) and written
+  int cnt, t, bits;
+};
+void launch_expand_round(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, hipStream_t s);
+constexpr long EXPAND_ROUND_MIN_DEFAULT = 2048;
 
 // ---- fused fold step (server.rs:407-424) ----------------------------------------------------
 // One workgroup per (pair i, plane): out[plane][i] = from_ntt( [G-C | C] * NTT(G^-1([ct_i ; ct_{i+half}])) ),

@@ -105,6 +105,97 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
 }
 
 // ------------------------------------------------------------------------------------------------
+// One expansion round's digit transforms and products (kernels.hpp, ExpandSideDesc): grid (left.cnt + right.cnt, 2 moduli).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_expand_round(DevTables T, ExpandSideDesc dl, ExpandSideDesc dr) {
+  constexpr int GD = 4;   // digit polynomials per transform pass
+  __shared__ u32 lds0[GD * LDS_WORDS];
+  __shared__ u32 lds1[GD * LDS_WORDS];
+  const int tau = threadIdx.x;
+  const int c = blockIdx.y;
+  const bool right = (int)blockIdx.x >= dl.cnt;
+  const ExpandSideDesc& d = right ? dr : dl;
+  const int b = (int)blockIdx.x - (right ? dl.cnt : 0);
+  const ModConst m = T.c.mod[c];
+  const u32* fw = T.tw + (size_t)c * 4 * N;
+  const u64* src = d.raw + (size_t)d.pos[b] * 2 * N;
+  u64 x[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) x[k] = src[tau + 256 * k];
+  const u64 mask = (1ULL << d.bits) - 1ULL;   // (bits <= 28: launch_expand_round)
+  u64 acc0[8], acc1[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) acc0[k] = acc1[k] = 0;
+#pragma unroll 1
+  for (int k0 = 0; k0 < d.t; k0 += GD) {
+    u32 v[GD][8];
+#pragma unroll
+    for (int mm = 0; mm < GD; mm++) {
+      const int sh = (k0 + mm) * d.bits;
+      const bool live = k0 + mm < d.t && sh < 64;
+#pragma unroll
+      for (int k = 0; k < 8; k++) v[mm][k] = live ? (u32)((x[k] >> (sh & 63)) & mask) : 0u;   // gadget.rs:48-53
+    }
+    int tk = tau;
+    const u32* fwk = fw;
+    asm volatile("" : "+v"(tk));    // (addresses recomputed per pass instead of hoisted and spilled)
+    asm volatile("" : "+s"(fwk));
+    ntt_fwd_block_m<GD>(v, tk, lds0, lds1, fwk, fwk + N, m.q, m.two_q);   // -> element 8 tau + k, canonical
+#pragma unroll
+    for (int mm = 0; mm < GD; mm++) {
+      const int kk = k0 + mm;
+      if (kk < d.t) {
+        const uint4* a0 = reinterpret_cast<const uint4*>(d.A + ((size_t)kk * 2 + c) * N + 8 * tk);
+        const uint4* a1 = reinterpret_cast<const uint4*>(d.A + ((size_t)(d.t + kk) * 2 + c) * N + 8 * tk);
+        const uint4 p0 = a0[0], p1 = a0[1], r0 = a1[0], r1 = a1[1];
+        acc0[0] += (u64)p0.x * v[mm][0]; acc0[1] += (u64)p0.y * v[mm][1]; acc0[2] += (u64)p0.z * v[mm][2]; acc0[3] += (u64)p0.w * v[mm][3];
+        acc0[4] += (u64)p1.x * v[mm][4]; acc0[5] += (u64)p1.y * v[mm][5]; acc0[6] += (u64)p1.z * v[mm][6]; acc0[7] += (u64)p1.w * v[mm][7];
+        acc1[0] += (u64)r0.x * v[mm][0]; acc1[1] += (u64)r0.y * v[mm][1]; acc1[2] += (u64)r0.z * v[mm][2]; acc1[3] += (u64)r0.w * v[mm][3];
+        acc1[4] += (u64)r1.x * v[mm][4]; acc1[5] += (u64)r1.y * v[mm][5]; acc1[6] += (u64)r1.z * v[mm][6]; acc1[7] += (u64)r1.w * v[mm][7];
+      }
+    }
+    if (((k0 / GD) & 7) == 7) {   // at most 32 products of < 2^56 between Barrett folds
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        acc0[k] = reduce64(acc0[k], m);
+        acc1[k] = reduce64(acc1[k], m);
+      }
+    }
+    __syncthreads();   // the LDS buffers are reused by the next pass
+  }
+  // to_ntt of the ciphertext's second row (poly.rs:613-623: reduced mod q first), added to output row 1
+  u32 e1[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) e1[k] = reduce64(src[(size_t)N + tau + 256 * k], m);
+  ntt_fwd_block(e1, tau, lds0, lds1, fw, fw + N, m.q, m.two_q);
+  u32* o0 = d.v + ((size_t)d.out_idx[b] * 2 + c) * N + 8 * tau;
+  u32* o1 = o0 + (size_t)2 * N;
+  const uint4 g0 = reinterpret_cast<const uint4*>(o0)[0], g1 = reinterpret_cast<const uint4*>(o0)[1];
+  const uint4 h0 = reinterpret_cast<const uint4*>(o1)[0], h1 = reinterpret_cast<const uint4*>(o1)[1];
+  const u32 ga[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const u32 ha[8] = {h0.x, h0.y, h0.z, h0.w, h1.x, h1.y, h1.z, h1.w};
+  u32 w0[8], w1[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    w0[k] = reduce64(acc0[k] + ga[k], m);
+    w1[k] = reduce64(acc1[k] + (u64)ha[k] + e1[k], m);
+  }
+  reinterpret_cast<uint4*>(o0)[0] = make_uint4(w0[0], w0[1], w0[2], w0[3]);
+  reinterpret_cast<uint4*>(o0)[1] = make_uint4(w0[4], w0[5], w0[6], w0[7]);
+  reinterpret_cast<uint4*>(o1)[0] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
+  reinterpret_cast<uint4*>(o1)[1] = make_uint4(w1[4], w1[5], w1[6], w1[7]);
+}
+void launch_expand_round(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, hipStream_t s) {
+  const int total = std::max(left.cnt, 0) + std::max(right.cnt, 0);
+  if (total <= 0) return;
+  ExpandSideDesc a = left, b = right;
+  a.cnt = std::max(a.cnt, 0);
+  b.cnt = std::max(b.cnt, 0);
+  hipLaunchKernelGGL(k_expand_round, dim3(total, 2), dim3(256), 0, s, T, a, b);
+  launched(PATH_EXPAND_FUSED, "k_expand_round");
+}
+
+// ------------------------------------------------------------------------------------------------
 // inverse NTT (both moduli) + Garner CRT -> raw u64.  grid (n_polys)
 // The composed value is the unique v in [0, Q) with v = x mod q0, v = y mod q1, i.e. exactly
 // (x*q1*(q1^-1 mod q0) + y*q0*(q0^-1 mod q1)) mod Q of params.rs:207-214.

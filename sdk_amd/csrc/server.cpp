@@ -703,7 +703,14 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
       f1.src_cols = 1;
       fd[2] = f1;
     }
-    launch_ntt_fwd3(D.T, fd[0], fd[1], fd[2], s);
+    // (2) + (3) in one launch where the round is large enough to fill the chip with one workgroup per (ciphertext, modulus):
+    // nothing but the results is written (kernels.hpp, launch_expand_round; switch expand_round_min = digit transforms per modulus)
+    const long round_transforms = (long)rp.n_left * tl + (long)rp.n_right * tr;
+    // NOT for the odd subtree of a split expansion (tree 2: it runs on the second stream beside the first sweep launches, and
+    // its 57-pass workgroups cost the sweep more than the rounds gain: profiles/r05_expand_round.md; switch expand_round_odd)
+    const bool one_launch = round_transforms >= tunable("expand_round_min", EXPAND_ROUND_MIN_DEFAULT) && fd[0].bits <= 28 && fd[1].bits <= 28 &&
+                            (tree != 2 || tunable("expand_round_odd", 0) != 0);
+    if (!one_launch) launch_ntt_fwd3(D.T, fd[0], fd[1], fd[2], s);
     // (3) v_i += W * ginv + [0; to_ntt(ct_auto row 1)]   (server.rs:89-102)
     MacDesc md[2];
     for (int side = 0; side < 2; side++) {
@@ -733,7 +740,14 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
       m.extra_row = 1;
       md[side] = m;
     }
-    launch_mac2(D.T, md[0], md[1], s);
+    if (one_launch) {
+      ExpandSideDesc es[2];
+      for (int side = 0; side < 2; side++)
+        es[side] = ExpandSideDesc{fd[side].src, fd[side].src_idx, md[side].out_idx, md[side].A, md[side].out, md[side].batch_inner, fd[side].t, fd[side].bits};
+      launch_expand_round(D.T, es[0], es[1], s);
+    } else {
+      launch_mac2(D.T, md[0], md[1], s);
+    }
   }
 }
 

@@ -1252,16 +1252,20 @@ def test_config_sweep_response_parity(sp, oracle_mod, monkeypatch, ci, fused_min
     assert sp.process_query(p, gpp, c["q"], gdb) == c["resp"]
 
 
-@pytest.mark.parametrize("mode", ["split", "launches"])
+@pytest.mark.parametrize("mode", ["split", "launches", "one_launch_rounds"])
 @pytest.mark.parametrize("ci", [0, 1, 2, 4, 6, 8, 11, 12, 13])
 def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mode):
     """The expansion schedules over gadget widths from 2 to 56 digits, 28-bit digits included: everything on one stream, and
     the odd subtree + GSW side on the second stream (SPIRAL_EXPAND_SPLIT, profiles/r02_expand_experiments.md); expand_query
-    and the response must not change, twice in a row on the same workspace (join of the previous odd side)."""
+    and the response must not change, twice in a row on the same workspace (join of the previous odd side).
+    `one_launch_rounds`: every round's digit transforms and products in ONE launch (k_expand_round, which the library takes
+    for rounds of expand_round_min digit transforms or more -- here for every round)."""
     cfg = _FUZZ[ci]
     # launches (the default of narrow databases): one stream; split (the default before a pipelined sweep): the odd subtree
     # + GSW side on the second stream
-    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "1" if mode == "split" else "0")
+    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", "0" if mode == "launches" else "1")
+    monkeypatch.setenv("SPIRAL_EXPAND_ROUND_MIN", "1" if mode == "one_launch_rounds" else str(1 << 30))
+    monkeypatch.setenv("SPIRAL_EXPAND_ROUND_ODD", "1")   # (the odd subtree of a split expansion too; off by default)
     idx = (613 * (ci + 1)) % oracle_mod.Params(cfg).num_items
     c = _oracle_case(oracle_mod, cfg, idx, 70 + ci, 170 + ci)   # (shared by the two schedules of a configuration)
     o, pp, q, db = c["o"], c["pp"], c["q"], c["db"]
@@ -1271,7 +1275,10 @@ def test_expansion_variants_response_parity(sp, oracle_mod, monkeypatch, ci, mod
     sp.paths_taken()
     v_reg, v_fold = sp.expand_query(p, gpp, q)
     taken = sp.paths_taken()
-    assert ("expand_split" in taken) == (mode == "split"), taken
+    assert ("expand_split" in taken) == (mode != "launches"), taken
+    # (k_expand_round keeps its digits in 32-bit words: gadget digits of more than 28 bits -- t_exp = 2 -- stay on the three-launch form)
+    narrow = all(56 // cfg[k] + 1 <= 28 for k in ("t_exp_left", "t_exp_right"))
+    assert ("expand_round_one_launch" in taken) == (mode == "one_launch_rounds" and narrow), taken
     e_reg, e_fold = o.expand_query(pp, q)
     assert (v_reg == e_reg).all() and (v_fold == e_fold).all()
     expect = c["resp"]

@@ -24,7 +24,8 @@ LIMITS = {
                  # k_fold_fused2 (fallback for gadget widths the wave kernel does not take): 12 bytes since the lazy inverse butterfly
                  # (r05, timed: profiles/r05_call1_ab.md), three dwords outside its transform loops
                  "k_fold_fusedE": (0, 256), "k_fold_fused2E": (16, 256)},
-    "ntt.hip": {"k_from_sweep4E": (0, 256), "k_ntt_invE": (0, 128), "k_ntt_fwdE": (0, 128), "k_ntt_fwd3E": (0, 128)},
+    "ntt.hip": {"k_from_sweep4E": (0, 256), "k_ntt_invE": (0, 128), "k_ntt_fwdE": (0, 128), "k_ntt_fwd3E": (0, 128),
+                "k_expand_roundE": (0, 168)},
     "sweep.hip": {"k_sweep_packed_ringILi8E": (0, 256), "k_sweep_packed_ringILi4E": (0, 256), "k_sweep_packed_ringILi2E": (0, 256),
                   "k_sweep_packed_persistE": (0, 256), "k_sweep_wideE": (0, 256),
                   # the batched passes on the matrix cores over the PACKED words: the one-tile form is clean; the two-tile form (16
