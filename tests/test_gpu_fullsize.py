@@ -130,9 +130,12 @@ def test_c2_batch8_matrix_core_pass_at_full_size(sp, oracle_mod):
 
 
 def test_c2_batch16_two_query_tiles_at_full_size(sp, oracle_mod):
-    """Sixteen queries per database pass at full size (k_sweep_mfma_batch, two query tiles: 128 KiB of query digits in LDS,
-    one workgroup per CU, ring of 8 sixteen-row steps): one response of each tile byte for byte against the oracle, all
-    sixteen against the groups-of-8 path that the test above ties to the oracle."""
+    """Sixteen queries per database pass at full size.  The production pass of a 9-16-query group is k_sweep_planar over the
+    digit-planar copy of the database (sweep_planar.hpp: +64 GiB beside the 56 GiB PACKED words, built on the first group) --
+    asserted through sp_paths_taken, so that a silent fall-back to the PACKED two-tile kernel (no room for the copy) fails here
+    instead of passing: one response of each query tile byte for byte against the oracle.  Then the same sixteen through the
+    fall-back itself (`batch_planar` = 0: k_sweep_mfma_batch with two query tiles, the path of databases too large for a copy,
+    C3 / C4) and through groups of 8 (one tile, the path the test above ties to the oracle): identical bytes."""
     import ctypes as C
     _need_hbm(130)
     o, cl, pp = _client(oracle_mod, C2, 501)
@@ -143,16 +146,21 @@ def test_c2_batch16_two_query_tiles_at_full_size(sp, oracle_mod):
     sp.paths_taken()
     outs = sp.process_query_batch(p, gpp, queries, db)
     taken = sp.paths_taken()
-    assert {"sweep_batch", "sweep_batch_mfma", "sweep_batch_mfma_two_tiles"} <= taken, taken
+    assert {"sweep_batch", "sweep_batch_mfma", "sweep_batch_mfma_two_tiles", "sweep_batch_planar"} <= taken, taken
     for k in (3, 12):
         want = o.process_query_synth(pp, queries[k], SEED)
         assert outs[k] == want, "query %d of the sixteen differs from the oracle (sha %s vs %s)" % (
             k, hashlib.sha256(outs[k]).hexdigest()[:16], hashlib.sha256(want).hexdigest()[:16])
-    sp.lib().sp_debug_set(b"batch_group", C.c_long(8))
-    try:
-        assert sp.process_query_batch(p, gpp, queries, db) == outs
-    finally:
-        sp.lib().sp_debug_set(b"batch_group", C.c_long(0))
+    for switch, value, must, must_not in ((b"batch_planar", 0, "sweep_batch_mfma_two_tiles", "sweep_batch_planar"),
+                                          (b"batch_group", 8, "sweep_batch_mfma", "sweep_batch_mfma_two_tiles")):
+        sp.lib().sp_debug_set(switch, C.c_long(value))
+        try:
+            sp.paths_taken()
+            assert sp.process_query_batch(p, gpp, queries, db) == outs, switch
+            taken = sp.paths_taken()
+            assert must in taken and must_not not in taken, (switch, taken)
+        finally:
+            sp.lib().sp_debug_set(switch, C.c_long(1 if switch == b"batch_planar" else 0))
     del db
     gc.collect()
 

@@ -256,9 +256,12 @@ def test_coefficient_expansion_and_regev_to_gsw(sp, oracle_mod):
     assert (sp.regev_to_gsw(p, gpp, v_gsw_inp, o.db_dim_2) == o.regev_to_gsw(v_gsw_inp, v_conv, o.db_dim_2)).all()
 
 
-@pytest.mark.parametrize("dim0,num_per", [(64, 4), (512, 32), (16, 64), (300, 128), (64, 256), (512, 1), (700, 2)])
+@pytest.mark.parametrize("dim0,num_per", [(64, 4), (512, 32), (16, 64), (300, 128), (64, 256), (512, 1), (700, 2),
+                                          (1024, 2), (1024, 64), (1024, 128), (2048, 4)])
 def test_multiply_reg_by_database_shapes(sp, oracle_mod, dim0, num_per):
-    """db sweep on random (not NTT-of-plaintext) words incl. ragged dim0 and the >255-row fold path."""
+    """db sweep on random (not NTT-of-plaintext) words incl. ragged dim0 and the >255-row fold path; 1024 rows = nu_1 = 10 of
+    CFG_16_100000 (util.rs:21-34: (1024, 64) is its plane shape; (1024, 128) the same depth on the PACKED ring kernel), 2048 rows
+    beyond every shipped configuration."""
     p, o = _pair(sp, oracle_mod, FAST)
     rng = np.random.default_rng(dim0 * 1000 + num_per)
     N = 2048
