@@ -128,10 +128,16 @@ int sp_db_update_item(sp_db_t*, size_t item_idx, const uint8_t* data, size_t len
 /* Synthetic benchmark database generated on the device: reference-layout word index i holds
  * sp_synth_word(seed, i).  (Roofline runs at sizes no host buffer can hold.) */
 int sp_db_fill_synthetic(sp_db_t*, uint64_t seed);
+/* Build now what batched calls would otherwise build inside the first sp_process_query_batch of 9 .. 16 queries: the
+ * digit-planar copy of an unsharded PACKED database (8 more bytes per word) that the two-tile matrix-core pass reads --
+ * when the shape has one and the device has the room (call it after the load, e.g. where bin/server.rs:98-141 has loaded
+ * the database).  *built (may be null): 1 = the copy stands, 0 = this database keeps to the PACKED kernels.  The copy
+ * follows sp_db_update_item in place (8 sixteen-byte entries per (plane, z)); the bulk loaders drop it. */
+int sp_db_prepare_batch(sp_db_t*, int* built);
 uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index);
 /* Read back words of the reference-layout view (debug / tests): plane, z, ii, j0..j0+count within the shard's rows */
 int sp_db_read_ref(const sp_db_t*, int plane, int z, int ii, int j0, int count, uint64_t* out);
-size_t sp_db_device_bytes(const sp_db_t*);
+size_t sp_db_device_bytes(const sp_db_t*); /* device memory the handle holds now (the planar copy included while it stands) */
 
 /* ------------------------------------------------------- PublicParameters
  * client.rs:212-259 PublicParameters::deserialize(params, data): 32-byte seed, row 0 of every
@@ -150,7 +156,13 @@ int sp_pp_export(const sp_pp_t*, uint64_t* out, size_t cap_words, size_t* n_word
  * out must hold response_bytes. */
 int sp_process_query(const sp_params_t*, const sp_pp_t*, const uint8_t* query, size_t query_len,
                      const sp_db_t*, uint8_t* out, size_t out_cap, size_t* out_len);
-/* Same, B queries against one database pass each (sequentially pipelined on one stream). */
+/* The per-request loop of lib/server (bin/server.rs:152-158: process_query for every query of the list) as one call: the
+ * responses are those of `batch` sp_process_query calls, out + i * out_stride each.  On an unsharded PACKED database the
+ * queries share database passes in groups -- up to 8 per pass, up to 16 where the two-tile matrix-core pass applies (which
+ * reads the digit-planar copy of the database when one stands: sp_db_prepare_batch) -- with the next group's expansions
+ * queued behind the current group's folds; on 8-byte (narrow) databases it is one pass per query with up to three queries
+ * in flight on their own streams.  Out of memory is handled inside the call (the planar copy is given back, then groups of
+ * 8 one at a time, then one query at a time) before it is reported. */
 int sp_process_query_batch(const sp_params_t*, const sp_pp_t* const* pps, const uint8_t* const* queries,
                            const size_t* query_lens, int batch, const sp_db_t*, uint8_t* out,
                            size_t out_stride, size_t* out_len);

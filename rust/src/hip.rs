@@ -82,6 +82,7 @@ pub mod sys {
         pub fn sp_db_load_items(db: *mut sp_db_t, file: *const u8, file_len: usize) -> c_int;
         pub fn sp_db_update_item(db: *mut sp_db_t, item_idx: usize, data: *const u8, len: usize) -> c_int;
         pub fn sp_db_fill_synthetic(db: *mut sp_db_t, seed: u64) -> c_int;
+        pub fn sp_db_prepare_batch(db: *mut sp_db_t, built: *mut c_int) -> c_int;
         pub fn sp_synth_word(seed: u64, ref_index: u64) -> u64;
         pub fn sp_db_read_ref(db: *const sp_db_t, plane: c_int, z: c_int, ii: c_int, j0: c_int, count: c_int, out: *mut u64) -> c_int;
         pub fn sp_db_device_bytes(db: *const sp_db_t) -> usize;
@@ -329,6 +330,13 @@ impl Database {
     }
     pub fn fill_synthetic(&mut self, seed: u64) {
         must(check(unsafe { sys::sp_db_fill_synthetic(self.0, seed) }))
+    }
+    /// Builds the digit-planar copy that lists of 9..16 queries read, at load time instead of inside the first such
+    /// list; `true` when the copy stands (unsharded PACKED database with room for 8 more bytes per word).
+    pub fn prepare_batch(&mut self) -> bool {
+        let mut built: c_int = 0;
+        must(check(unsafe { sys::sp_db_prepare_batch(self.0, &mut built) }));
+        built != 0
     }
     pub fn device_bytes(&self) -> usize {
         unsafe { sys::sp_db_device_bytes(self.0) }

@@ -8,7 +8,7 @@ import sqlite3
 import sys
 
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-from sdk_amd.kernel_signature import SWEEP_C2, kernel_signature  # noqa: E402
+from sdk_amd.kernel_signature import SWEEP_C2, compiler_version, kernel_signature  # noqa: E402
 
 
 def mean_counter(db, counter, kernel_substr):
@@ -28,6 +28,7 @@ def main(fetch_db, write_db, out, kernel="k_sweep_packed_", launches_per_query=4
         # identity of the profiled kernel: bench.py replays this record only into a library whose kernel has the same machine code
         "kernel_signature": sig,
         "kernel_signature_of": mangled,
+        "hipcc_version": compiler_version(),   # of the build that was profiled (tests/test_traffic_replay_guard.py)
         "note": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on `python bench.py "
                 "--steps 1 --warmup 0 --sweep-iters 2 --no-cpu-baseline`, config c2, kernel %s (7-byte PACKED "
                 "database, one launch per plane), %d / %d dispatches" % (kernel, nf, nw),

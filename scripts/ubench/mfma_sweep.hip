@@ -235,7 +235,7 @@ static void run_variant16(Ctx& c, int cpw, int reps, const char* tag) {
   const int batch_was = c.batch;
   c.batch = 16;
   c.d.batch = 16;
-  const size_t lds = (size_t)c.nj * 128 * 2;
+  const size_t lds = (size_t)c.nj * 128 * 2 + 256;   // + the tiles' offset terms (r06)
   CK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_sweep_mfma_batch<NB, 1, DIAG, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   for (int b = 0; b < 16; b++) CK(hipMemset(c.out[b], 0xEE, (size_t)4 * N * c.num_per * 4));
   const dim3 grid((unsigned)((size_t)c.nz * (c.chunks / cpw)));

@@ -128,17 +128,23 @@ void check_device(int dev) {
 
 }  // namespace
 
-// The digit-planar copy of a PACKED, unsharded database (sweep_planar.hpp): what the 9 .. 16-query pass reads.  Built on first
-// use (one gather pass over the PACKED units), only when the device has the room for a second copy (8 bytes per word) beside
-// the workspaces of two groups; nullptr = keep to the PACKED kernels.
+// The digit-planar copy of a PACKED, unsharded database (sweep_planar.hpp): what the 9 .. 16-query pass reads.  Built by
+// sp_db_prepare_batch (at load time) or on first use (one gather pass over the PACKED units), only when the device has the room for
+// a second copy (8 bytes per word) beside the workspaces of two groups; nullptr = keep to the PACKED kernels.
 const unsigned char* sp_db::ensure_planar(hipStream_t s) {
   std::lock_guard<std::mutex> lk(mu);
-  if (tunable("batch_planar", 1) == 0) return nullptr;   // (run-time switch: an existing copy is kept, not used)
+  if (tunable("batch_planar", 1) == 0) {   // switched off: the copy's memory goes back too
+    drop_planar();
+    return nullptr;
+  }
   if (planar_state == 1) return reinterpret_cast<const unsigned char*>(planar.p);
-  if (planar_state < 0) return nullptr;
+  if (planar_state == -1) return nullptr;
   const Params& p = params->p;
-  planar_state = -1;
-  if (!packed || sparse || num_shards != 1 || col_G != 1 || !sweep_planar_shape_ok(np_local, nj)) return nullptr;
+  if (!packed || sparse || num_shards != 1 || col_G != 1 || !sweep_planar_shape_ok(np_local, nj)) {
+    planar_state = -1;
+    return nullptr;
+  }
+  planar_state = -2;   // until the copy stands: a shortfall of memory is looked at again next time
   const size_t bytes = sweep_planar_bytes((int)p.planes(), np_local, nj);
   if (planar.n * sizeof(u64) < bytes) {
     size_t fr = 0, tot = 0;
@@ -363,7 +369,7 @@ size_t sp_db_sparse_items(const sp_db_t* d) {
 sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, false); }
 sp_db_t* sp_db_create_columns(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, true); }
 void sp_db_free(sp_db_t* d) { delete d; }
-size_t sp_db_device_bytes(const sp_db_t* d) { return d ? (d->sparse ? d->polys.bytes() : d->words.bytes()) : 0; }
+size_t sp_db_device_bytes(const sp_db_t* d) { return d ? (d->sparse ? d->polys.bytes() : d->words.bytes() + d->planar.bytes()) : 0; }
 
 int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* words) {
   return guarded([&] {
@@ -373,7 +379,10 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     need(plane >= 0 && (size_t)plane < p.planes() && z0 >= 0 && nz >= 0 && (size_t)(z0 + nz) <= POLY_LEN, "bad plane / z range");
     check_device(d->device);
     std::lock_guard<std::mutex> lk(d->mu);
-    d->drop_planar();
+    struct DropAfter {   // on every path out, after the last write to `words` has completed (mu held)
+      sp_db* d;
+      ~DropAfter() { d->drop_planar(); }
+    } drop_after{d};
     const size_t row_words = p.num_per() * p.dim0();
     const size_t max_stage = ((size_t)64 << 20) / 8;  // 64 MiB staging
     const int zs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, max_stage / row_words));
@@ -411,11 +420,14 @@ int sp_db_load_items(sp_db_t* d, const uint8_t* file, size_t file_len) {
     need(d && (file || file_len == 0), "null argument");
     need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
-    d->drop_planar();
     sp_params* h = const_cast<sp_params*>(d->params);
     const Params& p = h->p;
     DeviceState& D = h->device_state();
     std::lock_guard<std::mutex> lk(d->mu);
+    struct DropAfter {
+      sp_db* d;
+      ~DropAfter() { d->drop_planar(); }
+    } drop_after{d};
     size_t logp = 0;
     while (((u64)1 << logp) < p.pt_modulus) logp++;
     const size_t chunks = p.planes();
@@ -470,7 +482,6 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
   return guarded([&] {
     need(d && (data || len == 0), "null argument");
     check_device(d->device);
-    d->drop_planar();
     sp_params* h = const_cast<sp_params*>(d->params);
     const Params& p = h->p;
     need(item_idx < p.num_items(), "item index out of range");
@@ -550,6 +561,11 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     e.only_item = (long)item_idx;
     e.only_q = (int)((ii / (size_t)d->col_G) / 2);
     launch_db_encode(D.T, e, 0);
+    // a planar copy follows the item: its 8 entries per (plane, z), regathered from the words just written (same stream) -- an
+    // upsert costs 64 KiB of writes, not a 64 GiB rebuild by the next group of 9 .. 16 queries
+    if (d->planar_state == 1)
+      launch_planar_patch_item(reinterpret_cast<unsigned char*>(d->planar.p), d->words.p, (int)p.planes(), d->np_local, d->nj,
+                               (int)j - d->j0, (int)(ii / (size_t)d->col_G), 0);
     HIP_CHECK(hipDeviceSynchronize());
   });
 }
@@ -559,10 +575,26 @@ int sp_db_fill_synthetic(sp_db_t* d, uint64_t seed) {
     need(d != nullptr, "null db");
     need(!d->sparse, "a sparse bucket is filled through sp_db_update_item");
     check_device(d->device);
-    d->drop_planar();
+    std::lock_guard<std::mutex> lk(d->mu);
+    struct DropAfter {
+      sp_db* d;
+      ~DropAfter() { d->drop_planar(); }
+    } drop_after{d};
     const Params& p = d->params->p;
     launch_db_synth(d->words.p, seed, (int)p.planes(), d->np_local, (int)p.dim0(), d->j0, d->nj, d->packed, d->colmap(), 0);
     HIP_CHECK(hipDeviceSynchronize());
+  });
+}
+
+// Everything a database needs for batched calls, built now instead of inside the first sp_process_query_batch of 9 .. 16 queries:
+// the digit-planar copy of a PACKED, unsharded database (+ 8 bytes per word; sweep_planar.hpp) when the shape has one and the
+// device has the room.  *built (optional): 1 = the copy stands, 0 = this database keeps to the PACKED kernels.
+int sp_db_prepare_batch(sp_db_t* d, int* built) {
+  return guarded([&] {
+    need(d != nullptr, "null db");
+    check_device(d->device);
+    const unsigned char* c = d->sparse ? nullptr : d->ensure_planar(nullptr);
+    if (built) *built = c != nullptr;
   });
 }
 uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index) { return synth_word(seed, ref_index); }
@@ -1009,6 +1041,10 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
   // most two groups hold workspaces at a time.  Measured at C2 (profiles/r02_fold_batch_experiments.md): the overlap
   // buys nothing yet -- 16 queries take 2 x the time of 8, and 8 as 2 x 4 are slower (195 vs 236 queries/s) -- because
   // the batched sweep's workgroups fill every CU's register file, so a fold wave only starts when the pass drains.
+  {  // the questions below (LDS opt-in limit, free memory) are put to the CURRENT device: it has to be the database's
+    const int rc0 = guarded([&] { check_device(db->device); });
+    if (rc0 != SP_OK) return rc0;
+  }
   const int shape_max = sweep_batch_group_max(db->np_local, db->nj);
   int group_max = (int)tunable("batch_group", 0);
   if (group_max <= 0) group_max = shape_max;
@@ -1039,11 +1075,16 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
   };
   size_t prev_group = 0;
   int start = 0;   // first query not yet answered (a retry after an out-of-memory resumes here)
+  bool use_planar = true, one_group = false;   // what the out-of-memory ladder below gives up, in this order
   auto run_groups = [&] {
     check_device(db->device);
     for (int g0 = start; g0 < batch; g0 += group_max) {
       const int B = std::min(group_max, batch - g0);
-      if (all_qs.size() > prev_group) drain(all_qs.size() - prev_group);  // keep only the previous group in flight
+      if (one_group) {
+        if (!all_qs.empty()) drain(all_qs.size());                        // nothing in flight beside this group
+      } else if (all_qs.size() > prev_group) {
+        drain(all_qs.size() - prev_group);                                // keep only the previous group in flight
+      }
       // 1. expand every query of the group on its own stream.  (r05: the sixteen expansions of a group are 8-10 of a step's 49 ms
       // and looked like a launch-rate problem -- 1,600 small launches, 1.5 kernels in flight.  They are not: enqueued by 1, 2, 4 or
       // 8 host threads, on 4, 8 or 16 hardware queues, or recorded and issued as ONE chain of ~100 table launches for the whole
@@ -1081,7 +1122,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       if (sweep_batch_wants_mfma(d)) {
         W0.batch_rq.ensure(sweep_batch_rq_words(d.nj, sweep_batch_tiles(d.batch)));
         d.rq = W0.batch_rq.p;
-        if (sweep_batch_tiles(d.batch) == 2) d.planar = const_cast<sp_db_t*>(db)->ensure_planar(W0.stream);
+        if (use_planar && sweep_batch_tiles(d.batch) == 2) d.planar = const_cast<sp_db_t*>(db)->ensure_planar(W0.stream);
       }
       sweep_batch_prepare(W0.D->T, d, W0.stream);
       // (a per-plane form of the pass with every query folding plane p beside the pass of plane p + 1 was measured in rounds
@@ -1110,13 +1151,32 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     prev_pass = nullptr;
   };
   int rc = guarded(run_groups);
-  if (rc == SP_E_OOM && group_max > SWEEP_BATCH_MAX) {
-    // no memory for the workspaces of two groups of 16 beside the database (the hipMemGetInfo estimate above is rough): give
-    // the in-flight queries' workspaces back and answer the rest in groups of 8.  Responses already copied out stay.
+  // Out of memory (the hipMemGetInfo estimates above are rough): give up, one after the other, what only makes the call faster, and
+  // answer the REST of the list each time -- responses already copied out stay.  (1) the digit-planar copy of the database (its
+  // memory is released; a later call may build it again when there is room); (2) groups of 16 and the second group in flight:
+  // groups of 8, one at a time -- the in-flight queries' workspaces went back to the pool, so a group of 8 needs no more than was
+  // already allocated unless the failure came before 8 workspaces existed; (3) one query at a time, one workspace.
+  for (int step = 1; rc == SP_E_OOM && step <= 3; step++) {
     abandon();
     (void)hipGetLastError();
     start = (int)drained;
-    group_max = SWEEP_BATCH_MAX;
+    if (step == 1) {
+      sp_db* wdb = const_cast<sp_db_t*>(db);
+      std::lock_guard<std::mutex> lk(wdb->mu);
+      use_planar = false;
+      if (!wdb->planar.p) continue;   // nothing to give back here: next step
+      wdb->drop_planar();
+      wdb->planar_state = -2;
+    } else if (step == 2) {
+      if (group_max <= SWEEP_BATCH_MAX && one_group) continue;
+      group_max = std::min(group_max, SWEEP_BATCH_MAX);
+      one_group = true;
+    } else {
+      rc = SP_OK;
+      for (int i = start; i < batch && rc == SP_OK; i++, drained++)
+        rc = sp_process_query(h, pps[i], queries[i], query_lens[i], db, out + (size_t)i * out_stride, out_stride, out_len);
+      break;
+    }
     rc = guarded(run_groups);
   }
   if (rc != SP_OK) {
@@ -1667,11 +1727,11 @@ int sp_fold_ciphertexts_fused(const sp_params_t* h, uint64_t* cts, size_t num_pe
       res = run_fold(*W, W->foldX.p, W->foldY.p, 1, (int)num_per, -1);
     } catch (...) {
       W->fused_min_pairs = saved;
-      W->fold_inputs_below_q = true;
+      W->fold_inputs_below_q = false;
       throw;
     }
     W->fused_min_pairs = saved;
-    W->fold_inputs_below_q = true;
+    W->fold_inputs_below_q = false;
     download_raw(*W, res, 2 * POLY_LEN, cts);
   });
 }

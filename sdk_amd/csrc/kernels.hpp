@@ -373,6 +373,8 @@ bool sweep_planar_shape_ok(int num_per, int nj);
 size_t sweep_planar_bytes(int planes, int num_per, int nj);
 // PACKED database -> digit-planar copy (one-time, per database; planes * N * num_per * nj * 8 bytes)
 void launch_packed_to_planar(unsigned char* planar, const u64* packed, int planes, int num_per, int nj, hipStream_t s);
+// ... and the 8 entries per (plane, z) that hold one item (local row j, local column ii), after sp_db_update_item
+void launch_planar_patch_item(unsigned char* planar, const u64* packed, int planes, int num_per, int nj, int j, int ii, hipStream_t s);
 void launch_sweep_planar(const DevTables& T, const SweepBatchDesc& d, hipStream_t s);   // sweep_planar.hip
 // does this shape / group size run on the matrix cores (switch batch_mfma, default on from batch_mfma_min = 4 queries)?
 // Groups of more than SWEEP_BATCH_MAX queries exist only there.

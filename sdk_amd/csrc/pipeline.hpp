@@ -52,10 +52,11 @@ struct Workspace {
   uint8_t* h_response = nullptr;
   bool host_pinned = true;  // the three staging buffers above come from hipHostMalloc (false: malloc, debug switch ws_pinned)
   bool delta_tail = true;  // unfused fold levels use the delta form too (false: literal two-matrix form)
-  // the ciphertexts run_fold is given are below Q (from_ntt / fold outputs: every query flow), so the fused kernels may skip the
-  // gadget digits that are then identically zero (FoldDesc::t_live); false while a stage-level entry point folds the CALLER's
-  // ciphertexts, which nothing constrains
-  bool fold_inputs_below_q = true;
+  // true only while run_fold works on ciphertexts the library produced itself (from_ntt / fold outputs: below Q; set by
+  // run_fold_canonical, server.cpp) or on a caller's ciphertexts the stage-level entry point has checked: the fused kernels may
+  // then skip the gadget digits that are identically zero (FoldDesc::t_live).  Default false: raw buffers from a caller or a peer
+  // rank are decomposed in full.
+  bool fold_inputs_below_q = false;
   int out_G = 1;  // column interleave of the sweep output (multi-GPU reduce-scatter path)
   bool zero_shortcuts = false;  // lib/server fold semantics (sparse buckets): set per query, every level fused
   long fused_min_pairs = 256;  // fold levels with at least this many (pair, plane) units use k_fold_fused

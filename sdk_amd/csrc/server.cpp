@@ -952,6 +952,18 @@ void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const i
 }
 
 // from_ntt + fold of `np` planes starting at plane pg0 (sweep_out -> final_cts), on W.stream
+// run_fold on ciphertexts this library has just produced itself (from_ntt / fold outputs: canonical, below Q) -- the only callers
+// that may let the fused kernels skip the dead top gadget digit (FoldDesc::t_live).  Everything else (stage-level entry points,
+// ciphertexts gathered from peer ranks or handed in by the caller of the split API) folds with every digit.
+static u64* run_fold_canonical(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_begin = 0, int d_end = -1) {
+  struct Mark {
+    Workspace& W;
+    explicit Mark(Workspace& w) : W(w) { W.fold_inputs_below_q = true; }
+    ~Mark() { W.fold_inputs_below_q = false; }
+  } mark(W);
+  return run_fold(W, X, Y, np, num_cts, top, d_begin, d_end);
+}
+
 static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
   const Params& p = *W.P;
   DeviceState& D = *W.D;
@@ -968,7 +980,7 @@ static void fold_planes(Workspace& W, size_t pg0, int np, bool premod) {
     inv.premod = premod ? 1 : 0;
     launch_ntt_inv(D.T, inv, s);
   }
-  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
+  u64* res = run_fold_canonical(W, W.foldX.p, W.foldY.p, np, (int)p.num_per(), -1);
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 
@@ -987,7 +999,7 @@ static int tail_defer_levels(const Params& p, long stop) {  // levels folded per
 static void fold_plane_head(Workspace& W, size_t pl, int levels) {  // from_ntt + the first `levels` levels, parked
   const Params& p = *W.P;
   launch_from_sweep4(W.D->T, W.sweep_out.p + pl * 4 * POLY_LEN * p.num_per(), (int)p.num_per(), 1, 0, W.foldX.p, W.stream);
-  u64* res = run_fold(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, levels);
+  u64* res = run_fold_canonical(W, W.foldX.p, W.foldY.p, 1, (int)p.num_per(), -1, 0, levels);
   const size_t cts = p.num_per() >> levels;
   HIP_CHECK(hipMemcpyAsync(W.fold_tail.p + pl * cts * 2 * POLY_LEN, res, cts * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
 }
@@ -995,7 +1007,7 @@ static void fold_tails(Workspace& W, int levels) {  // the parked planes togethe
   const Params& p = *W.P;
   const size_t cts = p.num_per() >> levels;
   u64* other = W.fold_tail.p + p.planes() * cts * 2 * POLY_LEN;
-  u64* res = run_fold(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1);
+  u64* res = run_fold_canonical(W, W.fold_tail.p, other, (int)p.planes(), (int)p.num_per(), -1, levels, -1);
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p, res, p.planes() * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, W.stream));
 }
 
@@ -1371,7 +1383,7 @@ static void fold_local_planes(Workspace& W, const u32* chunk, int G, size_t pg0,
     inv.premod = 1;
     launch_ntt_inv(D.T, inv, s);
   }
-  u64* res = run_fold(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
+  u64* res = run_fold_canonical(W, W.foldX.p, W.foldY.p, np, npl, (int)p.db_dim_2 - 1);
   HIP_CHECK(hipMemcpyAsync(W.final_cts.p + pg0 * 2 * POLY_LEN, res, (size_t)np * 2 * POLY_LEN * sizeof(u64), hipMemcpyDeviceToDevice, s));
 }
 

@@ -203,13 +203,19 @@ struct sp_db {
   int np_local = 0;                   // columns held = num_per / col_G
   spiral::ColMap colmap() const { return spiral::ColMap{col_g, col_G, np_local * col_G}; }
   spiral::DevBuf<spiral::u64> words;  // [plane][z][j_local][ii] (or the PACKED unit stream)
-  // digit-planar copy of a PACKED database for the 9 .. 16-query pass (sweep_planar.hpp): built from `words` by the first such
-  // group when the device has the room, dropped by every writer of `words`; planar_state: 0 = not built, 1 = valid, -1 = does
-  // not fit / not applicable (not tried again until the database is rewritten)
+  // digit-planar copy of a PACKED database for the 9 .. 16-query pass (sweep_planar.hpp): built from `words` by
+  // sp_db_prepare_batch or by the first such group when the device has the room; bulk writers of `words` invalidate it AFTER their
+  // write, under `mu` (a build between an early invalidation and the end of the write would stay valid and stale),
+  // sp_db_update_item patches its 8 entries per (plane, z) in place.  planar_state: 0 = not built, 1 = valid, -1 = the shape has
+  // no planar form (never tried again), -2 = no room when last tried (tried again by the next group / prepare call).  The memory is
+  // released when the switch `batch_planar` is off, when the copy is invalidated, and when a batched call runs out of memory.
   spiral::DevBuf<spiral::u64> planar;
   int planar_state = 0;
   const unsigned char* ensure_planar(hipStream_t s);   // capi.cpp; nullptr: use the PACKED kernels
-  void drop_planar() { planar_state = 0; }
+  void drop_planar() {                                  // caller holds mu
+    if (planar_state != -1) planar_state = 0;
+    planar.release();
+  }
   std::mutex mu;
   // ---- sparse bucket (sp_db_create_sparse; lib/server/src/db/sparse_db.rs:5-48): only present items are stored
   bool sparse = false;

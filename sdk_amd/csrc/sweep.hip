@@ -477,7 +477,7 @@ int sweep_batch_group_max(int num_per, int nj) {
     (void)hipGetLastError();
     return SWEEP_BATCH_MAX;
   }
-  return (size_t)lds_optin >= (size_t)nj * 128 * 2 ? SWEEP_GROUP_MAX : SWEEP_BATCH_MAX;
+  return (size_t)lds_optin >= (size_t)nj * 128 * 2 + 256 ? SWEEP_GROUP_MAX : SWEEP_BATCH_MAX;
 }
 void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
   d.use_mfma = 0;
@@ -537,7 +537,7 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
     // registers in AGPRs), the load ring as deep as the step count allows (one wave per SIMD has to keep the HBM pipe full
     // alone).  Measured (scripts/ubench/mfma_sweep.hip, profiles/r04_mfma_two_tiles.md): 4.19 ms per C2 plane for 16 queries
     // against 2.95 for 8 -- 1.05 instead of 1.48 ms of database pass per query.
-    const size_t lds2 = (size_t)d.nj * 128 * 2;
+    const size_t lds2 = (size_t)d.nj * 128 * 2 + 256;   // both tiles' digit tables of a z-row + their 16 x 16 bytes of offset terms
     const int steps = d.nj >> 4;
 #define SP_MFMA2(NB_)                                                                                                  \
   {                                                                                                                    \

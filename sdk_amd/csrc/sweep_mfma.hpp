@@ -183,8 +183,18 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
       out_b1[qt] = kb == k2 ? d.out[8 * qt + 2 * k2 + 1] : out_b1[qt];
     }
     // offset terms of this lane's four query columns n = 4 kb + i of the tile, both moduli (the same for every chunk)
-    off0[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + kb];
-    off1[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + 4 + kb];
+    if (QT == 1) {
+      off0[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + kb];
+      off1[qt] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)qt * N + z) * 8 + 4 + kb];
+    }
+  }
+  // two query tiles: the 16 offset registers would sit in scratch through the chunk loop; they wait in LDS behind the digit
+  // tables instead (256 bytes; the launch adds them to the dynamic size) and are read per chunk epilogue (lgkmcnt, not vmcnt)
+  mf_u32x4_t* const smem_off = reinterpret_cast<mf_u32x4_t*>(smem_rq) + (size_t)QT * n16;
+  if (QT == 2) {
+    if (threadIdx.x < 16)
+      smem_off[threadIdx.x] = reinterpret_cast<const mf_u32x4_t*>(d.rq_off)[((size_t)(threadIdx.x >> 3) * N + z) * 8 + (threadIdx.x & 7)];
+    __syncthreads();
   }
   mf_u32x4_t va[NB][2];
   mf_u32x3_t vb[NB][2];
@@ -277,18 +287,33 @@ __global__ __launch_bounds__(256, MINWG) void k_sweep_mfma_batch(DevTables T, Sw
     // chunk done: recombine the digit sums, reduce, store: register i = query column 4 kb + i (b = 2 kb + i / 2,
     // r = i % 2), lane mp = slot 16 g + mp = columns 2 (16 g + mp) + e
     const size_t rcw = (size_t)N * d.num_per;
-    const size_t col = DIAG == 5 ? (size_t)(32 * g + 2 * mp)
-                                 : (size_t)z * d.num_per + (size_t)(chunk0 + ch) * 128 + 32 * g + 2 * mp;
+    // (two query tiles: the epilogue derives its lane-dependent values from ONE opaque copy of the lane number, so that the
+    // chunk loop keeps no query pair, column or address of it alive -- each was a scratch slot)
+    int le = lane;
+    if (QT == 2) asm volatile("" : "+v"(le));
+    const int kbe = le >> 4, mpe = le & 15;
+    const size_t col = DIAG == 5 ? (size_t)(32 * g + 2 * mpe)
+                                 : (size_t)z * d.num_per + (size_t)(chunk0 + ch) * 128 + 32 * g + 2 * mpe;
 #pragma unroll
     for (int qt = 0; qt < QT; qt++)
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-      if (8 * qt + 2 * kb + (i >> 1) < d.batch) {
-        u32* ob = ((i >> 1) ? out_b1[qt] : out_b0[qt]) + ((size_t)plane * 4 + (i & 1) * 2) * rcw + col;
+      if (8 * qt + 2 * kbe + (i >> 1) < d.batch) {
+        u32* sel = (i >> 1) ? out_b1[qt] : out_b0[qt];
+        if (QT == 2) {
+          // two query tiles: every register counts (224 accumulators + the load ring).  Left alone, the compiler forms the 24
+          // loop-invariant store addresses of a chunk's epilogue before the chunk loop and parks them in scratch (49 dwords, r04-r05);
+          // from the opaque lane copy above they are per-chunk work: a dozen selects from the kernel arguments
+          sel = d.out[8 * qt + (i >> 1)];
+#pragma unroll
+          for (int k2 = 1; k2 < 4; k2++) sel = kbe == k2 ? d.out[8 * qt + 2 * k2 + (i >> 1)] : sel;
+        }
+        u32* ob = sel + ((size_t)plane * 4 + (i & 1) * 2) * rcw + col;
 #pragma unroll
         for (int c = 0; c < 2; c++) {
           const ModConst mc = c ? m1 : m0;
-          const u32 oc = c ? off1[qt][i] : off0[qt][i];
+          u32 oc = QT == 2 ? smem_off[qt * 8 + c * 4 + kbe][i] : (c ? off1[qt][i] : off0[qt][i]);
+          if (QT == 2) asm volatile("" : "+v"(oc));   // (as above: keeps (q << 29) + offset, 16 64-bit values, out of the chunk loop's live set)
           const u32 v0 = combine_digit_sums(acc[qt][0][c][0][i], acc[qt][0][c][1][i], acc[qt][0][c][2][i], acc[qt][0][c][3][i],
                                             acc[qt][0][c][4][i], acc[qt][0][c][5][i], acc[qt][0][c][6][i], mc, d.c4[c], d.c5[c], d.c6[c], oc);
           const u32 v1 = combine_digit_sums(acc[qt][1][c][0][i], acc[qt][1][c][1][i], acc[qt][1][c][2][i], acc[qt][1][c][3][i],

@@ -22,40 +22,61 @@ bool sweep_planar_shape_ok(int num_per, int nj) {
          (num_per % 128) == 0;
 }
 size_t sweep_planar_bytes(int planes, int num_per, int nj) { return (size_t)planes * N * (size_t)num_per * (size_t)nj * 8; }
-// one 16-byte planar entry per thread, [zp][chunk][g][c][block][e][a][lane], gathered from the PACKED units
-__global__ __launch_bounds__(256) void k_packed_to_planar(unsigned char* planar, const u32* packed, size_t entries, int num_per, int nj) {
+// one 16-byte planar entry, index [zp][chunk][g][c][block][e][a][lane], gathered from the PACKED units
+static __device__ __forceinline__ mf_u32x4_t planar_gather_entry(const u32* packed, size_t idx, int num_per, int nj) {
   const int chunks = num_per >> 7, blocks = nj >> 6, npairs = nj >> 1;
-  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < entries; idx += (size_t)gridDim.x * 256) {
-    const int lane = (int)(idx & 63);
-    size_t r = idx >> 6;
-    const int a = (int)(r & 3), e = (int)((r >> 2) & 1);
-    r >>= 3;
-    const int block = (int)(r % blocks);
-    r /= blocks;
-    const int c = (int)(r & 1);
-    r >>= 1;
-    const int g = (int)(r & 3);
-    r >>= 2;
-    const int chunk = (int)(r % chunks);
-    const size_t zp = r / chunks;
-    const int kb = lane >> 4, n = lane & 15;
-    const int slot = 16 * g + n;   // PACKED lane slot: columns 2 slot, 2 slot + 1 of the chunk; this tile's column is 2 slot + e
-    mf_u32x4_t o = {0u, 0u, 0u, 0u};
+  const int lane = (int)(idx & 63);
+  size_t r = idx >> 6;
+  const int a = (int)(r & 3), e = (int)((r >> 2) & 1);
+  r >>= 3;
+  const int block = (int)(r % blocks);
+  r /= blocks;
+  const int c = (int)(r & 1);
+  r >>= 1;
+  const int g = (int)(r & 3);
+  r >>= 2;
+  const int chunk = (int)(r % chunks);
+  const size_t zp = r / chunks;
+  const int kb = lane >> 4, n = lane & 15;
+  const int slot = 16 * g + n;   // PACKED lane slot: columns 2 slot, 2 slot + 1 of the chunk; this tile's column is 2 slot + e
+  mf_u32x4_t o = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const int j = 64 * block + 16 * kb + t;
-      const u32* unit = packed + packed_unit_offset(zp, j >> 1, chunk, npairs, chunks);
-      const u64 w = unpack_word(unit, slot, (j & 1) * 2 + e);
-      const u32 x = c ? (u32)(w >> 32) : (u32)w;
-      o[t >> 2] |= ((offset_digits(x) >> (8 * a)) & 0xffu) << (8 * (t & 3));
-    }
-    reinterpret_cast<mf_u32x4_t*>(planar)[idx] = o;
+  for (int t = 0; t < 16; t++) {
+    const int j = 64 * block + 16 * kb + t;
+    const u32* unit = packed + packed_unit_offset(zp, j >> 1, chunk, npairs, chunks);
+    const u64 w = unpack_word(unit, slot, (j & 1) * 2 + e);
+    const u32 x = c ? (u32)(w >> 32) : (u32)w;
+    o[t >> 2] |= ((offset_digits(x) >> (8 * a)) & 0xffu) << (8 * (t & 3));
   }
+  return o;
+}
+__global__ __launch_bounds__(256) void k_packed_to_planar(unsigned char* planar, const u32* packed, size_t entries, int num_per, int nj) {
+  for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < entries; idx += (size_t)gridDim.x * 256)
+    reinterpret_cast<mf_u32x4_t*>(planar)[idx] = planar_gather_entry(packed, idx, num_per, nj);
 }
 void launch_packed_to_planar(unsigned char* planar, const u64* packed, int planes, int num_per, int nj, hipStream_t s) {
   const size_t entries = sweep_planar_bytes(planes, num_per, nj) / 16;
   hipLaunchKernelGGL(k_packed_to_planar, dim3(256 * 64), dim3(256), 0, s, planar, reinterpret_cast<const u32*>(packed), entries, num_per, nj);
   launched(0, "k_packed_to_planar");
+}
+// sp_db_update_item on a database that has a planar copy: the item (local row j, local column ii) is one word per (plane, z) of
+// the PACKED words = one byte in each of the 8 entries (modulus c, digit a) of that (plane, z): regather those, one per thread
+__global__ __launch_bounds__(256) void k_planar_patch_item(unsigned char* planar, const u32* packed, size_t zps, int num_per, int nj, int j, int ii) {
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= zps * 8) return;
+  const size_t zp = t >> 3;
+  const int c = (int)((t >> 2) & 1), a = (int)(t & 3);
+  const int chunks = num_per >> 7, blocks = nj >> 6;
+  const int chunk = ii >> 7, col = ii & 127, slot = col >> 1, e = col & 1, g = slot >> 4, n = slot & 15;
+  const int block = j >> 6, kb = (j & 63) >> 4;
+  const size_t idx = planar_operand_offset(zp, chunk, g, block, e, c, a, chunks, blocks) / 16 + (size_t)(16 * kb + n);
+  reinterpret_cast<mf_u32x4_t*>(planar)[idx] = planar_gather_entry(packed, idx, num_per, nj);
+}
+void launch_planar_patch_item(unsigned char* planar, const u64* packed, int planes, int num_per, int nj, int j, int ii, hipStream_t s) {
+  const size_t zps = (size_t)planes * N;
+  hipLaunchKernelGGL(k_planar_patch_item, dim3((unsigned)((zps * 8 + 255) / 256)), dim3(256), 0, s, planar,
+                     reinterpret_cast<const u32*>(packed), zps, num_per, nj, j, ii);
+  launched(0, "k_planar_patch_item");
 }
 // the 9 .. 16-query pass over the planar copy: 3.47 ms per C2 plane against 4.19 for k_sweep_mfma_batch<8, 1, 0, 2> on the PACKED
 // words (scripts/ubench/mfma_planar.hip, profiles/r05_mfma_planar.md); eight waves per workgroup share the z-row's query planes

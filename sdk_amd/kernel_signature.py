@@ -72,6 +72,17 @@ def kernel_signature(so_path, name_fragment):
     return sig, name
 
 
+def compiler_version():
+    """first two lines of `hipcc --version` (HIP + clang build), or "" -- stored beside a record's signature: machine code compiled
+    by another hipcc differs without the kernel's SOURCE having changed, which a reader of a refused record wants to know"""
+    import subprocess
+    try:
+        out = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True, timeout=60).stdout
+        return " | ".join(line.strip() for line in out.splitlines()[:2])
+    except Exception:
+        return ""
+
+
 SWEEP_C2 = "k_sweep_packed_ringILi8E"   # the judged kernel: the ring-form PACKED sweep with buffers of 8 row pairs
 
 

@@ -439,6 +439,13 @@ class Database:
         _chk(lib().sp_db_fill_synthetic(_vp(self.h), C.c_uint64(seed)))
         return self
 
+    def prepare_batch(self):
+        """build what lists of 9..16 queries read (the digit-planar copy of an unsharded PACKED database) now, at load time;
+        True when the copy stands, False when this database keeps to the PACKED kernels (shape, or no room)"""
+        built = C.c_int(0)
+        _chk(lib().sp_db_prepare_batch(_vp(self.h), C.byref(built)))
+        return bool(built.value)
+
     def read_ref(self, plane, z, ii, j0, count):
         out = np.zeros(count, dtype=np.uint64)
         _chk(lib().sp_db_read_ref(_vp(self.h), C.c_int(plane), C.c_int(z), C.c_int(ii), C.c_int(j0), C.c_int(count),

@@ -1182,6 +1182,69 @@ def test_process_query_batch_two_query_tiles(sp, oracle_mod, nu_1, nu_2, B, chec
         assert cls[1].decode_response(resp[9 if B > 9 else 1]) == o.item_to_vec(o.generate_random_db_and_get_item(idxs[9 if B > 9 else 1])[0])
 
 
+@pytest.mark.parametrize("nu_1,nu_2", [(6, 7), (7, 8)], ids=["64x128", "128x256"])
+def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
+    """The digit-planar copy of a PACKED database (what groups of 9-16 queries read) over the life of a bucket:
+    built at load time by sp_db_prepare_batch; sp_db_update_item PATCHES it -- the 8 sixteen-byte entries per (plane, z) that hold
+    the item -- instead of invalidating 8 bytes per database word, so the batch after a series of upserts (first / last row and
+    column, both columns of a lane slot, both rows of a row pair, an overwrite) reads the copy and returns the oracle's bytes on
+    the edited file; a bulk writer drops it and gives the memory back; so does the switch."""
+    import ctypes as C
+    cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
+           "t_exp_right": 56, "instances": 1, "db_item_size": 256}
+    o = oracle_mod.Params(cfg)
+    p = sp.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(61)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    rng = np.random.default_rng(nu_1 + nu_2)
+    isz = o.db_item_size
+    blob = rng.integers(0, 256, o.num_items * isz, dtype=np.uint8)
+    gdb = sp.Database(p).load_items(blob)
+    words = gdb.device_bytes()
+    assert gdb.prepare_batch() is True
+    assert gdb.device_bytes() == words + 4 * 2048 * o.num_per * o.dim0 * 8       # + 8 bytes per database word
+    npr, d0 = o.num_per, o.dim0
+    edits = [0, 1, npr, npr + 1, (d0 - 1) * npr + npr - 1, (d0 // 2) * npr + 77, 3 * npr + 126, 3 * npr + 127, 64 * npr % o.num_items + 5, 1]
+    for k, it in enumerate(edits):
+        rec = rng.integers(0, 256, isz - (k % 4), dtype=np.uint8)
+        blob[it * isz:(it + 1) * isz] = 0
+        blob[it * isz:it * isz + rec.size] = rec
+        gdb.update_item(it, rec.tobytes())
+    assert gdb.device_bytes() == words + 4 * 2048 * npr * d0 * 8                 # the copy survived the upserts
+    exp = o.load_db_from_bytes(blob.tobytes())
+    B = 11
+    idxs = [edits[i] if i < 9 else (977 * i + 3) % o.num_items for i in range(B)]
+    qs = [cl.generate_query(idxs[i], 900 + i) for i in range(B)]
+    sp.paths_taken()
+    resp = sp.process_query_batch(p, [gpp] * B, qs, gdb)
+    assert "sweep_batch_planar" in sp.paths_taken()
+    for i in range(B):
+        assert resp[i] == o.process_query(pp, qs[i], exp), (i, idxs[i])
+    got = cl.decode_response(resp[4])
+    item = blob[idxs[4] * isz:(idxs[4] + 1) * isz].tobytes()
+    assert all(got[t * 64:(t + 1) * 64] == item[t * 64:(t + 1) * 64] for t in range(4))
+    # bulk writer: the copy and its memory go; the next group builds it again
+    gdb.load_items(blob)
+    assert gdb.device_bytes() == words
+    sp.paths_taken()
+    assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp
+    assert "sweep_batch_planar" in sp.paths_taken() and gdb.device_bytes() > words
+    # switched off: PACKED two-tile kernel, memory released
+    sp.lib().sp_debug_set(b"batch_planar", C.c_long(0))
+    try:
+        sp.paths_taken()
+        assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp
+        taken = sp.paths_taken()
+        assert "sweep_batch_planar" not in taken and "sweep_batch_mfma_two_tiles" in taken
+        assert gdb.device_bytes() == words
+        assert gdb.prepare_batch() is False
+    finally:
+        sp.lib().sp_debug_set(b"batch_planar", C.c_long(1))
+    # a narrow (8-byte) database has no planar form
+    assert sp.Database(sp.Params(dict(cfg, nu_2=3))).prepare_batch() is False
+
+
 def test_process_query_batch_matrix_core_extreme_digits(sp, oracle_mod):
     """Database words whose residues sit at the edges of the signed-digit split (every byte 0x80 / 0x7f, q - 1, 0, the
     largest top digit) in every row: the i32 digit sums of k_sweep_mfma_batch reach their largest magnitudes; 256 rows.

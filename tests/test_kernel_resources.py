@@ -28,11 +28,14 @@ LIMITS = {
                 "k_expand_roundE": (0, 168)},
     "sweep.hip": {"k_sweep_packed_ringILi8E": (0, 256), "k_sweep_packed_ringILi4E": (0, 256), "k_sweep_packed_ringILi2E": (0, 256),
                   "k_sweep_packed_persistE": (0, 256), "k_sweep_wideE": (0, 256),
-                  # the batched passes on the matrix cores over the PACKED words: the one-tile form is clean; the two-tile form (16
-                  # queries, one wave per SIMD, 256 VGPRs + 256 AGPRs) keeps 200 bytes of scratch outside its multiply loop.  Since
-                  # r05 it is the FALLBACK of groups of 9 .. 16 (no room for the digit-planar copy, or a first dimension that is not
-                  # whole 64-row blocks); the planar pass below has none
-                  "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (200, 512)},
+                  # the batched passes on the matrix cores over the PACKED words.  The two-tile form (16 queries, one wave per SIMD,
+                  # 256 VGPRs + 256 AGPRs; since r05 the FALLBACK of groups of 9 .. 16: databases with no room for the digit-planar
+                  # copy -- C3, C4 -- or a first dimension that is not whole 64-row blocks) carried 200 bytes of scratch in r04-r05:
+                  # 24 loop-invariant store addresses and 16 offset terms of the chunk epilogue, formed before the chunk loop and
+                  # parked.  r06: the epilogue recomputes them per chunk from an opaque copy of the lane number, the offsets wait in
+                  # LDS: one dword is left in the deepest ring (the lane number itself), none in the others
+                  "k_sweep_mfma_batchILi2ELi2ELi0ELi1E": (0, 256), "k_sweep_mfma_batchILi8ELi1ELi0ELi2E": (8, 512),
+                  "k_sweep_mfma_batchILi4ELi1ELi0ELi2E": (0, 512), "k_sweep_mfma_batchILi2ELi1ELi0ELi2E": (0, 512)},
     # r05: the 9 .. 16-query pass over the digit-planar copy -- one modulus per pass keeps its accumulators in the vector
     # registers: no scratch, and the eight-wave form (two waves per SIMD) stays under 256
     "sweep_planar.hip": {"k_sweep_planarILi4ELi2ELi0ELi1ELi8E": (0, 256), "k_sweep_planarILi2ELi2ELi0ELi1ELi8E": (0, 256),

@@ -10,7 +10,7 @@ from conftest import ROOT
 
 import bench
 from sdk_amd import library_path
-from sdk_amd.kernel_signature import SWEEP_C2, kernel_signature
+from sdk_amd.kernel_signature import SWEEP_C2, compiler_version, kernel_signature
 
 pytestmark = pytest.mark.skipif(not os.path.exists(library_path()), reason="libspiral_hip.so not built")
 
@@ -30,6 +30,15 @@ def test_newest_record_matches_the_built_library():
     a new PMC pass -- which is the point)."""
     sig, _ = kernel_signature(library_path(), SWEEP_C2)
     traffic, source = bench.pmc_traffic("c2", 1, 4, library_path())
+    if traffic is None:
+        # a library built by ANOTHER hipcc has other machine code for the same source: that is not the event this test is for
+        # (ADVICE r05).  Records carry the compiler of the profiled build since r06; older ones were made with the image's ROCm 7.2.0.
+        names = sorted(n for n in os.listdir(os.path.join(ROOT, "profiles")) if n.endswith("pmc_sweep_c2.json"))
+        rec = json.load(open(os.path.join(ROOT, "profiles", names[-1])))
+        recorded = rec.get("hipcc_version") or "HIP version: 7.2.26015"
+        here = compiler_version()
+        if not here or recorded.split(" | ")[0] not in here:
+            pytest.skip("built with %r, newest record %s was profiled on a build of %r" % (here, names[-1], recorded))
     assert traffic is not None and sig in source, source
     assert 14.5e9 < traffic < 16.5e9          # one plane launch: 15.1 GB algorithmic in the resident format
 
