@@ -338,6 +338,60 @@ def cpu_baseline(cfg_name, cfg):
     }
 
 
+def batched_pass_record(sp, cfg, db, runs, iters):
+    """One database pass for a whole group of begun queries, timed alone (sp_bench_sweep_batch: HIP events on the launch stream),
+    with the kernel that ran named from sp_paths_taken -- not from what the shape would normally pick -- and its bytes counted
+    in the format it READ: the digit-planar copy (8 bytes per word) for k_sweep_planar, the PACKED words (7) otherwise."""
+    sp.paths_taken()
+    pass_ms = sp.bench_sweep_batch(runs, db, iters)
+    taken = sp.paths_taken()
+    B = len(runs)
+    N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
+    planar = "sweep_batch_planar" in taken
+    two_tiles = "sweep_batch_mfma_two_tiles" in taken
+    db_bytes = db.batch_copy_bytes() if planar else db.device_bytes()
+    out_bytes = B * T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4
+    pass_bytes = db_bytes + B * N_ * (1 << cfg["nu_1"]) * 16 + out_bytes
+    kernel = ("k_sweep_planar<4, 2, 0, 1, 8> (two query tiles, digit-planar database)" if planar else
+              "k_sweep_mfma_batch<8, 1, 0, 2> (two query tiles, PACKED database)" if two_tiles else
+              "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % B)
+    return {"kernel": kernel, "planar": planar, "two_query_tiles": two_tiles, "queries_per_pass": B,
+            "database_format": "digit-planar copy, 8 bytes per word (sweep_planar.hpp)" if planar else "PACKED, 7 bytes per word",
+            "ms_per_pass": pass_ms, "ms_of_pass_per_query": pass_ms / B, "bytes_per_pass": pass_bytes,
+            "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+            "note": "database in the format the pass read + %d query slices + %d x u32 outputs (%.0f MB of HBM writes inside the "
+                    "read stream)" % (B, B, out_bytes / 1e6)}
+
+
+def batched_step(sp, torch, p, pp, db, cfg, B, steps, iters, single=None):
+    """`steps` timed lists of B queries through sp_process_query_batch after a self-check against the single-query path and two
+    warm-up lists (the first of which builds whatever the batched call builds once), + the pass kernel's own record."""
+    qs = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(B)]
+    outs = sp.process_query_batch(p, pp, qs, db)
+    if single is None:
+        single = [sp.process_query(p, pp, q, db) for q in qs]
+    check = "ok" if outs == single else "MISMATCH"
+    if check != "ok":
+        print("bench: responses of the %d-query step DIFFER from the single-query path" % B, file=sys.stderr, flush=True)
+    for _ in range(2):
+        sp.process_query_batch(p, pp, qs, db)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sp.process_query_batch(p, pp, qs, db)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    runs = [sp.QueryRun(p, pp, q, db=db) for q in qs]
+    try:
+        rec = batched_pass_record(sp, cfg, db, runs, iters)
+    finally:
+        for r in runs:
+            r.free()
+    return {"value": (B * steps / dt) if check == "ok" else None, "unit": "queries/s", "steps": steps, "queries_per_step": B,
+            "ms_per_step": dt * 1e3 / steps, "batch_selfcheck": check, "batched_pass": rec}, single
+
+
 def secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step):
     """Measurements the driver's default run also records, on the database the headline just used (BASELINE configs[1]
     resident): `sustained` (a long run of consecutive single queries: q/s of the first and of the last 100, GPU
@@ -367,66 +421,26 @@ def secondary_same_db(sp, torch, args, p, pp, db, queries, cfg, step):
             "note": "the headline's step repeated back to back, one query at a time, no pause; rocm-smi sampled outside "
                     "the loop"}
     if cfg["nu_2"] >= 7:
-        B, bsteps = 8, 5
-        qs8 = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(B)]
-        outs = sp.process_query_batch(p, pp, qs8, db)
-        single = [sp.process_query(p, pp, q, db) for q in qs8]
-        check = "ok" if outs == single else "MISMATCH"
-        if check != "ok":
-            print("bench: batched responses DIFFER from the single-query path", file=sys.stderr, flush=True)
-        for _ in range(2):
-            sp.process_query_batch(p, pp, qs8, db)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(bsteps):
-            sp.process_query_batch(p, pp, qs8, db)
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
-        runs = [sp.QueryRun(p, pp, q, db=db) for q in qs8]
-        sp.paths_taken()
-        pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
-        taken = sp.paths_taken()
-        for r in runs:
-            r.free()
-        N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
-        pass_bytes = db.device_bytes() + B * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
-        out["batch8"] = {
-            "workload": "BASELINE configs[4] at one GPU: 8 queries per step sharing ONE database pass (sp_process_query_batch)",
-            "value": (B * bsteps / dt) if check == "ok" else None, "unit": "queries/s", "steps": bsteps,
-            "queries_per_step": B, "ms_per_step": dt * 1e3 / bsteps, "batch_selfcheck": check,
-            "batched_pass": {"kernel": "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<8>",
-                             "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
-                             "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
-        # sixteen queries per step: ONE pass for all of them (two query tiles on the matrix cores, r04) where the shape allows
-        B16 = 16
-        qs16 = [synthetic_wire_bytes(p.query_bytes(), 100 + i) for i in range(B16)]
-        outs16 = sp.process_query_batch(p, pp, qs16, db)
-        check16 = "ok" if outs16[:8] == single and outs16[8:] == [sp.process_query(p, pp, q, db) for q in qs16[8:]] else "MISMATCH"
-        if check16 != "ok":
-            print("bench: responses of the 16-query pass DIFFER from the single-query path", file=sys.stderr, flush=True)
-        sp.paths_taken()
-        sp.process_query_batch(p, pp, qs16, db)
-        two_tiles = "sweep_batch_mfma_two_tiles" in sp.paths_taken()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(3):
-            sp.process_query_batch(p, pp, qs16, db)
-        torch.cuda.synchronize()
-        dt16 = time.perf_counter() - t0
-        runs = [sp.QueryRun(p, pp, q, db=db) for q in qs16]
-        pass16_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
-        for r in runs:
-            r.free()
-        pass16_bytes = db.device_bytes() + B16 * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
-        out["batch16"] = {
-            "workload": "16 queries per step sharing ONE database pass (sp_process_query_batch; two query tiles per pass: %s)" % two_tiles,
-            "value": (B16 * 3 / dt16) if check16 == "ok" else None, "unit": "queries/s", "steps": 3, "queries_per_step": B16,
-            "ms_per_step": dt16 * 1e3 / 3, "batch_selfcheck": check16,
-            "batched_pass": {"kernel": "k_sweep_mfma_batch<8, 1, 0, 2>" if two_tiles else "two passes of k_sweep_mfma_batch<2, 2>",
-                             "ms_per_pass": pass16_ms, "ms_of_pass_per_query": pass16_ms / B16, "bytes_per_pass": pass16_bytes,
-                             "achieved": pass16_bytes / (pass16_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                             "frac": pass16_bytes / (pass16_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS}}
+        rec8, single8 = batched_step(sp, torch, p, pp, db, cfg, 8, 5, args.sweep_iters)
+        out["batch8"] = dict({"workload": "BASELINE configs[4] at one GPU: 8 queries per step sharing ONE database pass "
+                                          "(sp_process_query_batch)"}, **rec8)
+        # sixteen queries per step: ONE pass for all of them (two query tiles on the matrix cores; over the digit-planar copy of
+        # the database where the device has room for one -- built here, at load time, as a host would: sp_db_prepare_batch)
+        prepared = db.prepare_batch()
+        single16 = single8 + [sp.process_query(p, pp, synthetic_wire_bytes(p.query_bytes(), 100 + i), db) for i in range(8, 16)]
+        rec16, _ = batched_step(sp, torch, p, pp, db, cfg, 16, 3, args.sweep_iters, single=single16)
+        out["batch16"] = dict({"workload": "16 queries per step sharing ONE database pass (sp_process_query_batch; two query tiles "
+                                           "per pass: %s; digit-planar copy built by sp_db_prepare_batch: %s)"
+                                           % (rec16["batched_pass"]["two_query_tiles"], prepared)}, **rec16)
+        # the same sixteen through the FALLBACK of that pass -- the two-tile kernel over the PACKED words, what databases with no
+        # room for a planar copy run (C3, C4) -- so that it has a number too; switching the copy off releases its memory
+        sp.lib().sp_debug_set(b"batch_planar", C.c_long(0))
+        try:
+            recf, _ = batched_step(sp, torch, p, pp, db, cfg, 16, 2, args.sweep_iters, single=single16)
+            out["batch16_packed_fallback"] = dict({"workload": "as batch16 with SPIRAL_BATCH_PLANAR=0: k_sweep_mfma_batch, two query "
+                                                               "tiles, over the PACKED words"}, **recf)
+        finally:
+            sp.lib().sp_debug_set(b"batch_planar", C.c_long(1))
     return out
 
 
@@ -476,6 +490,13 @@ def secondary_c4(sp, torch, args):
                         "achieved": moved / (in_situ_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                         "frac": moved / (in_situ_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
            "fill_seconds": fill_s}
+    # the batched pass on a database too large for a digit-planar copy: 8 queries per step over the PACKED words (VERDICT r05
+    # item 4; the two-tile PACKED kernel's number is `secondary.batch16_packed_fallback`, on C2)
+    # (groups of 16 do not form here: 32 workspaces of ~3 GiB do not fit beside 224 GiB, the library keeps to groups of 8)
+    try:
+        res["batch8"], _ = batched_step(sp, torch, p, pp, db, cfg, 8, 2, 2)
+    except sp.SpiralError as e:
+        res["batch8"] = {"error": str(e)[:300]}
     del db, pp, p
     return res
 
@@ -727,32 +748,15 @@ def main():
     batch_pass = None
     if mode in ("single", "replicas") and batch > 1 and cfg["nu_2"] >= 7 and (1 << cfg["nu_1"]) % 2 == 0:   # PACKED databases only
         runs = [sp.QueryRun(p, pp, queries[k % len(queries)], db=db) for k in range(min(batch, 16 if batch > 8 else 8))]
-        sp.paths_taken()
         try:
-            pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
+            batch_pass = batched_pass_record(sp, cfg, db, runs, args.sweep_iters)
         except sp.SpiralError:          # a shape without the two-tile pass: groups of 8
             for r in runs[8:]:
                 r.free()
             runs = runs[:8]
-            pass_ms = sp.bench_sweep_batch(runs, db, args.sweep_iters)
-        taken = sp.paths_taken()
+            batch_pass = batched_pass_record(sp, cfg, db, runs, args.sweep_iters)
         for r in runs:
             r.free()
-        N_, T_ = 2048, cfg["instances"] * cfg["n"] ** 2
-        # the 9 .. 16-query pass reads the digit-planar copy of the database where it exists: 8 bytes per word instead of 7
-        planar = "sweep_batch_planar" in taken
-        pass_db_bytes = db.device_bytes() * 8 // 7 if planar else db.device_bytes()
-        pass_bytes = pass_db_bytes + len(runs) * (N_ * (1 << cfg["nu_1"]) * 16 + T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4)
-        batch_pass = {"kernel": "k_sweep_planar<4, 2, 0, 1, 8> (two query tiles, digit-planar database)" if planar else
-                                "k_sweep_mfma_batch<8, 1, 0, 2> (two query tiles)" if "sweep_batch_mfma_two_tiles" in taken else
-                                "k_sweep_mfma_batch<2, 2>" if "sweep_batch_mfma" in taken else "k_sweep_packed_batch<%d>" % len(runs),
-                      "queries_per_pass": len(runs), "ms_per_pass": pass_ms, "bytes_per_pass": pass_bytes,
-                      "database_format": "digit-planar copy, 8 bytes per word (sweep_planar.hpp)" if planar else "PACKED, 7 bytes per word",
-                      "achieved": pass_bytes / (pass_ms * 1e-3) / 1e9, "frac": pass_bytes / (pass_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                      "note": "one pass over the whole resident database for the whole group (sp_bench_sweep_batch, HIP events "
-                              "on the launch stream): PACKED database + %d query slices + %d x u32 outputs; the outputs "
-                              "(%.0f MB per pass) are HBM WRITES, which cost 3-4x a read byte when mixed into the read stream "
-                              "on this part (scripts/ubench/rw_mix.hip)" % (len(runs), len(runs), len(runs) * T_ * (1 << cfg["nu_2"]) * 4 * N_ * 4 / 1e6)}
     shards = world if sharded else 1
     alg_bytes = sweep_algorithmic_bytes(cfg, shards) / launches
     moved_bytes = sweep_moved_bytes(cfg, shards, db.device_bytes()) / launches

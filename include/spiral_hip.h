@@ -137,7 +137,8 @@ int sp_db_prepare_batch(sp_db_t*, int* built);
 uint64_t sp_synth_word(uint64_t seed, uint64_t ref_index);
 /* Read back words of the reference-layout view (debug / tests): plane, z, ii, j0..j0+count within the shard's rows */
 int sp_db_read_ref(const sp_db_t*, int plane, int z, int ii, int j0, int count, uint64_t* out);
-size_t sp_db_device_bytes(const sp_db_t*); /* device memory the handle holds now (the planar copy included while it stands) */
+size_t sp_db_device_bytes(const sp_db_t*);      /* the resident database words */
+size_t sp_db_batch_copy_bytes(const sp_db_t*);  /* the digit-planar copy beside them while it stands (sp_db_prepare_batch), else 0 */
 
 /* ------------------------------------------------------- PublicParameters
  * client.rs:212-259 PublicParameters::deserialize(params, data): 32-byte seed, row 0 of every

@@ -83,6 +83,7 @@ pub mod sys {
         pub fn sp_db_update_item(db: *mut sp_db_t, item_idx: usize, data: *const u8, len: usize) -> c_int;
         pub fn sp_db_fill_synthetic(db: *mut sp_db_t, seed: u64) -> c_int;
         pub fn sp_db_prepare_batch(db: *mut sp_db_t, built: *mut c_int) -> c_int;
+        pub fn sp_db_batch_copy_bytes(db: *const sp_db_t) -> usize;
         pub fn sp_synth_word(seed: u64, ref_index: u64) -> u64;
         pub fn sp_db_read_ref(db: *const sp_db_t, plane: c_int, z: c_int, ii: c_int, j0: c_int, count: c_int, out: *mut u64) -> c_int;
         pub fn sp_db_device_bytes(db: *const sp_db_t) -> usize;
@@ -340,6 +341,10 @@ impl Database {
     }
     pub fn device_bytes(&self) -> usize {
         unsafe { sys::sp_db_device_bytes(self.0) }
+    }
+    /// Bytes of the digit-planar copy while it stands (0 otherwise).
+    pub fn batch_copy_bytes(&self) -> usize {
+        unsafe { sys::sp_db_batch_copy_bytes(self.0) }
     }
 }
 impl Drop for Database {

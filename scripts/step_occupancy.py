@@ -7,19 +7,24 @@ import sys
 
 rows = [l.rstrip('\n').split('\t') for l in open(sys.argv[1]) if not l.startswith('#')][1:]
 R = [(r[0], float(r[1]), float(r[2]), r[3], r[4]) for r in rows]
-passes = [r for r in R if r[0].startswith('k_sweep_mfma_batch')]
+PASS_KERNELS = ('k_sweep_mfma_batch', 'k_sweep_planar', 'k_sweep_packed_batch')   # whichever pass the group took (r05: planar)
+passes = [r for r in R if r[0].startswith(PASS_KERNELS)]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+if len(passes) < 2:
+    sys.exit("step_occupancy: %d batched passes in %s (kernels seen: %s) -- need two to delimit a step"
+             % (len(passes), sys.argv[1], ", ".join(sorted({r[0].split('<')[0] for r in R}))[:400]))
+k = min(k, len(passes) - 2)
 t0, t1 = passes[k][1] - 200, passes[k + 1][1] - 200
 
 
 def cls(n):
-    if n.startswith('k_sweep_mfma'):
+    if n.startswith(PASS_KERNELS):
         return 'pass'
     if n.startswith('k_fold'):
         return 'fold'
     if n.startswith('k_from'):
         return 'from_ntt'
-    if n.startswith(('k_ntt_fwd', 'k_ntt_inv', 'k_mac')):
+    if n.startswith(('k_ntt_fwd', 'k_ntt_inv', 'k_mac', 'k_expand')):
         return 'expand'
     return 'other'
 

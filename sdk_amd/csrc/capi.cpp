@@ -369,7 +369,8 @@ size_t sp_db_sparse_items(const sp_db_t* d) {
 sp_db_t* sp_db_create(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, false); }
 sp_db_t* sp_db_create_columns(const sp_params_t* h, int shard, int num_shards) { return db_create_impl(h, shard, num_shards, true); }
 void sp_db_free(sp_db_t* d) { delete d; }
-size_t sp_db_device_bytes(const sp_db_t* d) { return d ? (d->sparse ? d->polys.bytes() : d->words.bytes() + d->planar.bytes()) : 0; }
+size_t sp_db_device_bytes(const sp_db_t* d) { return d ? (d->sparse ? d->polys.bytes() : d->words.bytes()) : 0; }
+size_t sp_db_batch_copy_bytes(const sp_db_t* d) { return d ? d->planar.bytes() : 0; }
 
 int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* words) {
   return guarded([&] {

@@ -63,6 +63,8 @@ def lib():
         L.sp_db_free.argtypes = [C.c_void_p]
         L.sp_db_device_bytes.restype = C.c_size_t
         L.sp_db_device_bytes.argtypes = [C.c_void_p]
+        L.sp_db_batch_copy_bytes.restype = C.c_size_t
+        L.sp_db_batch_copy_bytes.argtypes = [C.c_void_p]
         L.sp_synth_word.restype = C.c_uint64
         L.sp_synth_word.argtypes = [C.c_uint64, C.c_uint64]
         L.sp_pp_deserialize.restype = C.c_void_p
@@ -454,6 +456,10 @@ class Database:
 
     def device_bytes(self):
         return int(lib().sp_db_device_bytes(_vp(self.h)))
+
+    def batch_copy_bytes(self):
+        """bytes of the digit-planar copy beside the resident words while it stands (prepare_batch), else 0"""
+        return int(lib().sp_db_batch_copy_bytes(_vp(self.h)))
 
 
 def synth_word(seed, ref_index):

@@ -1201,9 +1201,10 @@ def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
     isz = o.db_item_size
     blob = rng.integers(0, 256, o.num_items * isz, dtype=np.uint8)
     gdb = sp.Database(p).load_items(blob)
-    words = gdb.device_bytes()
+    copy = 4 * 2048 * o.num_per * o.dim0 * 8                                      # 8 bytes per database word
+    assert gdb.batch_copy_bytes() == 0
     assert gdb.prepare_batch() is True
-    assert gdb.device_bytes() == words + 4 * 2048 * o.num_per * o.dim0 * 8       # + 8 bytes per database word
+    assert gdb.batch_copy_bytes() == copy
     npr, d0 = o.num_per, o.dim0
     edits = [0, 1, npr, npr + 1, (d0 - 1) * npr + npr - 1, (d0 // 2) * npr + 77, 3 * npr + 126, 3 * npr + 127, 64 * npr % o.num_items + 5, 1]
     for k, it in enumerate(edits):
@@ -1211,7 +1212,7 @@ def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
         blob[it * isz:(it + 1) * isz] = 0
         blob[it * isz:it * isz + rec.size] = rec
         gdb.update_item(it, rec.tobytes())
-    assert gdb.device_bytes() == words + 4 * 2048 * npr * d0 * 8                 # the copy survived the upserts
+    assert gdb.batch_copy_bytes() == copy                                        # the copy survived the upserts
     exp = o.load_db_from_bytes(blob.tobytes())
     B = 11
     idxs = [edits[i] if i < 9 else (977 * i + 3) % o.num_items for i in range(B)]
@@ -1226,10 +1227,10 @@ def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
     assert all(got[t * 64:(t + 1) * 64] == item[t * 64:(t + 1) * 64] for t in range(4))
     # bulk writer: the copy and its memory go; the next group builds it again
     gdb.load_items(blob)
-    assert gdb.device_bytes() == words
+    assert gdb.batch_copy_bytes() == 0
     sp.paths_taken()
     assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp
-    assert "sweep_batch_planar" in sp.paths_taken() and gdb.device_bytes() > words
+    assert "sweep_batch_planar" in sp.paths_taken() and gdb.batch_copy_bytes() == copy
     # switched off: PACKED two-tile kernel, memory released
     sp.lib().sp_debug_set(b"batch_planar", C.c_long(0))
     try:
@@ -1237,7 +1238,7 @@ def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
         assert sp.process_query_batch(p, [gpp] * B, qs, gdb) == resp
         taken = sp.paths_taken()
         assert "sweep_batch_planar" not in taken and "sweep_batch_mfma_two_tiles" in taken
-        assert gdb.device_bytes() == words
+        assert gdb.batch_copy_bytes() == 0
         assert gdb.prepare_batch() is False
     finally:
         sp.lib().sp_debug_set(b"batch_planar", C.c_long(1))
