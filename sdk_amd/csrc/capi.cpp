@@ -227,7 +227,8 @@ const char* sp_path_name(int bit) {
                                 "from_sweep4_xcd_order", "fold_tail_persistent", "expand_round_one_launch", "sweep_sparse",
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
-                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8", "sweep_batch_planar"};
+                                "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8", "sweep_batch_planar",
+                                "expand_group"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -700,6 +701,24 @@ int sp_pp_export(const sp_pp_t* pp, uint64_t* out, size_t cap_words, size_t* n_w
 }
 
 // ------------------------------------------------------------------------------ process_query
+// a query object with its workspace, nothing enqueued yet but the "begin" event (the group flow of sp_process_query_batch, which
+// expands its queries together: run_begin_group); state 0 until the caller has begun it
+static sp_query_t* query_open(const sp_params_t* h, const sp_pp_t* pp) {
+  sp_query_t* out = nullptr;
+  int rc = guarded([&] {
+    need(h && pp, "null argument");
+    need(pp->params == h, "public parameters were created for different params");
+    check_device(pp->device);
+    auto q = std::make_unique<sp_query>();
+    q->params = const_cast<sp_params*>(h);
+    q->pp = pp;
+    q->ws = q->params->acquire_ws();
+    HIP_CHECK(hipEventRecord(q->ws->ev[0], q->ws->stream));
+    out = q.release();
+  });
+  return rc == SP_OK ? out : nullptr;
+}
+
 sp_query_t* sp_query_begin(const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len) {
   return sp_query_begin_for_db(h, pp, query, query_len, nullptr);
 }
@@ -1091,9 +1110,13 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       // 8 host threads, on 4, 8 or 16 hardware queues, or recorded and issued as ONE chain of ~100 table launches for the whole
       // group, they take the same time -- 0.5 ms of a query's expansion is transforms that fill the chip (320 k forward NTTs, more
       // than its fold has).  profiles/r05_batch16_step_timeline.md, r05_batch_expand.md; scripts/archive/r05_batch_expand/.)
+      // r06: they ARE 2x off the transform rate, and the cure is the shape of the launches, not their number: a round of ONE query
+      // under-fills the chip until its last rounds (a right-hand ciphertext's 57 transforms run in sequence in one workgroup), so
+      // the group's rounds are shared launches with the query as one more grid dimension (run_begin_group; switch expand_group).
       const size_t first = all_qs.size();
+      const bool group_expand = B >= 2 && p.expand_queries && tunable("expand_group", 1) != 0;
       for (int i = 0; i < B; i++) {
-        sp_query_t* q = sp_query_begin(h, pps[g0 + i], queries[g0 + i], query_lens[g0 + i]);
+        sp_query_t* q = group_expand ? query_open(h, pps[g0 + i]) : sp_query_begin(h, pps[g0 + i], queries[g0 + i], query_lens[g0 + i]);
         if (!q) {
           if (g_last_rc == SP_E_OOM) throw OomError(g_last_error);   // (reported by status: the caller retries in smaller groups)
           throw ArgError(g_last_error);
@@ -1102,6 +1125,15 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         q->ws->ensure_sweep();
       }
       sp_query_t* const* qs = all_qs.data() + first;
+      if (group_expand) {
+        Workspace* Ws[GROUP_MAX];
+        for (int i = 0; i < B; i++) Ws[i] = qs[i]->ws.get();
+        run_begin_group(Ws, pps + g0, queries + g0, query_lens + g0, B);
+        for (int i = 0; i < B; i++) {
+          HIP_CHECK(hipEventRecord(Ws[i]->ev[1], Ws[i]->stream));
+          qs[i]->state = 1;
+        }
+      }
       // 2. one database pass for the whole group, on the first query's stream, after the previous group's pass
       Workspace& W0 = *qs[0]->ws;
       SweepBatchDesc d{};

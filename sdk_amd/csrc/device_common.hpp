@@ -548,4 +548,10 @@ __device__ __forceinline__ u64 unpack_word(const u32* unit, int lane, int which)
   return (u64)f[0] | ((u64)f[1] << 32);
 }
 
+// query qi's buffer from query 0's pointer (GroupOff, kernels.hpp): a null pointer stays null
+template <typename P>
+__device__ __forceinline__ P* group_rebase(P* p, long long byte_off) {
+  return p ? reinterpret_cast<P*>(reinterpret_cast<unsigned long long>(p) + (unsigned long long)byte_off) : p;
+}
+
 }  // namespace spiral

@@ -17,6 +17,30 @@ __global__ __launch_bounds__(256) void k_mac2(DevTables T, MacDesc d0, MacDesc d
   else
     mac_body(T, d1, y - d0.batch_inner, 0, blockIdx.y);
 }
+// grouped form (kernels.hpp, GroupOff): grid.z = query
+__global__ __launch_bounds__(256) void k_mac2_group(DevTables T, MacDesc d0, MacDesc d1, GroupOff g) {
+  const int qi = blockIdx.z;
+  int y = blockIdx.x;
+  MacDesc d = d0;
+  if (y >= d0.batch_inner) {
+    d = d1;
+    y -= d0.batch_inner;
+  }
+  d.A = group_rebase(d.A, g.pp[qi]);
+  d.B = group_rebase(d.B, g.dig[qi]);
+  d.out = group_rebase(d.out, g.v[qi]);
+  d.addend = group_rebase(d.addend, g.v[qi]);
+  d.extra = group_rebase(d.extra, g.ct1[qi]);
+  mac_body(T, d, y, 0, blockIdx.y);
+}
+void launch_mac2_group(const DevTables& T, const MacDesc& d0, const MacDesc& d1, const GroupOff& g, int B, hipStream_t s) {
+  MacDesc a = d0, b = d1;
+  a.batch_inner = std::max(a.batch_inner, 0);
+  b.batch_inner = std::max(b.batch_inner, 0);
+  if (a.batch_inner + b.batch_inner <= 0 || B <= 0) return;
+  hipLaunchKernelGGL(k_mac2_group, dim3(a.batch_inner + b.batch_inner, 2 * N / 256, B), dim3(256), 0, s, T, a, b, g);
+  launched(PATH_EXPAND_GROUP, "k_mac2_group");
+}
 void launch_mac(const DevTables& T, const MacDesc& d, hipStream_t s) {
   if (d.batch_inner <= 0 || d.batch_outer <= 0) return;
   hipLaunchKernelGGL(k_mac, dim3(d.batch_inner, 2 * N / 256, d.batch_outer), dim3(256), 0, s, T, d);

@@ -76,7 +76,8 @@ enum PathBit : u64 {
   PATH_SWEEP_RING = 1ull << 28,       // k_sweep_packed_ring (persistent sweep, two buffers of row pairs per wave)
   PATH_SWEEP_MFMA2 = 1ull << 29,      // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
   PATH_FOLD_WAVE8 = 1ull << 30,       // (retired in the round that built it: k_fold_wave8, profiles/r05_fold_wave8.md)
-  PATH_SWEEP_PLANAR = 1ull << 31      // k_sweep_planar: the 9 .. 16-query pass over the digit-planar copy of the database
+  PATH_SWEEP_PLANAR = 1ull << 31,     // k_sweep_planar: the 9 .. 16-query pass over the digit-planar copy of the database
+  PATH_EXPAND_GROUP = 1ull << 32      // a group's expansions with every round's launches shared (grid dimension = query; r06)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -196,6 +197,25 @@ struct ExpandSideDesc {
 };
 void launch_expand_round(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, hipStream_t s);
 constexpr long EXPAND_ROUND_MIN_DEFAULT = 2048;
+
+// ---- the expansions of a GROUP of queries with every round's launches shared (batched steps, r06) ------------------------------
+// The queries of a group have the same Params (same index lists, same schedule) but each its own workspace buffers and its own
+// public parameters.  A grouped launch is the single-query launch with one more grid dimension = the query; its descriptors are
+// query 0's, and query qi's pointers are query 0's plus a BYTE offset per class of buffer: v (the ciphertext tree, NTT form), raw
+// (the round's automorphed ciphertexts), dig (their digit transforms), ct1 (the transforms of their second rows), pp (the public
+// parameters' polynomials).  A round of 16 queries then fills the chip from round 2 or 3 on, where sixteen separate chains each
+// left most of it idle behind four hardware queues (profiles/r06_group_expansion.md).
+constexpr int GROUP_MAX = 16;   // == SWEEP_GROUP_MAX
+struct GroupOff {
+  long long v[GROUP_MAX], raw[GROUP_MAX], dig[GROUP_MAX], ct1[GROUP_MAX], pp[GROUP_MAX];
+};
+void launch_ntt_inv_group(const DevTables& T, const InvDesc& d, const GroupOff& g, int B, hipStream_t s);      // src, scal_dst: v; dst: raw
+void launch_ntt_fwd3_group(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, const GroupOff& g, int B,
+                           hipStream_t s);                                                                         // src: raw; dst: dig, dig, ct1
+void launch_mac2_group(const DevTables& T, const MacDesc& d0, const MacDesc& d1, const GroupOff& g, int B, hipStream_t s);   // A: pp; B: dig; out, addend: v; extra: ct1
+void launch_expand_round_group(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, const GroupOff& g, int B,
+                               hipStream_t s);                                                                     // raw: raw; A: pp; v: v
+constexpr long EXPAND_GROUP_ROUND_MIN_DEFAULT = 4096;   // digit transforms per modulus of the WHOLE group from which a round is one launch
 
 // ---- fused fold step (server.rs:407-424) ----------------------------------------------------
 // One workgroup per (pair i, plane): out[plane][i] = from_ntt( [G-C | C] * NTT(G^-1([ct_i ; ct_{i+half}])) ),

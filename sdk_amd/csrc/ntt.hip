@@ -88,6 +88,37 @@ __global__ __launch_bounds__(256) void k_ntt_fwd3(DevTables T, FwdDesc d0, FwdDe
     ntt_fwd_body(T, d2, o - d0.n_out - d1.n_out, blockIdx.y, ldsA, ldsB);
   }
 }
+// grouped form (kernels.hpp, GroupOff): grid.z = query
+__global__ __launch_bounds__(256) void k_ntt_fwd3_group(DevTables T, FwdDesc d0, FwdDesc d1, FwdDesc d2, GroupOff g) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  const int qi = blockIdx.z;
+  int o = blockIdx.x;
+  FwdDesc d = d0;
+  long long dst_off = g.dig[qi];
+  if (o >= d0.n_out + d1.n_out) {
+    d = d2;
+    o -= d0.n_out + d1.n_out;
+    dst_off = g.ct1[qi];
+  } else if (o >= d0.n_out) {
+    d = d1;
+    o -= d0.n_out;
+  }
+  d.src = group_rebase(d.src, g.raw[qi]);
+  d.dst = group_rebase(d.dst, dst_off);
+  ntt_fwd_body(T, d, o, blockIdx.y, ldsA, ldsB);
+}
+void launch_ntt_fwd3_group(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, const FwdDesc& d2, const GroupOff& g, int B,
+                           hipStream_t s) {
+  const int total = std::max(d0.n_out, 0) + std::max(d1.n_out, 0) + std::max(d2.n_out, 0);
+  if (total <= 0 || B <= 0) return;
+  FwdDesc a = d0, b = d1, c = d2;
+  a.n_out = std::max(a.n_out, 0);
+  b.n_out = std::max(b.n_out, 0);
+  c.n_out = std::max(c.n_out, 0);
+  hipLaunchKernelGGL(k_ntt_fwd3_group, dim3(total, 2, B), dim3(256), 0, s, T, a, b, c, g);
+  launched(PATH_EXPAND_GROUP, "k_ntt_fwd3_group");
+}
 void launch_ntt_fwd(const DevTables& T, const FwdDesc& d, hipStream_t s) {
   if (d.n_out <= 0) return;
   hipLaunchKernelGGL(k_ntt_fwd, dim3(d.n_out, 2), dim3(256), 0, s, T, d);
@@ -107,15 +138,10 @@ void launch_ntt_fwd3(const DevTables& T, const FwdDesc& d0, const FwdDesc& d1, c
 // ------------------------------------------------------------------------------------------------
 // One expansion round's digit transforms and products (kernels.hpp, ExpandSideDesc): grid (left.cnt + right.cnt, 2 moduli).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_expand_round(DevTables T, ExpandSideDesc dl, ExpandSideDesc dr) {
-  constexpr int GD = 4;   // digit polynomials per transform pass
-  __shared__ u32 lds0[GD * LDS_WORDS];
-  __shared__ u32 lds1[GD * LDS_WORDS];
+constexpr int EXPAND_GD = 4;   // digit polynomials per transform pass
+static __device__ __forceinline__ void expand_round_body(const DevTables& T, const ExpandSideDesc& d, int b, int c, u32* lds0, u32* lds1) {
+  constexpr int GD = EXPAND_GD;
   const int tau = threadIdx.x;
-  const int c = blockIdx.y;
-  const bool right = (int)blockIdx.x >= dl.cnt;
-  const ExpandSideDesc& d = right ? dr : dl;
-  const int b = (int)blockIdx.x - (right ? dl.cnt : 0);
   const ModConst m = T.c.mod[c];
   const u32* fw = T.tw + (size_t)c * 4 * N;
   const u64* src = d.raw + (size_t)d.pos[b] * 2 * N;
@@ -185,6 +211,35 @@ __global__ __launch_bounds__(256) void k_expand_round(DevTables T, ExpandSideDes
   reinterpret_cast<uint4*>(o1)[0] = make_uint4(w1[0], w1[1], w1[2], w1[3]);
   reinterpret_cast<uint4*>(o1)[1] = make_uint4(w1[4], w1[5], w1[6], w1[7]);
 }
+__global__ __launch_bounds__(256) void k_expand_round(DevTables T, ExpandSideDesc dl, ExpandSideDesc dr) {
+  __shared__ u32 lds0[EXPAND_GD * LDS_WORDS];
+  __shared__ u32 lds1[EXPAND_GD * LDS_WORDS];
+  const bool right = (int)blockIdx.x >= dl.cnt;
+  expand_round_body(T, right ? dr : dl, (int)blockIdx.x - (right ? dl.cnt : 0), blockIdx.y, lds0, lds1);
+}
+// grouped form (kernels.hpp, GroupOff): grid.z = query.  The RIGHT side's workgroups come first: a right-hand ciphertext has 56
+// one-bit digits (15 transform passes) against 8 (3) on the left, so the long workgroups start first and the short ones fill in
+__global__ __launch_bounds__(256) void k_expand_round_group(DevTables T, ExpandSideDesc dl, ExpandSideDesc dr, GroupOff g) {
+  __shared__ u32 lds0[EXPAND_GD * LDS_WORDS];
+  __shared__ u32 lds1[EXPAND_GD * LDS_WORDS];
+  const int qi = blockIdx.z;
+  const bool right = (int)blockIdx.x < dr.cnt;
+  ExpandSideDesc d = right ? dr : dl;
+  d.raw = group_rebase(d.raw, g.raw[qi]);
+  d.A = group_rebase(d.A, g.pp[qi]);
+  d.v = group_rebase(d.v, g.v[qi]);
+  expand_round_body(T, d, (int)blockIdx.x - (right ? 0 : dr.cnt), blockIdx.y, lds0, lds1);
+}
+void launch_expand_round_group(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, const GroupOff& g, int B,
+                               hipStream_t s) {
+  const int total = std::max(left.cnt, 0) + std::max(right.cnt, 0);
+  if (total <= 0 || B <= 0) return;
+  ExpandSideDesc a = left, b = right;
+  a.cnt = std::max(a.cnt, 0);
+  b.cnt = std::max(b.cnt, 0);
+  hipLaunchKernelGGL(k_expand_round_group, dim3(total, 2, B), dim3(256), 0, s, T, a, b, g);
+  launched(PATH_EXPAND_FUSED | PATH_EXPAND_GROUP, "k_expand_round_group");
+}
 void launch_expand_round(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, hipStream_t s) {
   const int total = std::max(left.cnt, 0) + std::max(right.cnt, 0);
   if (total <= 0) return;
@@ -204,6 +259,22 @@ __global__ __launch_bounds__(256) void k_ntt_inv(DevTables T, InvDesc d) {
   __shared__ u32 ldsA[LDS_WORDS];
   __shared__ u32 ldsB[LDS_WORDS];
   ntt_inv_body(T, d, blockIdx.x, ldsA, ldsB);
+}
+// grouped form (kernels.hpp, GroupOff): grid.y = query
+__global__ __launch_bounds__(256) void k_ntt_inv_group(DevTables T, InvDesc d, GroupOff g) {
+  __shared__ u32 ldsA[LDS_WORDS];
+  __shared__ u32 ldsB[LDS_WORDS];
+  const int qi = blockIdx.y;
+  d.src = group_rebase(d.src, g.v[qi]);
+  d.scal_dst = group_rebase(d.scal_dst, g.v[qi]);
+  d.dst = group_rebase(d.dst, g.raw[qi]);
+  ntt_inv_body(T, d, blockIdx.x, ldsA, ldsB);
+}
+void launch_ntt_inv_group(const DevTables& T, const InvDesc& d, const GroupOff& g, int B, hipStream_t s) {
+  const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);
+  if (blocks <= 0 || B <= 0) return;
+  hipLaunchKernelGGL(k_ntt_inv_group, dim3(blocks, B), dim3(256), 0, s, T, d, g);
+  launched(PATH_EXPAND_GROUP, "k_ntt_inv_group");
 }
 void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
   const int blocks = d.n_polys + (d.scal ? 2 * d.n_scalar_only : 0);

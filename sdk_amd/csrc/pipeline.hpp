@@ -80,6 +80,8 @@ void run_folding_neg(Workspace& W);
 void run_mats_to_wave(Workspace& W, size_t levels);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
+// B queries of one group (same params, un-pruned): the expansions' rounds as shared launches (kernels.hpp, GroupOff)
+void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_t* const* queries, const size_t* query_lens, int B);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0,
                const DeviceState::PrunedPlan* plan = nullptr);
 void run_sweep_sparse(Workspace& W, const sp_db& db, const int* col_ptr, const int* col_rows, const int* col_slots);

@@ -634,119 +634,167 @@ static void on_stream(Workspace& W, hipStream_t s, const std::function<void()>& 
 
 void join_right(Workspace& W);
 
+// the launches of ONE expansion round of one query (server.rs:80-110), as descriptors
+struct RoundLaunches {
+  InvDesc inv;            // (1) v[num_in + i] = neg1[r] * v[i] fused into ct = from_ntt(v_i); ct_auto = automorph(ct, t)
+  FwdDesc fd[3];          // (2) gadget_invert_rdim(ct_auto, rdim = 1) -> to_ntt_no_reduce for both sides, and to_ntt(ct_auto row 1)
+  MacDesc md[2];          // (3) v_i += W * ginv + [0; to_ntt(ct_auto row 1)]   (server.rs:89-102)
+  ExpandSideDesc es[2];   // (2) + (3) as one launch (k_expand_round)
+  long round_transforms;  // digit transforms per modulus
+  bool digits_fit;        // k_expand_round takes the round's digit widths
+};
+static RoundLaunches round_launches(Workspace& W, const sp_pp& pp, const RoundPlan& rp, size_t r, const int* L, int tree) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  // the odd subtree has its own scratch: it runs concurrently with the even subtree (run_begin)
+  u64* const exp_raw = tree == 2 ? W.exp_raw_r.p : W.exp_raw.p;
+  u32* const exp_dig = tree == 2 ? W.exp_dig_r.p : W.exp_dig.p;
+  u32* const exp_ct1 = tree == 2 ? W.exp_ct1_r.p : W.exp_ct1.p;
+  const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
+  RoundLaunches R{};
+  InvDesc& inv = R.inv;
+  inv.src = W.v.p;
+  inv.idx = L + rp.all_ct;
+  inv.polys_per_idx = 2;
+  inv.idx_stride = 4 * POLY_LEN;
+  inv.poly_stride = 2 * POLY_LEN;
+  inv.crt_stride = POLY_LEN;
+  inv.z_stride = 1;
+  inv.dst = exp_raw;
+  inv.n_polys = rp.n_all * 2;
+  inv.automorph_t = rp.t_auto;
+  inv.scal = D.neg1.p + r * 2 * POLY_LEN;
+  inv.scal_dst = W.v.p;
+  inv.scal_thresh = rp.num_in;
+  inv.scal_only_idx = L + rp.skip2;
+  inv.n_scalar_only = rp.n_skip2;
+  for (int side = 0; side < 2; side++) {
+    const int cnt = side == 0 ? rp.n_left : rp.n_right;
+    const int t = side == 0 ? tl : tr;
+    FwdDesc f{};
+    f.src = exp_raw;
+    f.src_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
+    f.dst = exp_dig + (side == 0 ? 0 : (size_t)rp.n_left * tl * 2 * POLY_LEN);
+    f.n_out = cnt * t;
+    f.rdim = 1;
+    f.cols = 1;
+    f.t = t;
+    f.bits = (int)p.bits_per(t);
+    f.src_batch_stride = 2;
+    f.src_row0 = 0;
+    f.src_cols = 1;
+    R.fd[side] = f;
+  }
+  {
+    FwdDesc f1{};
+    f1.src = exp_raw;
+    f1.dst = exp_ct1;
+    f1.n_out = rp.n_all;
+    f1.rdim = 1;
+    f1.cols = 1;
+    f1.t = 1;
+    f1.bits = 64;
+    f1.src_batch_stride = 2;
+    f1.src_row0 = 1;
+    f1.src_cols = 1;
+    R.fd[2] = f1;
+  }
+  R.round_transforms = (long)rp.n_left * tl + (long)rp.n_right * tr;
+  R.digits_fit = R.fd[0].bits <= 28 && R.fd[1].bits <= 28;
+  for (int side = 0; side < 2; side++) {
+    const int cnt = side == 0 ? rp.n_left : rp.n_right;
+    const int t = side == 0 ? tl : tr;
+    // nu_2 == 0: expand_query passes v_w_left for both sides (server.rs:573)
+    const bool use_right = side == 1 && pp.has_right && p.db_dim_2 > 0;
+    const size_t woff = use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl;
+    MacDesc m{};
+    m.A = pp.all.p + woff * 2 * POLY_LEN;
+    m.B = R.fd[side].dst;
+    m.out = W.v.p;
+    m.addend = W.v.p;
+    m.out_idx = L + (side == 0 ? rp.left_out : rp.right_out);
+    m.R = 2;
+    m.K = t;
+    m.batch_inner = cnt;
+    m.batch_outer = 1;
+    m.B_inner_stride = t;
+    m.B_outer_stride = 0;
+    m.split_k = t;
+    m.split_off = 0;
+    m.out_batch_stride = 0;
+    m.out_row_stride = 1;
+    m.extra = exp_ct1;
+    m.extra_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
+    m.extra_row = 1;
+    R.md[side] = m;
+    R.es[side] = ExpandSideDesc{R.fd[side].src, R.fd[side].src_idx, m.out_idx, m.A, m.out, m.batch_inner, R.fd[side].t, R.fd[side].bits};
+  }
+  return R;
+}
+
 void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, const DeviceState::PrunedPlan* plan,
                                int tree, size_t r_begin) {
-  const Params& p = *W.P;
   DeviceState& D = *W.D;
   hipStream_t s = W.stream;
   const int* L = plan ? plan->lists.p : D.lists.p;
   const std::vector<RoundPlan>& rounds = tree == 1   ? (plan ? plan->rounds_even : D.rounds_even)
                                          : tree == 2 ? (plan ? plan->rounds_odd : D.rounds_odd)
                                                      : (plan ? plan->rounds : D.rounds);
-  // the odd subtree has its own scratch: it runs concurrently with the even subtree (run_begin)
-  u64* const exp_raw = tree == 2 ? W.exp_raw_r.p : W.exp_raw.p;
-  u32* const exp_dig = tree == 2 ? W.exp_dig_r.p : W.exp_dig.p;
-  u32* const exp_ct1 = tree == 2 ? W.exp_ct1_r.p : W.exp_ct1.p;
-  const int tl = (int)p.t_exp_left, tr = (int)p.t_exp_right;
   for (size_t r = r_begin; r < g_rounds; r++) {
     const RoundPlan& rp = rounds[r];
     if (rp.n_all == 0 && (tree != 0 || rp.n_skip2 == 0)) continue;  // (a subtree's skipped cts are never read again)
-    // three launches per round:
-    // (1) v[num_in + i] = neg1[r] * v[i] (server.rs:105-110) fused into ct = from_ntt(v_i); ct_auto = automorph(ct, t)
-    InvDesc inv{};
-    inv.src = W.v.p;
-    inv.idx = L + rp.all_ct;
-    inv.polys_per_idx = 2;
-    inv.idx_stride = 4 * POLY_LEN;
-    inv.poly_stride = 2 * POLY_LEN;
-    inv.crt_stride = POLY_LEN;
-    inv.z_stride = 1;
-    inv.dst = exp_raw;
-    inv.n_polys = rp.n_all * 2;
-    inv.automorph_t = rp.t_auto;
-    inv.scal = D.neg1.p + r * 2 * POLY_LEN;
-    inv.scal_dst = W.v.p;
-    inv.scal_thresh = rp.num_in;
-    inv.scal_only_idx = L + rp.skip2;
-    inv.n_scalar_only = rp.n_skip2;
-    launch_ntt_inv(D.T, inv, s);
-    // (2) gadget_invert_rdim(ct_auto, rdim = 1) -> to_ntt_no_reduce for both groups, and to_ntt(ct_auto row 1)
-    FwdDesc fd[3];
-    for (int side = 0; side < 2; side++) {
-      const int cnt = side == 0 ? rp.n_left : rp.n_right;
-      const int t = side == 0 ? tl : tr;
-      FwdDesc f{};
-      f.src = exp_raw;
-      f.src_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
-      f.dst = exp_dig + (side == 0 ? 0 : (size_t)rp.n_left * tl * 2 * POLY_LEN);
-      f.n_out = cnt * t;
-      f.rdim = 1;
-      f.cols = 1;
-      f.t = t;
-      f.bits = (int)p.bits_per(t);
-      f.src_batch_stride = 2;
-      f.src_row0 = 0;
-      f.src_cols = 1;
-      fd[side] = f;
-    }
-    {
-      FwdDesc f1{};
-      f1.src = exp_raw;
-      f1.dst = exp_ct1;
-      f1.n_out = rp.n_all;
-      f1.rdim = 1;
-      f1.cols = 1;
-      f1.t = 1;
-      f1.bits = 64;
-      f1.src_batch_stride = 2;
-      f1.src_row0 = 1;
-      f1.src_cols = 1;
-      fd[2] = f1;
-    }
-    // (2) + (3) in one launch where the round is large enough to fill the chip with one workgroup per (ciphertext, modulus):
-    // nothing but the results is written (kernels.hpp, launch_expand_round; switch expand_round_min = digit transforms per modulus)
-    const long round_transforms = (long)rp.n_left * tl + (long)rp.n_right * tr;
+    const RoundLaunches R = round_launches(W, pp, rp, r, L, tree);
+    // three launches per round -- or two: (2) + (3) in one launch where the round is large enough to fill the chip with one
+    // workgroup per (ciphertext, modulus): nothing but the results is written (kernels.hpp, launch_expand_round; switch
+    // expand_round_min = digit transforms per modulus).
     // NOT for the odd subtree of a split expansion (tree 2: it runs on the second stream beside the first sweep launches, and
     // its 57-pass workgroups cost the sweep more than the rounds gain: profiles/r05_expand_round.md; switch expand_round_odd)
-    const bool one_launch = round_transforms >= tunable("expand_round_min", EXPAND_ROUND_MIN_DEFAULT) && fd[0].bits <= 28 && fd[1].bits <= 28 &&
+    const bool one_launch = R.round_transforms >= tunable("expand_round_min", EXPAND_ROUND_MIN_DEFAULT) && R.digits_fit &&
                             (tree != 2 || tunable("expand_round_odd", 0) != 0);
-    if (!one_launch) launch_ntt_fwd3(D.T, fd[0], fd[1], fd[2], s);
-    // (3) v_i += W * ginv + [0; to_ntt(ct_auto row 1)]   (server.rs:89-102)
-    MacDesc md[2];
-    for (int side = 0; side < 2; side++) {
-      const int cnt = side == 0 ? rp.n_left : rp.n_right;
-      const int t = side == 0 ? tl : tr;
-      // nu_2 == 0: expand_query passes v_w_left for both sides (server.rs:573)
-      const bool use_right = side == 1 && pp.has_right && p.db_dim_2 > 0;
-      const size_t woff = use_right ? pp.off_right + r * 2 * tr : pp.off_left + r * 2 * tl;
-      MacDesc m{};
-      m.A = pp.all.p + woff * 2 * POLY_LEN;
-      m.B = fd[side].dst;
-      m.out = W.v.p;
-      m.addend = W.v.p;
-      m.out_idx = L + (side == 0 ? rp.left_out : rp.right_out);
-      m.R = 2;
-      m.K = t;
-      m.batch_inner = cnt;
-      m.batch_outer = 1;
-      m.B_inner_stride = t;
-      m.B_outer_stride = 0;
-      m.split_k = t;
-      m.split_off = 0;
-      m.out_batch_stride = 0;
-      m.out_row_stride = 1;
-      m.extra = exp_ct1;
-      m.extra_idx = L + (side == 0 ? rp.left_pos : rp.right_pos);
-      m.extra_row = 1;
-      md[side] = m;
-    }
+    launch_ntt_inv(D.T, R.inv, s);
     if (one_launch) {
-      ExpandSideDesc es[2];
-      for (int side = 0; side < 2; side++)
-        es[side] = ExpandSideDesc{fd[side].src, fd[side].src_idx, md[side].out_idx, md[side].A, md[side].out, md[side].batch_inner, fd[side].t, fd[side].bits};
-      launch_expand_round(D.T, es[0], es[1], s);
+      launch_expand_round(D.T, R.es[0], R.es[1], s);
     } else {
-      launch_mac2(D.T, md[0], md[1], s);
+      launch_ntt_fwd3(D.T, R.fd[0], R.fd[1], R.fd[2], s);
+      launch_mac2(D.T, R.md[0], R.md[1], s);
+    }
+  }
+}
+
+// The same rounds for a GROUP of B queries (same Params; each its own workspace and public parameters), every launch shared: one
+// more grid dimension = the query, query qi's buffers addressed as query 0's plus a byte offset per class (kernels.hpp, GroupOff).
+// Whole tree, no pruning, on Ws[0]'s stream -- the caller has ordered that stream after every query's v[0] and orders the queries'
+// own streams after it.  A round is one launch (k_expand_round) from `expand_group_round_min` digit transforms of the whole group.
+void run_group_expansion(Workspace* const* Ws, const sp_pp* const* pps, int B, size_t g_rounds) {
+  Workspace& W0 = *Ws[0];
+  DeviceState& D = *W0.D;
+  hipStream_t s = W0.stream;
+  const int* L = D.lists.p;
+  if (B < 1 || B > GROUP_MAX) throw ArgError("group size out of range");
+  GroupOff g{};
+  auto off = [](const void* q, const void* q0) { return (long long)((const char*)q - (const char*)q0); };
+  for (int i = 0; i < B; i++) {
+    Workspace& W = *Ws[i];
+    if (W.P != W0.P || W.D != W0.D) throw ArgError("a group's queries must share params and device");
+    g.v[i] = off(W.v.p, W0.v.p);
+    g.raw[i] = off(W.exp_raw.p, W0.exp_raw.p);
+    g.dig[i] = off(W.exp_dig.p, W0.exp_dig.p);
+    g.ct1[i] = off(W.exp_ct1.p, W0.exp_ct1.p);
+    g.pp[i] = off(pps[i]->all.p, pps[0]->all.p);
+    if (pps[i]->has_right != pps[0]->has_right || pps[i]->off_left != pps[0]->off_left || pps[i]->off_right != pps[0]->off_right)
+      throw ArgError("a group's public parameters must have one layout");
+  }
+  const long group_min = tunable("expand_group_round_min", EXPAND_GROUP_ROUND_MIN_DEFAULT);
+  for (size_t r = 0; r < g_rounds; r++) {
+    const RoundPlan& rp = D.rounds[r];
+    if (rp.n_all == 0 && rp.n_skip2 == 0) continue;
+    const RoundLaunches R = round_launches(W0, *pps[0], rp, r, L, 0);
+    launch_ntt_inv_group(D.T, R.inv, g, B, s);
+    if (R.round_transforms * B >= group_min && R.digits_fit) {
+      launch_expand_round_group(D.T, R.es[0], R.es[1], g, B, s);
+    } else {
+      launch_ntt_fwd3_group(D.T, R.fd[0], R.fd[1], R.fd[2], g, B, s);
+      launch_mac2_group(D.T, R.md[0], R.md[1], g, B, s);
     }
   }
 }
@@ -862,16 +910,10 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
   HIP_CHECK(hipStreamSynchronize(s));  // the host staging vectors go out of scope
 }
 
-// Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
-void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0, int nj,
-               const DeviceState::PrunedPlan* plan) {
+// Query::deserialize (client.rs:303-314) up to v[0] = query.ct.ntt() (server.rs:545), enqueued on W.stream
+static void run_begin_query_ct(Workspace& W, const uint8_t* query, size_t query_len) {
   const Params& p = *W.P;
-  DeviceState& D = *W.D;
   if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
-  if (!p.expand_queries) {
-    run_begin_direct(W, query);
-    return;
-  }
   if (p.db_dim_2 == 0 && p.t_exp_left != p.t_exp_right) throw ArgError("nu_2 == 0 requires t_exp_left == t_exp_right (server.rs:573)");
   W.ensure_expand();
   hipStream_t s = W.stream;
@@ -882,14 +924,65 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
   for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - (W.h_query[i] % p.modulus);
   memcpy(W.h_query + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
   HIP_CHECK(hipMemcpyAsync(W.q_raw.p, W.h_query, 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, s));
-  FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};  // v[0] = query.ct.ntt()  (server.rs:545)
+  FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};
+  launch_ntt_fwd(W.D->T, f, s);
+}
+
+// what follows the rounds of an un-pruned, un-split expansion: v_reg, the GSW side, G - C (server.rs:566-591, 505-523)
+static void run_begin_after_rounds(Workspace& W, const sp_pp& pp) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  const int* L = D.lists.p;
+  if (p.db_dim_2 > 0) {
+    launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), W.stream);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+    run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
+    run_folding_neg(W);
+  } else {
+    launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), W.stream);  // server.rs:574-576
+  }
+}
+
+// run_begin for a GROUP of queries that share one database pass (sp_process_query_batch): every query's ciphertext on its own
+// stream, the rounds of all expansions as shared launches on the first query's stream (run_group_expansion), then every query's
+// v_reg / GSW side / G - C on its own stream again.  Same values as B run_begin calls: the kernels are the same bodies.
+void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_t* const* queries, const size_t* query_lens, int B) {
+  Workspace& W0 = *Ws[0];
+  const Params& p = *W0.P;
+  if (!p.expand_queries) throw ArgError("run_begin_group: direct-upload queries have no expansion to share");
+  for (int i = 0; i < B; i++) {
+    run_begin_query_ct(*Ws[i], queries[i], query_lens[i]);
+    if (i > 0) {
+      HIP_CHECK(hipEventRecord(Ws[i]->ev_round0, Ws[i]->stream));
+      HIP_CHECK(hipStreamWaitEvent(W0.stream, Ws[i]->ev_round0, 0));
+    }
+  }
+  note_path(PATH_EXPAND_GROUP);
+  run_group_expansion(Ws, pps, B, p.g());
+  HIP_CHECK(hipEventRecord(W0.ev_round0, W0.stream));
+  for (int i = 0; i < B; i++) {
+    if (i > 0) HIP_CHECK(hipStreamWaitEvent(Ws[i]->stream, W0.ev_round0, 0));
+    run_begin_after_rounds(*Ws[i], *pps[i]);
+  }
+}
+
+// Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg
+void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0, int nj,
+               const DeviceState::PrunedPlan* plan) {
+  const Params& p = *W.P;
+  DeviceState& D = *W.D;
+  if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
+  if (!p.expand_queries) {
+    run_begin_direct(W, query);
+    return;
+  }
+  run_begin_query_ct(W, query, query_len);
+  hipStream_t s = W.stream;
   const size_t g = p.g();
   // a row shard only needs the first-dimension ciphertexts of its rows: prune the even subtree of the expansion
   const bool prune = p.db_dim_2 > 0 && nj > 0 && (j0 != 0 || nj != (int)p.dim0());
   if (prune || (plan && p.db_dim_2 > 0)) note_path(PATH_EXPAND_PRUNED);
   const DeviceState::PrunedPlan* pl = plan && p.db_dim_2 > 0 ? plan : (prune ? &D.pruned_plan(p, j0, nj) : nullptr);
   const int* L = D.lists.p;
-  launch_ntt_fwd(D.T, f, s);
   const long split_mode = tunable("expand_split", -1);  // -1: only when a long sweep follows (it hides the odd subtree)
   if (p.db_dim_2 > 0 && g >= 2 && (split_mode > 0 || (split_mode < 0 && W.long_sweep_follows))) {
     // expand_split (default -1: only before a per-plane pipelined sweep, i.e. wide packed databases; 1: always; 0: never):
@@ -920,13 +1013,7 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
     return;
   }
   run_coefficient_expansion(W, pp, g, pl);
-  if (p.db_dim_2 > 0) {
-    launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
-    run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-    run_folding_neg(W);
-  } else {
-    launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), s);  // server.rs:574-576
-  }
+  run_begin_after_rounds(W, pp);
 }
 
 // orders the current stream after the odd expansion subtree of this workspace's query (no-op when it was not split off)

@@ -1098,7 +1098,23 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
     qs = [cls[i % 2].generate_query(idxs[i], 500 + i) for i in range(B)]
     sp.paths_taken()
     resp = sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb)
-    assert "sweep_batch_mfma" in sp.paths_taken()
+    taken = sp.paths_taken()
+    assert "sweep_batch_mfma" in taken
+    # r06: the group's expansions share every round's launches (grid dimension = query, two clients' public parameters behind
+    # per-query offsets); one query at a time on sixteen streams -- the r02-r05 form -- must give the same bytes, and so must
+    # both extremes of the shared rounds' dispatch (every round as three launches / every round as k_expand_round)
+    assert "expand_group" in taken, taken
+    for switch, value in ((b"expand_group", 0), (b"expand_group_round_min", 1 << 40), (b"expand_group_round_min", 1)):
+        sp.lib().sp_debug_set(switch, C.c_long(value))
+        try:
+            sp.paths_taken()
+            assert sp.process_query_batch(p, [gpps[i % 2] for i in range(B)], qs, gdb) == resp, (switch, value)
+            taken = sp.paths_taken()
+            assert ("expand_group" in taken) == (switch != b"expand_group"), (switch, taken)
+            if switch == b"expand_group_round_min":
+                assert ("expand_round_one_launch" in taken) == (value == 1), (value, taken)
+        finally:
+            sp.lib().sp_debug_set(switch, C.c_long(1 if switch == b"expand_group" else 4096))
     sp.lib().sp_debug_set(b"batch_mfma", C.c_long(0))
     try:
         sp.paths_taken()
