@@ -1,4 +1,5 @@
 // extern "C" surface of libspiral_hip.so (include/spiral_hip.h).
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <deque>
@@ -997,6 +998,14 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
   }
   const Params& p = h->p;
   tunables_new_call();  // the switches below are read before the first guarded() section of this call
+  // diagnostic (switch batch_trace): host time stamps of this call's phases on stderr, microseconds from entry
+  const bool trace = tunable("batch_trace", 0) != 0;
+  const auto t_entry = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what) {
+    if (trace)
+      fprintf(stderr, "[spiral] batch %-22s %8.1f us\n", what,
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_entry).count());
+  };
   const bool batched = db->packed && db->num_shards == 1 && db->col_G == 1 && !tunable("no_batch_sweep", 0);
   if (!batched) {
     // 8-byte / narrow databases: one pass per query, up to `batch_in_flight` (default 3, at most 4; 1 = one at a time)
@@ -1065,6 +1074,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     const int rc0 = guarded([&] { check_device(db->device); });
     if (rc0 != SP_OK) return rc0;
   }
+  stamp("entry");
   const int shape_max = sweep_batch_group_max(db->np_local, db->nj);
   int group_max = (int)tunable("batch_group", 0);
   if (group_max <= 0) group_max = shape_max;
@@ -1077,6 +1087,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
     if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < (size_t)2 * SWEEP_GROUP_MAX * per_ws) group_max = SWEEP_BATCH_MAX;
     (void)hipGetLastError();
   }
+  stamp("group size decided");
   // a list of exactly 9 .. 16 queries is one group; longer lists are cut into groups of group_max (a last group of <= 8
   // takes the one-tile pass)
   std::vector<sp_query_t*> all_qs;   // queries in flight (at most two groups: bounds the workspaces held)
@@ -1125,6 +1136,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         q->ws->ensure_sweep();
       }
       sp_query_t* const* qs = all_qs.data() + first;
+      stamp("workspaces acquired");
       if (group_expand) {
         Workspace* Ws[GROUP_MAX];
         for (int i = 0; i < B; i++) Ws[i] = qs[i]->ws.get();
@@ -1134,6 +1146,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
           qs[i]->state = 1;
         }
       }
+      stamp("expansions enqueued");
       // 2. one database pass for the whole group, on the first query's stream, after the previous group's pass
       Workspace& W0 = *qs[0]->ws;
       SweepBatchDesc d{};
@@ -1163,6 +1176,7 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       launch_sweep_batch(W0.D->T, d, W0.stream);
       HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
       prev_pass = W0.ev[2];
+      stamp("pass enqueued");
       // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
       for (int i = 0; i < B; i++) {
         Workspace& W = *qs[i]->ws;
@@ -1173,8 +1187,10 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
         run_finish(W, *qs[i]->pp, false);
       }
       prev_group = (size_t)B;
+      stamp("folds enqueued");
     }
     drain(all_qs.size());
+    stamp("drained");
   };
   auto abandon = [&] {  // let whatever was queued drain before the workspaces go back to the pool
     for (auto* q : all_qs) (void)hipStreamSynchronize(q->ws->stream);

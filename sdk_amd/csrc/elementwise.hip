@@ -122,6 +122,21 @@ void launch_copy_polys(u32* dst, const int* dst_idx, int dst_row_stride, const u
   launched(0, "k_copy_polys");
 }
 
+// grouped forms (kernels.hpp, GroupOff): one more grid dimension = the query
+__global__ __launch_bounds__(256) void k_copy_polys_group(CopyPolysDesc d, GroupOff g) {
+  const int qi = blockIdx.z;
+  d.dst = group_rebase(d.dst, g.raw[qi]);
+  d.src = group_rebase(d.src, g.v[qi]);
+  copy_polys_body(d, blockIdx.x, blockIdx.y);
+}
+void launch_copy_polys_group(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx, int src_row_stride,
+                             int R, int batch, const GroupOff& g, int B, hipStream_t s) {
+  if (batch <= 0 || B <= 0) return;
+  const CopyPolysDesc d{dst, dst_idx, dst_row_stride, src, src_idx, src_row_stride, R, batch};
+  hipLaunchKernelGGL(k_copy_polys_group, dim3(batch * R, 2 * N / 256, B), dim3(256), 0, s, d, g);
+  launched(PATH_EXPAND_GROUP, "k_copy_polys_group");
+}
+
 // Diagnostics for resident data: checksum of a buffer as KERNELS see it (through the caches), and a kernel whose
 // waves write back and invalidate the L2 of the XCD they run on (system-scope fence: buffer_wbl2 + buffer_inv).
 __global__ __launch_bounds__(256) void k_checksum(const u32* p, size_t n, unsigned long long* out) {
@@ -163,6 +178,19 @@ void launch_folding_neg(const DevTables& T, u32* mats, const u32* gadget_ntt, in
   const FoldingNegDesc d{mats, gadget_ntt, two_t, nu2};
   hipLaunchKernelGGL(k_folding_neg, dim3(2 * N / 256, 2 * two_t, nu2), dim3(256), 0, s, T, d);
   launched(0, "k_folding_neg");
+}
+
+__global__ __launch_bounds__(256) void k_folding_neg_group(DevTables T, FoldingNegDesc d, GroupOff g) {
+  const int qi = blockIdx.z / d.nu2;
+  d.mats = group_rebase(d.mats, g.v[qi]);
+  folding_neg_body(T, d, blockIdx.x, blockIdx.y, blockIdx.z - qi * d.nu2);
+}
+void launch_folding_neg_group(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, const GroupOff& g, int B,
+                              hipStream_t s) {
+  if (nu2 <= 0 || B <= 0) return;
+  const FoldingNegDesc d{mats, gadget_ntt, two_t, nu2};
+  hipLaunchKernelGGL(k_folding_neg_group, dim3(2 * N / 256, 2 * two_t, nu2 * B), dim3(256), 0, s, T, d, g);
+  launched(PATH_EXPAND_GROUP, "k_folding_neg_group");
 }
 
 __global__ __launch_bounds__(256) void k_add(DevTables T, u32* out, const u32* a, const u32* b) {
@@ -252,6 +280,21 @@ void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipS
   const ReorientDesc d{out, v, first, step, dim0};
   hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, d);
   launched(0, "k_reorient");
+}
+
+__global__ __launch_bounds__(256) void k_reorient_group(ReorientDesc d, GroupOff g, int tiles_x) {
+  __shared__ u64 tile[32 * 33];
+  const int qi = blockIdx.x / tiles_x;
+  d.out = group_rebase(d.out, g.raw[qi]);
+  d.v = group_rebase(d.v, g.v[qi]);
+  reorient_body(d, blockIdx.x - qi * tiles_x, blockIdx.y, blockIdx.z, tile);
+}
+void launch_reorient_group(u64* out, const u32* v, int first, int step, int dim0, const GroupOff& g, int B, hipStream_t s) {
+  if (B <= 0) return;
+  const ReorientDesc d{out, v, first, step, dim0};
+  const int tiles_x = (dim0 + 31) / 32;
+  hipLaunchKernelGGL(k_reorient_group, dim3(tiles_x * B, N / 32, 2), dim3(256), 0, s, d, g, tiles_x);
+  launched(PATH_EXPAND_GROUP, "k_reorient_group");
 }
 
 // ---- placement probe (diagnostics): every workgroup records which XCC / shader engine / CU it ran on -------------

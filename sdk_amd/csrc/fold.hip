@@ -552,6 +552,20 @@ void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s
   launched(0, "k_mats_to_wave");
 }
 
+// grouped form (kernels.hpp, GroupOff): grid.y = query
+__global__ __launch_bounds__(256) void k_mats_to_wave_group(MatsToWaveDesc d, GroupOff g) {
+  const int qi = blockIdx.y;
+  d.dst = group_rebase(d.dst, g.raw[qi]);
+  d.src = group_rebase(d.src, g.v[qi]);
+  mats_to_wave_body(d, blockIdx.x);
+}
+void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, const GroupOff& g, int B, hipStream_t s) {
+  if (n_words == 0 || B <= 0) return;
+  const MatsToWaveDesc d{dst, src, n_words};
+  hipLaunchKernelGGL(k_mats_to_wave_group, dim3((unsigned)((n_words + 255) / 256), B), dim3(256), 0, s, d, g);
+  launched(PATH_EXPAND_GROUP, "k_mats_to_wave_group");
+}
+
 void launch_fold_fused(const DevTables& T, const FoldDesc& d, hipStream_t s) {
   if (d.half <= 0 || d.planes <= 0) return;
   // fold_variant: 5 (default) = k_fold_wave where two workgroups fit a CU's LDS, else the cooperative kernels;

@@ -215,6 +215,15 @@ void launch_ntt_fwd3_group(const DevTables& T, const FwdDesc& d0, const FwdDesc&
 void launch_mac2_group(const DevTables& T, const MacDesc& d0, const MacDesc& d1, const GroupOff& g, int B, hipStream_t s);   // A: pp; B: dig; out, addend: v; extra: ct1
 void launch_expand_round_group(const DevTables& T, const ExpandSideDesc& left, const ExpandSideDesc& right, const GroupOff& g, int B,
                                hipStream_t s);                                                                     // raw: raw; A: pp; v: v
+// ... and what follows the rounds (v_reg, regev_to_gsw, G - C, wave layout of the fold operands).  The transform and multiply
+// launches above serve again with other buffers behind their offset classes; four small kernels get grouped forms of their own
+// (classes named per launcher: "v" = the source side, "raw" = the destination side):
+void launch_reorient_group(u64* out, const u32* v, int first, int step, int dim0, const GroupOff& g, int B, hipStream_t s);       // out: raw; v: v
+void launch_copy_polys_group(u32* dst, const int* dst_idx, int dst_row_stride, const u32* src, const int* src_idx, int src_row_stride,
+                             int R, int batch, const GroupOff& g, int B, hipStream_t s);                                            // dst: raw; src: v
+void launch_folding_neg_group(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, const GroupOff& g, int B,
+                              hipStream_t s);                                                                                       // mats: v
+void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, const GroupOff& g, int B, hipStream_t s);                  // dst: raw; src: v
 constexpr long EXPAND_GROUP_ROUND_MIN_DEFAULT = 4096;   // digit transforms per modulus of the WHOLE group from which a round is one launch
 
 // ---- fused fold step (server.rs:407-424) ----------------------------------------------------

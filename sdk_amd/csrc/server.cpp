@@ -203,13 +203,38 @@ void debug_stage(int stage) {
 }
 
 // ---------------------------------------------------------------------------------- ChaCha20
-static inline u32 rotl(u32 v, int c) { return (v << c) | (v >> (32 - c)); }
-static inline void quarter(u32* s, int a, int b, int c, int d) {
-  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
-  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
-  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
-  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+// LANES consecutive blocks side by side (counter ctr0 + lane): plain loops over the lane index that the host compiler turns into
+// vector code -- 8 x 32 bits with AVX2 where the CPU has it (the function-level target below), 4 x 32 with the baseline SSE2.  Same
+// keystream as the one-block loop it replaces (r06: a query's 16 KiB of keystream took ~25 us of host time per query, which a
+// 16-query call pays sixteen times before its first kernel can start).
+template <int LANES>
+static inline void chacha_blocks(const u32 init[16], u64 ctr0, u32 (*out)[16]) {
+  u32 s[16][LANES], in0[16][LANES];
+  for (int i = 0; i < 16; i++)
+    for (int l = 0; l < LANES; l++) in0[i][l] = init[i];
+  for (int l = 0; l < LANES; l++) {
+    const u64 c = ctr0 + (u64)l;
+    in0[12][l] = (u32)c;
+    in0[13][l] = (u32)(c >> 32);
+    in0[14][l] = in0[15][l] = 0;
+  }
+  memcpy(s, in0, sizeof(s));
+#define SP_QR(a, b, c, d)                                                                                       \
+  for (int l = 0; l < LANES; l++) { s[a][l] += s[b][l]; s[d][l] ^= s[a][l]; s[d][l] = (s[d][l] << 16) | (s[d][l] >> 16); } \
+  for (int l = 0; l < LANES; l++) { s[c][l] += s[d][l]; s[b][l] ^= s[c][l]; s[b][l] = (s[b][l] << 12) | (s[b][l] >> 20); } \
+  for (int l = 0; l < LANES; l++) { s[a][l] += s[b][l]; s[d][l] ^= s[a][l]; s[d][l] = (s[d][l] << 8) | (s[d][l] >> 24); }  \
+  for (int l = 0; l < LANES; l++) { s[c][l] += s[d][l]; s[b][l] ^= s[c][l]; s[b][l] = (s[b][l] << 7) | (s[b][l] >> 25); }
+  for (int rnd = 0; rnd < 10; rnd++) {
+    SP_QR(0, 4, 8, 12) SP_QR(1, 5, 9, 13) SP_QR(2, 6, 10, 14) SP_QR(3, 7, 11, 15)
+    SP_QR(0, 5, 10, 15) SP_QR(1, 6, 11, 12) SP_QR(2, 7, 8, 13) SP_QR(3, 4, 9, 14)
+  }
+#undef SP_QR
+  for (int l = 0; l < LANES; l++)
+    for (int i = 0; i < 16; i++) out[l][i] = s[i][l] + in0[i][l];
 }
+__attribute__((target("avx2"))) static void chacha_blocks8_avx2(const u32 init[16], u64 ctr0, u32 (*out)[16]) { chacha_blocks<8>(init, ctr0, out); }
+static void chacha_blocks8_base(const u32 init[16], u64 ctr0, u32 (*out)[16]) { chacha_blocks<8>(init, ctr0, out); }
+
 void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
   u32 init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
   for (int i = 0; i < 8; i++) {
@@ -217,23 +242,28 @@ void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
     memcpy(&w, seed + 4 * i, 4);
     init[4 + i] = w;
   }
+  static const bool have_avx2 = __builtin_cpu_supports("avx2");
   u64 ctr = 0;
   size_t done = 0;
+  u32 blk[8][16];
   while (done < count) {
-    init[12] = (u32)ctr;
-    init[13] = (u32)(ctr >> 32);
-    init[14] = init[15] = 0;
-    u32 s[16];
-    memcpy(s, init, sizeof(s));
-    for (int rnd = 0; rnd < 10; rnd++) {
-      quarter(s, 0, 4, 8, 12); quarter(s, 1, 5, 9, 13); quarter(s, 2, 6, 10, 14); quarter(s, 3, 7, 11, 15);
-      quarter(s, 0, 5, 10, 15); quarter(s, 1, 6, 11, 12); quarter(s, 2, 7, 8, 13); quarter(s, 3, 4, 9, 14);
-    }
-    for (int i = 0; i < 16 && done < count; i += 2, done++)
-      out[done] = (u64)(s[i] + init[i]) | ((u64)(s[i + 1] + init[i + 1]) << 32);
-    ctr++;
+    (have_avx2 ? chacha_blocks8_avx2 : chacha_blocks8_base)(init, ctr, blk);
+    ctr += 8;
+    for (int l = 0; l < 8 && done < count; l++)
+      for (int i = 0; i < 16 && done < count; i += 2, done++) out[done] = (u64)blk[l][i] | ((u64)blk[l][i + 1] << 32);
   }
 }
+
+// x mod Q for the 56-bit Q of the parameter sets (Q < 2^63): the quotient estimate mulhi(x, floor(2^64 / Q)) is at most 2 short
+struct FastMod {
+  u64 Q, m;
+  explicit FastMod(u64 q) : Q(q), m(q > 1 ? (u64)(((unsigned __int128)1 << 64) / q) : 0) {}
+  u64 operator()(u64 x) const {
+    u64 r = x - (u64)(((unsigned __int128)x * m) >> 64) * Q;
+    while (r >= Q) r -= Q;
+    return r;
+  }
+};
 
 // ---------------------------------------------------------------------------------- device state
 // Expansion schedule (server.rs:19-121) restricted to the first-dimension rows [j0, j0 + nj): output ct c of round
@@ -921,7 +951,8 @@ static void run_begin_query_ct(Workspace& W, const uint8_t* query, size_t query_
   W.right_pending = false;
   // row 0 = Q - (rng.gen::<u64>() % Q) (client.rs:47-49), row 1 from the wire
   chacha20_keystream_u64(query, W.h_query, POLY_LEN);
-  for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - (W.h_query[i] % p.modulus);
+  const FastMod modq(p.modulus);
+  for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - modq(W.h_query[i]);
   memcpy(W.h_query + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
   HIP_CHECK(hipMemcpyAsync(W.q_raw.p, W.h_query, 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, s));
   FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};
@@ -942,6 +973,80 @@ static void run_begin_after_rounds(Workspace& W, const sp_pp& pp) {
   }
 }
 
+// run_begin_after_rounds for the group, as shared launches on Ws[0]'s stream (nu_2 > 0, wave-layout fold operands): reorient,
+// regev_to_gsw (copy, inverse transform, digit transforms, products: server.rs:123-151), G - C, wave layout
+static void run_group_after_rounds(Workspace* const* Ws, const sp_pp* const* pps, int B) {
+  Workspace& W0 = *Ws[0];
+  const Params& p = *W0.P;
+  DeviceState& D = *W0.D;
+  hipStream_t s = W0.stream;
+  const int* L = D.lists.p;
+  auto off = [](const void* q, const void* q0) { return (long long)((const char*)q - (const char*)q0); };
+  const int nb = (int)(p.db_dim_2 * p.t_gsw);
+  const int four_t = (int)(4 * p.t_gsw);
+  const size_t mats_words = p.db_dim_2 * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
+  for (int i = 0; i < B; i++) Ws[i]->fold_mats_w.ensure(mats_words);
+  // offset classes per launch: see the launchers' comments in kernels.hpp
+  GroupOff g_reo{}, g_copy{}, g_inv{}, g_fwd{}, g_mac{}, g_neg{}, g_wave{};
+  for (int i = 0; i < B; i++) {
+    Workspace& W = *Ws[i];
+    const long long dv = off(W.v.p, W0.v.p), dm = off(W.fold_mats.p, W0.fold_mats.p);
+    g_reo.v[i] = dv;   g_reo.raw[i] = off(W.qv.p, W0.qv.p);
+    g_copy.v[i] = dv;  g_copy.raw[i] = dm;
+    g_inv.v[i] = dv;   g_inv.raw[i] = off(W.gsw_raw.p, W0.gsw_raw.p);
+    g_fwd.raw[i] = g_inv.raw[i];  g_fwd.dig[i] = off(W.gsw_dig.p, W0.gsw_dig.p);
+    g_mac.pp[i] = off(pps[i]->all.p, pps[0]->all.p);  g_mac.dig[i] = g_fwd.dig[i];  g_mac.v[i] = dm;
+    g_neg.v[i] = dm;
+    g_wave.v[i] = dm;  g_wave.raw[i] = off(W.fold_mats_w.p, W0.fold_mats_w.p);
+    if (pps[i]->off_conv != pps[0]->off_conv) throw ArgError("a group's public parameters must have one layout");
+  }
+  launch_reorient_group(W0.qv.p, W0.v.p, 0, 2, (int)p.dim0(), g_reo, B, s);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
+  if (nb > 0) {
+    launch_copy_polys_group(W0.fold_mats.p, L + D.gsw_out_odd, four_t, W0.v.p, L + D.gsw_src_poly, 1, 2, nb, g_copy, B, s);
+    InvDesc inv{};
+    inv.src = W0.v.p;
+    inv.idx = L + D.gsw_src_ct;
+    inv.polys_per_idx = 2;
+    inv.idx_stride = 4 * POLY_LEN;
+    inv.poly_stride = 2 * POLY_LEN;
+    inv.crt_stride = POLY_LEN;
+    inv.z_stride = 1;
+    inv.dst = W0.gsw_raw.p;
+    inv.n_polys = nb * 2;
+    launch_ntt_inv_group(D.T, inv, g_inv, B, s);
+    FwdDesc f{};
+    f.src = W0.gsw_raw.p;
+    f.dst = W0.gsw_dig.p;
+    f.n_out = nb * 2 * (int)p.t_conv;
+    f.rdim = 2;
+    f.cols = 1;
+    f.t = (int)p.t_conv;
+    f.bits = (int)p.bits_per(p.t_conv);
+    f.src_batch_stride = 2;
+    f.src_row0 = 0;
+    f.src_cols = 1;
+    FwdDesc none{};
+    launch_ntt_fwd3_group(D.T, f, none, none, g_fwd, B, s);
+    MacDesc m{};
+    m.A = pps[0]->all.p + pps[0]->off_conv * 2 * POLY_LEN;
+    m.B = W0.gsw_dig.p;
+    m.out = W0.fold_mats.p;
+    m.out_idx = L + D.gsw_out_even;
+    m.R = 2;
+    m.K = 2 * (int)p.t_conv;
+    m.batch_inner = nb;
+    m.batch_outer = 1;
+    m.B_inner_stride = 2 * p.t_conv;
+    m.split_k = m.K;
+    m.out_row_stride = four_t;
+    MacDesc none_m{};
+    launch_mac2_group(D.T, m, none_m, g_mac, B, s);
+  }
+  launch_folding_neg_group(D.T, W0.fold_mats.p, D.gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), g_neg, B, s);
+  launch_mats_to_wave_group(W0.fold_mats_w.p, W0.fold_mats.p, mats_words, g_wave, B, s);
+  for (int i = 0; i < B; i++) Ws[i]->mats_w_ready = true;
+}
+
 // run_begin for a GROUP of queries that share one database pass (sp_process_query_batch): every query's ciphertext on its own
 // stream, the rounds of all expansions as shared launches on the first query's stream (run_group_expansion), then every query's
 // v_reg / GSW side / G - C on its own stream again.  Same values as B run_begin calls: the kernels are the same bodies.
@@ -958,11 +1063,23 @@ void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_
   }
   note_path(PATH_EXPAND_GROUP);
   run_group_expansion(Ws, pps, B, p.g());
+  if (tunable("expand_group_tail", 1) != 0 && fused_fold_supported(p) && tunable("fold_variant", FOLD_VARIANT_DEFAULT) == 5 && p.db_dim_2 > 0)
+    run_group_after_rounds(Ws, pps, B);   // seven shared launches
+  else
+    for (int i = 0; i < B; i++) {          // (the single-query form of the tail on W0's stream; rare shapes)
+      Workspace& W = *Ws[i];
+      hipStream_t own = W.stream;
+      W.stream = W0.stream;
+      try {
+        run_begin_after_rounds(W, *pps[i]);
+      } catch (...) {
+        W.stream = own;
+        throw;
+      }
+      W.stream = own;
+    }
   HIP_CHECK(hipEventRecord(W0.ev_round0, W0.stream));
-  for (int i = 0; i < B; i++) {
-    if (i > 0) HIP_CHECK(hipStreamWaitEvent(Ws[i]->stream, W0.ev_round0, 0));
-    run_begin_after_rounds(*Ws[i], *pps[i]);
-  }
+  for (int i = 1; i < B; i++) HIP_CHECK(hipStreamWaitEvent(Ws[i]->stream, W0.ev_round0, 0));
 }
 
 // Query::deserialize (client.rs:303-314) + expand_query (server.rs:525-591) + get_v_folding_neg

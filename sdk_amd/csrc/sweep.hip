@@ -485,6 +485,11 @@ void sweep_batch_prepare(const DevTables& T, SweepBatchDesc& d, hipStream_t s) {
   // per tile of <= 8 queries: the digit table [tile][N][steps][2][64][4], then (after ALL tables) the offset terms [tile][N][32]
   const int tiles = sweep_batch_tiles(d.batch);
   const size_t entries = (size_t)N * (d.nj >> 4) * 128;
+  if (d.planar && tiles == 2 && tunable("batch_tables_merged", 1) != 0) {   // both tiles in one launch each (sweep_planar.hip)
+    launch_query_tables_planar2(T, d.qv, d.batch, d.dim0, d.j0, d.nj, d.rq, s);
+    d.use_mfma = 1;
+    return;
+  }
   for (int t = 0; t < tiles; t++) {
     QueryDigitsDesc q{};
     const int nb = std::min(SWEEP_BATCH_MAX, d.batch - t * SWEEP_BATCH_MAX);

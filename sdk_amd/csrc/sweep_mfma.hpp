@@ -61,6 +61,8 @@ struct QueryDigitsDesc {
 };
 // the same table in the order of the digit-planar pass (sweep_planar.hpp / sweep_planar.hip)
 void launch_query_digits_planar(const QueryDigitsDesc& q, size_t entries, hipStream_t s);
+// ... both tiles' tables and offset terms of a 9 .. 16-query group, one launch each (sweep_planar.hip)
+void launch_query_tables_planar2(const DevTables& T, const u64* const* qv, int batch, int dim0, int j0, int nj, u32* rq, hipStream_t s);
 // (internal linkage: this header is included by sweep.hip and, through sweep_planar.hpp, by sweep_planar.hip)
 static __global__ __launch_bounds__(256) void k_query_digits(QueryDigitsDesc d) {
   const int steps = d.nj >> 4;

@@ -15,6 +15,22 @@ void launch_query_digits_planar(const QueryDigitsDesc& q, size_t entries, hipStr
   launched(0, "k_query_digits_planar");
 }
 
+// both tiles of a 9 .. 16-query group: tables [tile][N][blocks][2][4][64][16 B], then the offset terms [tile][N][32]
+void launch_query_tables_planar2(const DevTables& T, const u64* const* qv, int batch, int dim0, int j0, int nj, u32* rq, hipStream_t s) {
+  QueryDigits2Desc q{};
+  for (int b = 0; b < batch && b < SWEEP_GROUP_MAX; b++) q.qv[b] = qv[b];
+  q.rq = rq;
+  q.batch = batch;
+  q.dim0 = dim0;
+  q.j0 = j0;
+  q.nj = nj;
+  const size_t entries = (size_t)N * (nj >> 4) * 128;   // 16-byte entries of one tile's table (== N * blocks * 8 * 64)
+  hipLaunchKernelGGL(k_query_digits_planar2, dim3((unsigned)((entries + 255) / 256), 2), dim3(256), 0, s, q);
+  launched(0, "k_query_digits_planar2");
+  hipLaunchKernelGGL(k_query_offset_terms2, dim3(N, 2), dim3(256), 0, s, T, q, rq + (size_t)2 * entries * 4);
+  launched(0, "k_query_offset_terms2");
+}
+
 // ---- digit-planar database (sweep_planar.hpp) ----------------------------------------------------------------------------
 bool sweep_planar_shape_ok(int num_per, int nj) {
   // whole 64-row blocks, the z-row's query planes of both tiles in LDS (nj <= 512), whole 128-column chunks

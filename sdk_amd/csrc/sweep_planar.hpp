@@ -75,6 +75,58 @@ static __global__ __launch_bounds__(256) void k_query_digits_planar(QueryDigitsD
   reinterpret_cast<mf_u32x4_t*>(d.rq)[idx] = o;
 }
 
+// r06: both tiles' tables and offset terms as ONE launch each (grid.y = tile) -- two 64-MiB tables built one after the other by
+// launches that reach 1.4 TB/s each were 0.35 ms of every 16-query step
+struct QueryDigits2Desc {
+  const u64* qv[SWEEP_GROUP_MAX];  // reoriented queries [N][dim0][2]
+  u32* rq;                          // [tile][...] tables, then the offset terms [tile][N][32]
+  int batch, dim0, j0, nj;
+};
+static __global__ __launch_bounds__(256) void k_query_digits_planar2(QueryDigits2Desc d) {
+  const int blocks = d.nj >> 6;
+  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte entry per thread
+  const size_t entries = (size_t)N * blocks * 8 * 64;
+  if (idx >= entries) return;
+  const int tile = blockIdx.y;
+  const int lane = (int)(idx & 63), b = (int)((idx >> 6) & 3), c = (int)((idx >> 8) & 1);
+  const size_t zb = idx >> 9;
+  const int block = (int)(zb % blocks), z = (int)(zb / blocks);
+  const int m = lane & 15, kb = lane >> 4, qb = 8 * tile + (m >> 1), r = m & 1;
+  mf_u32x4_t o = {0u, 0u, 0u, 0u};
+  if (qb < d.batch) {
+    const u64* q = d.qv[qb] + ((size_t)z * d.dim0 + d.j0 + 64 * block + 16 * kb) * 2 + r;
+#pragma unroll
+    for (int t = 0; t < 16; t++) {
+      const u64 w = q[2 * t];
+      const u32 x = c ? (u32)(w >> 32) : (u32)w;
+      const u32 dg = (signed_digits(x) >> (8 * b)) & 0xffu;
+      o[t >> 2] |= dg << (8 * (t & 3));
+    }
+  }
+  reinterpret_cast<mf_u32x4_t*>(d.rq)[(size_t)tile * entries + idx] = o;
+}
+// (k_query_offset_terms of sweep_mfma.hpp with the tile as grid.y)
+static __global__ __launch_bounds__(256) void k_query_offset_terms2(DevTables T, QueryDigits2Desc d, u32* off) {
+  const int z = blockIdx.x, t = threadIdx.x, tile = blockIdx.y;
+  const int combo = t >> 3, part = t & 7;      // combo = crt * 16 + n
+  const int crt = combo >> 4, n = combo & 15, b = 8 * tile + (n >> 1), r = n & 1;
+  u64 sum = 0;
+  if (b < d.batch) {
+    const u64* q = d.qv[b] + ((size_t)z * d.dim0 + d.j0) * 2 + r;
+    for (int j = part; j < d.nj; j += 8) {
+      const u64 w = q[2 * (size_t)j];
+      sum += crt ? (u32)(w >> 32) : (u32)w;
+    }
+  }
+#pragma unroll
+  for (int sft = 1; sft < 8; sft <<= 1) sum += __shfl_xor(sum, sft, 8);
+  if (part == 0) {
+    const ModConst m = T.c.mod[crt];
+    const u32 sy = reduce64(sum, m);
+    off[((size_t)tile * N + z) * 32 + combo] = reduce64((u64)sy * (u64)(DIGIT_OFFSET % m.q), m);
+  }
+}
+
 // WAVES = 4: one wave per SIMD and workgroup; WAVES = 8: the workgroup's chunks are split between two sets of four waves that
 // share the z-row's query planes in LDS -- two waves per SIMD (they cover each other's waits) where two four-wave workgroups
 // would need the 64 KiB per query tile twice.
