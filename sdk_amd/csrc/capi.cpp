@@ -69,10 +69,13 @@ struct sp_query {
   const sp_db* for_sparse = nullptr;  // begun for this sparse bucket: only the rows holding items were expanded
   std::shared_ptr<const sp_db::SparseIndex> sparse_index;  // ... with this snapshot of its index (kept until the query is freed)
   float ms[4] = {0, 0, 0, 0};
+  bool streams_idle = false;  // the owner has waited for the main stream after the last enqueue (which orders stream2's work before it)
   ~sp_query() {
     if (ws && params) {
-      (void)hipStreamSynchronize(ws->stream);
-      (void)hipStreamSynchronize(ws->stream2);
+      if (!streams_idle) {
+        (void)hipStreamSynchronize(ws->stream);
+        (void)hipStreamSynchronize(ws->stream2);
+      }
       ws->pipelined = false;
       ws->have_sweep_span = false;
       ws->zero_shortcuts = false;
@@ -1099,6 +1102,9 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       HIP_CHECK(hipStreamSynchronize(W.stream));
       memcpy(out + (drained + i) * out_stride, W.h_response, p.response_bytes());
       *out_len = p.response_bytes();
+      // (run_finish joins the second stream into the main one before the response copy, and a split-off odd expansion subtree
+      // -- not used by grouped expansions -- is joined before the fold: both streams are idle now)
+      all_qs[i]->streams_idle = !W.right_pending;
     }
     for (size_t i = 0; i < count; i++) sp_query_free(all_qs[i]);
     all_qs.erase(all_qs.begin(), all_qs.begin() + count);

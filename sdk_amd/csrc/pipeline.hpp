@@ -46,6 +46,8 @@ struct Workspace {
   DevBuf<u32> du_ntt;
   // host staging (pinned)
   u64* h_query = nullptr;
+  u64* h_group_query = nullptr;   // a group leader's pinned staging of all its queries' ciphertexts (run_begin_group), GROUP_MAX x 2 polys
+  DevBuf<u64> group_q_raw;        // ... and its device image
   u64* h_packed = nullptr;
   size_t h_packed_words = 0;
   DevBuf<u64> enc_out;       // response bits built on the device

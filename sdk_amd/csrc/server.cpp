@@ -570,10 +570,12 @@ Workspace::Workspace(const Params& P, DeviceState& D) : P(&P), D(&D) {
 Workspace::~Workspace() {
   if (host_pinned) {
     if (h_query) (void)hipHostFree(h_query);
+    if (h_group_query) (void)hipHostFree(h_group_query);
     if (h_packed) (void)hipHostFree(h_packed);
     if (h_response) (void)hipHostFree(h_response);
   } else {
     free(h_query);
+    free(h_group_query);
     free(h_packed);
     free(h_response);
   }
@@ -940,20 +942,25 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
   HIP_CHECK(hipStreamSynchronize(s));  // the host staging vectors go out of scope
 }
 
-// Query::deserialize (client.rs:303-314) up to v[0] = query.ct.ntt() (server.rs:545), enqueued on W.stream
-static void run_begin_query_ct(Workspace& W, const uint8_t* query, size_t query_len) {
+// Query::deserialize (client.rs:303-314): the query ciphertext's two raw polynomials into `host` -- row 0 = Q - (rng.gen::<u64>() % Q)
+// from the seed (client.rs:47-49), row 1 from the wire
+static void query_ct_host(Workspace& W, const uint8_t* query, size_t query_len, u64* host) {
   const Params& p = *W.P;
   if (query_len != p.query_bytes()) throw ArgError("query length " + std::to_string(query_len) + " != query_bytes " + std::to_string(p.query_bytes()));
   if (p.db_dim_2 == 0 && p.t_exp_left != p.t_exp_right) throw ArgError("nu_2 == 0 requires t_exp_left == t_exp_right (server.rs:573)");
+  chacha20_keystream_u64(query, host, POLY_LEN);
+  const FastMod modq(p.modulus);
+  for (size_t i = 0; i < POLY_LEN; i++) host[i] = p.modulus - modq(host[i]);
+  memcpy(host + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
+}
+
+// ... up to v[0] = query.ct.ntt() (server.rs:545), enqueued on W.stream
+static void run_begin_query_ct(Workspace& W, const uint8_t* query, size_t query_len) {
+  query_ct_host(W, query, query_len, W.h_query);
   W.ensure_expand();
   hipStream_t s = W.stream;
   join_right(W);  // a previous query of this workspace whose odd subtree nobody waited for
   W.right_pending = false;
-  // row 0 = Q - (rng.gen::<u64>() % Q) (client.rs:47-49), row 1 from the wire
-  chacha20_keystream_u64(query, W.h_query, POLY_LEN);
-  const FastMod modq(p.modulus);
-  for (size_t i = 0; i < POLY_LEN; i++) W.h_query[i] = p.modulus - modq(W.h_query[i]);
-  memcpy(W.h_query + POLY_LEN, query + SEED_LENGTH, POLY_LEN * sizeof(u64));
   HIP_CHECK(hipMemcpyAsync(W.q_raw.p, W.h_query, 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, s));
   FwdDesc f{W.q_raw.p, nullptr, W.v.p, 2, 1, 1, 1, 64, 1, 0, 1};
   launch_ntt_fwd(W.D->T, f, s);
@@ -1054,12 +1061,32 @@ void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_
   Workspace& W0 = *Ws[0];
   const Params& p = *W0.P;
   if (!p.expand_queries) throw ArgError("run_begin_group: direct-upload queries have no expansion to share");
+  // the B query ciphertexts: one pinned staging buffer, ONE upload, one launch of their transforms (sixteen uploads + launches on
+  // sixteen streams were 0.66 ms before the first shared round could start)
+  if (!W0.h_group_query) {
+    if (W0.host_pinned)
+      HIP_CHECK(hipHostMalloc((void**)&W0.h_group_query, (size_t)GROUP_MAX * 2 * POLY_LEN * sizeof(u64), hipHostMallocDefault));
+    else if (!(W0.h_group_query = (u64*)malloc((size_t)GROUP_MAX * 2 * POLY_LEN * sizeof(u64))))
+      throw OomError("host staging allocation failed");
+  }
+  W0.group_q_raw.ensure((size_t)GROUP_MAX * 2 * POLY_LEN);
+  GroupOff gq{};
   for (int i = 0; i < B; i++) {
-    run_begin_query_ct(*Ws[i], queries[i], query_lens[i]);
-    if (i > 0) {
-      HIP_CHECK(hipEventRecord(Ws[i]->ev_round0, Ws[i]->stream));
-      HIP_CHECK(hipStreamWaitEvent(W0.stream, Ws[i]->ev_round0, 0));
+    Workspace& W = *Ws[i];
+    query_ct_host(W, queries[i], query_lens[i], W0.h_group_query + (size_t)i * 2 * POLY_LEN);
+    W.ensure_expand();
+    if (W.right_pending) {   // a previous query of this workspace whose odd subtree nobody waited for
+      HIP_CHECK(hipStreamWaitEvent(W0.stream, W.ev_right, 0));
+      W.right_pending = false;
     }
+    gq.raw[i] = (long long)((size_t)i * 2 * POLY_LEN * sizeof(u64));
+    gq.dig[i] = (long long)((const char*)W.v.p - (const char*)W0.v.p);
+  }
+  HIP_CHECK(hipMemcpyAsync(W0.group_q_raw.p, W0.h_group_query, (size_t)B * 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, W0.stream));
+  {
+    FwdDesc f{W0.group_q_raw.p, nullptr, W0.v.p, 2, 1, 1, 1, 64, 1, 0, 1};  // v[0] = query.ct.ntt()  (server.rs:545)
+    FwdDesc none{};
+    launch_ntt_fwd3_group(W0.D->T, f, none, none, gq, B, W0.stream);
   }
   note_path(PATH_EXPAND_GROUP);
   run_group_expansion(Ws, pps, B, p.g());
