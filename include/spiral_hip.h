@@ -330,6 +330,10 @@ int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2);
 /* Diagnostic: checksums of the resident tables / index lists / public parameters as seen by a kernel, by a
  * device-to-host copy, by a kernel after an L2 write-back + invalidate, and of the host original (24 values). */
 int sp_debug_resident_check(const sp_params_t* params, const sp_pp_t* pp, uint64_t* out, int cap);
+/* The library's ChaCha20 keystream as u64 words (rand_chacha 0.3.1 ChaCha20Rng::from_seed(seed).gen::<u64>(), client.rs:47-49:
+ * what regenerates row 0 of the public parameters and of a query; no GPU needed): tests compare it with the RFC 8439-pinned
+ * restatement word for word, on lengths that exercise the eight-block AVX2 body and the one-block tail. */
+int sp_debug_chacha20_u64(const uint8_t seed[32], uint64_t* out, size_t count);
 
 /* Profiling aid: nanoseconds per 2048-point forward NTT of the transform core alone (M = 1, 2 or 4 coefficient
  * vectors per thread, `blocks` workgroups each chaining `reps` transforms, no memory traffic but twiddles). */

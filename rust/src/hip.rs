@@ -159,6 +159,7 @@ pub mod sys {
                                     ms_per_pass: *mut f32) -> c_int;
         pub fn sp_debug_cu_probe(bit_lo: c_int, bit_hi: c_int, blocks: c_int, out2: *mut u32) -> c_int;
         pub fn sp_debug_resident_check(params: *const sp_params_t, pp: *const sp_pp_t, out: *mut u64, cap: c_int) -> c_int;
+        pub fn sp_debug_chacha20_u64(seed: *const u8, out: *mut u64, count: usize) -> c_int;
         pub fn sp_bench_ntt(p: *const sp_params_t, m: c_int, blocks: c_int, reps: c_int, ns_per_ntt: *mut f32) -> c_int;
         // ---- stage level, 1:1 with the reference's pub functions (host arrays in the reference layouts)
         pub fn sp_ntt_forward(p: *const sp_params_t, data: *mut u64, count: usize) -> c_int;

@@ -1355,6 +1355,15 @@ int sp_debug_cu_probe(int bit_lo, int bit_hi, int blocks, uint32_t* out2) {
 // checksum as a kernel on a fresh non-blocking stream sees it, checksum of a device-to-host copy, the kernel view again
 // after k_cache_sync (L2 write-back + invalidate on every XCD), and the checksum of the host original where the
 // library still has it (tw; 0 otherwise).  A kernel view that differs from the copy view is a stale cache line.
+int sp_debug_chacha20_u64(const uint8_t seed[32], uint64_t* out, size_t count) {
+  if (!seed || (!out && count)) {
+    g_last_error = "null argument";
+    return SP_E_ARG;
+  }
+  chacha20_keystream_u64(seed, out, count);
+  return SP_OK;
+}
+
 int sp_debug_resident_check(const sp_params_t* h, const sp_pp_t* pp, uint64_t* out, int cap) {
   return guarded([&] {
     need(h && pp && out && cap >= 24, "bad argument");

@@ -286,6 +286,7 @@ void launch_ntt_inv(const DevTables& T, const InvDesc& d, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // from_ntt of four adjacent sweep-output columns per workgroup.  grid (np/4 * 2 * planes)
 // ------------------------------------------------------------------------------------------------
+typedef u32 mf4_t __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* src, int np, int premod, u64* dst, int xcd_map) {
   __shared__ u32 lds0[4 * LDS_WORDS];
   __shared__ u32 lds1[4 * LDS_WORDS];
@@ -312,7 +313,16 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
   for (int c = 0; c < 2; c++)
 #pragma unroll
     for (int k = 0; k < 8; k++)
-      xin[c][k] = *reinterpret_cast<const uint4*>(src + base + (size_t)c * N * np + (size_t)(8 * tau + k) * np);
+    {
+      const uint4* q = reinterpret_cast<const uint4*>(src + base + (size_t)c * N * np + (size_t)(8 * tau + k) * np);
+      // (r06 experiment, switch from_sweep_nt: loads that bypass the L1 -- 16 bytes of each 128-byte line are this workgroup's)
+      if (xcd_map & 2) {
+        const mf4_t t = __builtin_nontemporal_load(reinterpret_cast<const mf4_t*>(q));
+        xin[c][k] = make_uint4(t.x, t.y, t.z, t.w);
+      } else {
+        xin[c][k] = *q;
+      }
+    }
 #pragma unroll
   for (int c = 0; c < 2; c++) {
     const ModConst m = T.c.mod[c];
@@ -356,12 +366,12 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
   const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
-  const int xcd_map = tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0;
+  const int xcd_map = (tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0 ? 1 : 0) | (tunable("from_sweep_nt", 0) != 0 ? 2 : 0);
   // (r04: a persistent form of this kernel that pulled each workgroup's next operand into the L2 ahead of its transform was
   // measured on one allocation and changes nothing -- 85.8 vs 85.5 queries/s, 2.08 vs 2.05 ms of un-pipelined from_ntt +
   // fold, 30.4 vs 30.1 ms per 8-query step -- and is gone again: profiles/r04_fold_from_ntt_ab.md)
   hipLaunchKernelGGL(k_from_sweep4, dim3(groups), dim3(256), 0, s, T, src, np, premod, dst, xcd_map);
-  launched(PATH_FROM_SWEEP4 | (xcd_map ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
+  launched(PATH_FROM_SWEEP4 | ((xcd_map & 1) ? PATH_SWEEP_XCD_FROM : 0), "k_from_sweep4");
 }
 
 }  // namespace spiral

@@ -203,37 +203,68 @@ void debug_stage(int stage) {
 }
 
 // ---------------------------------------------------------------------------------- ChaCha20
-// LANES consecutive blocks side by side (counter ctr0 + lane): plain loops over the lane index that the host compiler turns into
-// vector code -- 8 x 32 bits with AVX2 where the CPU has it (the function-level target below), 4 x 32 with the baseline SSE2.  Same
-// keystream as the one-block loop it replaces (r06: a query's 16 KiB of keystream took ~25 us of host time per query, which a
-// 16-query call pays sixteen times before its first kernel can start).
-template <int LANES>
-static inline void chacha_blocks(const u32 init[16], u64 ctr0, u32 (*out)[16]) {
-  u32 s[16][LANES], in0[16][LANES];
-  for (int i = 0; i < 16; i++)
-    for (int l = 0; l < LANES; l++) in0[i][l] = init[i];
-  for (int l = 0; l < LANES; l++) {
-    const u64 c = ctr0 + (u64)l;
-    in0[12][l] = (u32)c;
-    in0[13][l] = (u32)(c >> 32);
-    in0[14][l] = in0[15][l] = 0;
-  }
+// One block at a time (any x86-64), and eight blocks side by side with AVX2 where the CPU has it (one __m256i per state word,
+// counters ctr0 .. ctr0 + 7): a query's 16 KiB of keystream takes 28 us of host time the first way, 8 the second -- and a
+// 16-query call pays it sixteen times before its first kernel can start (r06).  Same keystream either way.
+static inline u32 rotl(u32 v, int c) { return (v << c) | (v >> (32 - c)); }
+static inline void quarter(u32* s, int a, int b, int c, int d) {
+  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 16);
+  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 12);
+  s[a] += s[b]; s[d] = rotl(s[d] ^ s[a], 8);
+  s[c] += s[d]; s[b] = rotl(s[b] ^ s[c], 7);
+}
+static void chacha_block(const u32 init[16], u64 ctr, u32 out[16]) {
+  u32 in0[16], s[16];
+  memcpy(in0, init, sizeof(in0));
+  in0[12] = (u32)ctr;
+  in0[13] = (u32)(ctr >> 32);
+  in0[14] = in0[15] = 0;
   memcpy(s, in0, sizeof(s));
-#define SP_QR(a, b, c, d)                                                                                       \
-  for (int l = 0; l < LANES; l++) { s[a][l] += s[b][l]; s[d][l] ^= s[a][l]; s[d][l] = (s[d][l] << 16) | (s[d][l] >> 16); } \
-  for (int l = 0; l < LANES; l++) { s[c][l] += s[d][l]; s[b][l] ^= s[c][l]; s[b][l] = (s[b][l] << 12) | (s[b][l] >> 20); } \
-  for (int l = 0; l < LANES; l++) { s[a][l] += s[b][l]; s[d][l] ^= s[a][l]; s[d][l] = (s[d][l] << 8) | (s[d][l] >> 24); }  \
-  for (int l = 0; l < LANES; l++) { s[c][l] += s[d][l]; s[b][l] ^= s[c][l]; s[b][l] = (s[b][l] << 7) | (s[b][l] >> 25); }
+  for (int rnd = 0; rnd < 10; rnd++) {
+    quarter(s, 0, 4, 8, 12); quarter(s, 1, 5, 9, 13); quarter(s, 2, 6, 10, 14); quarter(s, 3, 7, 11, 15);
+    quarter(s, 0, 5, 10, 15); quarter(s, 1, 6, 11, 12); quarter(s, 2, 7, 8, 13); quarter(s, 3, 4, 9, 14);
+  }
+  for (int i = 0; i < 16; i++) out[i] = s[i] + in0[i];
+}
+#if defined(__x86_64__)
+}  // namespace spiral
+#include <immintrin.h>
+namespace spiral {
+__attribute__((target("avx2"))) static void chacha_blocks8_avx2(const u32 init[16], u64 ctr0, u32 (*out)[16]) {
+  __m256i in0[16], s[16];
+  for (int i = 0; i < 16; i++) in0[i] = _mm256_set1_epi32((int)init[i]);
+  alignas(32) u32 lo[8], hi[8];
+  for (int l = 0; l < 8; l++) {
+    const u64 c = ctr0 + (u64)l;
+    lo[l] = (u32)c;
+    hi[l] = (u32)(c >> 32);
+  }
+  in0[12] = _mm256_load_si256(reinterpret_cast<const __m256i*>(lo));
+  in0[13] = _mm256_load_si256(reinterpret_cast<const __m256i*>(hi));
+  in0[14] = in0[15] = _mm256_setzero_si256();
+  for (int i = 0; i < 16; i++) s[i] = in0[i];
+#define SP_ROT(x, n) _mm256_or_si256(_mm256_slli_epi32(x, n), _mm256_srli_epi32(x, 32 - n))
+#define SP_QR(a, b, c, d)                                                                              \
+  s[a] = _mm256_add_epi32(s[a], s[b]); s[d] = _mm256_xor_si256(s[d], s[a]); s[d] = SP_ROT(s[d], 16);   \
+  s[c] = _mm256_add_epi32(s[c], s[d]); s[b] = _mm256_xor_si256(s[b], s[c]); s[b] = SP_ROT(s[b], 12);   \
+  s[a] = _mm256_add_epi32(s[a], s[b]); s[d] = _mm256_xor_si256(s[d], s[a]); s[d] = SP_ROT(s[d], 8);    \
+  s[c] = _mm256_add_epi32(s[c], s[d]); s[b] = _mm256_xor_si256(s[b], s[c]); s[b] = SP_ROT(s[b], 7);
   for (int rnd = 0; rnd < 10; rnd++) {
     SP_QR(0, 4, 8, 12) SP_QR(1, 5, 9, 13) SP_QR(2, 6, 10, 14) SP_QR(3, 7, 11, 15)
     SP_QR(0, 5, 10, 15) SP_QR(1, 6, 11, 12) SP_QR(2, 7, 8, 13) SP_QR(3, 4, 9, 14)
   }
 #undef SP_QR
-  for (int l = 0; l < LANES; l++)
-    for (int i = 0; i < 16; i++) out[l][i] = s[i][l] + in0[i][l];
+#undef SP_ROT
+  alignas(32) u32 tmp[16][8];
+  for (int i = 0; i < 16; i++) _mm256_store_si256(reinterpret_cast<__m256i*>(tmp[i]), _mm256_add_epi32(s[i], in0[i]));
+  for (int l = 0; l < 8; l++)
+    for (int i = 0; i < 16; i++) out[l][i] = tmp[i][l];
 }
-__attribute__((target("avx2"))) static void chacha_blocks8_avx2(const u32 init[16], u64 ctr0, u32 (*out)[16]) { chacha_blocks<8>(init, ctr0, out); }
-static void chacha_blocks8_base(const u32 init[16], u64 ctr0, u32 (*out)[16]) { chacha_blocks<8>(init, ctr0, out); }
+static bool cpu_has_avx2() { return __builtin_cpu_supports("avx2"); }
+#else
+static void chacha_blocks8_avx2(const u32*, u64, u32 (*)[16]) {}
+static bool cpu_has_avx2() { return false; }
+#endif
 
 void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
   u32 init[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u};
@@ -242,14 +273,20 @@ void chacha20_keystream_u64(const uint8_t seed[32], u64* out, size_t count) {
     memcpy(&w, seed + 4 * i, 4);
     init[4 + i] = w;
   }
-  static const bool have_avx2 = __builtin_cpu_supports("avx2");
+  static const bool wide = cpu_has_avx2() && tunable("chacha_scalar", 0) == 0;
   u64 ctr = 0;
   size_t done = 0;
   u32 blk[8][16];
   while (done < count) {
-    (have_avx2 ? chacha_blocks8_avx2 : chacha_blocks8_base)(init, ctr, blk);
-    ctr += 8;
-    for (int l = 0; l < 8 && done < count; l++)
+    int have = 1;
+    if (wide && count - done >= 16) {   // (a short tail -- or a short request -- goes block by block)
+      chacha_blocks8_avx2(init, ctr, blk);
+      have = 8;
+    } else {
+      chacha_block(init, ctr, blk[0]);
+    }
+    ctr += (u64)have;
+    for (int l = 0; l < have && done < count; l++)
       for (int i = 0; i < 16 && done < count; i += 2, done++) out[done] = (u64)blk[l][i] | ((u64)blk[l][i + 1] << 32);
   }
 }

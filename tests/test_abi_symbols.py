@@ -106,3 +106,17 @@ def test_params_validation_rejects_what_the_reference_cannot_run():
             continue
         # nu_1 = 0 is legal if the reference accepts it; only the first five must raise
         assert bad.get("nu_1") == 0, bad
+
+
+def test_library_chacha20_equals_the_pinned_restatement(oracle_mod):
+    """sp_debug_chacha20_u64 (no GPU): the product's keystream -- eight blocks side by side with AVX2, one block at a time for short
+    requests and tails -- against the oracle's, which tests/test_oracle_kat.py pins to RFC 8439 and to rand_chacha's own vectors."""
+    import ctypes as C
+    import numpy as np
+    from sdk_amd import library_path
+    L = C.CDLL(library_path())
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 2048, 2051):
+        for seed in (bytes(range(32)), bytes(31) + b"\x01", b"\xff" * 32):
+            out = np.zeros(max(n, 1), dtype=np.uint64)
+            assert L.sp_debug_chacha20_u64((C.c_uint8 * 32)(*seed), out.ctypes.data_as(C.c_void_p), C.c_size_t(n)) == 0
+            assert (out[:n] == oracle_mod.chacha20_rng_u64(seed, n)[:n]).all(), (n, seed[:2])
