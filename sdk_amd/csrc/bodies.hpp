@@ -87,12 +87,15 @@ __device__ __forceinline__ void ntt_inv_body(const DevTables& T, const InvDesc& 
       const int ct = d.scal_only_idx[e >> 1], r = e & 1;
       const long sp = ((long)(ct - d.scal_thresh) * 2 + r) * 2 * N, dp = ((long)ct * 2 + r) * 2 * N;
 #pragma unroll
-      for (int c = 0; c < 2; c++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int z = 8 * tau + k;
-          d.scal_dst[dp + c * N + z] = reduce64((u64)d.src[sp + c * N + z] * (u64)d.scal[c * N + z], T.c.mod[c]);
-        }
+      for (int c = 0; c < 2; c++) {
+        const uint4* a = reinterpret_cast<const uint4*>(d.src + sp + c * N + 8 * tau);     // (polynomial offsets are multiples of N)
+        const uint4* b = reinterpret_cast<const uint4*>(d.scal + c * N + 8 * tau);
+        const uint4 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        const ModConst m = T.c.mod[c];
+        uint4* o = reinterpret_cast<uint4*>(d.scal_dst + dp + c * N + 8 * tau);
+        o[0] = make_uint4(reduce64((u64)a0.x * b0.x, m), reduce64((u64)a0.y * b0.y, m), reduce64((u64)a0.z * b0.z, m), reduce64((u64)a0.w * b0.w, m));
+        o[1] = make_uint4(reduce64((u64)a1.x * b1.x, m), reduce64((u64)a1.y * b1.y, m), reduce64((u64)a1.z * b1.z, m), reduce64((u64)a1.w * b1.w, m));
+      }
       return;
     }
     const int e = p / d.polys_per_idx, r = p - e * d.polys_per_idx;
@@ -108,15 +111,36 @@ __device__ __forceinline__ void ntt_inv_body(const DevTables& T, const InvDesc& 
     const ModConst m = T.c.mod[c];
     const u32* src = d.src + base + (long)c * crt_stride;
     u32 v[8];
+    if (z_stride == 1 && ((base | crt_stride | (scal_store < 0 ? 0 : scal_store)) & 3) == 0) {
+      // contiguous polynomials (every caller but the sweep-source mode): a thread's 8 coefficients are 32 contiguous bytes -- two
+      // 16-byte accesses instead of eight 4-byte ones at a 32-byte lane stride, for the source, the scalar and the stored product
+      // (r06: the expansion's inverse launches ran at 15 ns per transform, three times their transform's cost)
+      const uint4 a0 = reinterpret_cast<const uint4*>(src + 8 * tau)[0], a1 = reinterpret_cast<const uint4*>(src + 8 * tau)[1];
+      v[0] = a0.x; v[1] = a0.y; v[2] = a0.z; v[3] = a0.w; v[4] = a1.x; v[5] = a1.y; v[6] = a1.z; v[7] = a1.w;
+      if (d.premod) {
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-      u32 x = src[(long)(8 * tau + k) * z_stride];
-      if (d.premod) x = x % m.q;
-      if (scal_store >= 0) {
-        x = reduce64((u64)x * (u64)d.scal[c * N + 8 * tau + k], m);
-        d.scal_dst[scal_store + (long)c * crt_stride + 8 * tau + k] = x;
+        for (int k = 0; k < 8; k++) v[k] %= m.q;
       }
-      v[k] = x;
+      if (scal_store >= 0) {
+        const uint4 s0 = reinterpret_cast<const uint4*>(d.scal + c * N + 8 * tau)[0], s1 = reinterpret_cast<const uint4*>(d.scal + c * N + 8 * tau)[1];
+        const u32 sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = reduce64((u64)v[k] * (u64)sc[k], m);
+        uint4* o = reinterpret_cast<uint4*>(d.scal_dst + scal_store + (long)c * crt_stride + 8 * tau);
+        o[0] = make_uint4(v[0], v[1], v[2], v[3]);
+        o[1] = make_uint4(v[4], v[5], v[6], v[7]);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        u32 x = src[(long)(8 * tau + k) * z_stride];
+        if (d.premod) x = x % m.q;
+        if (scal_store >= 0) {
+          x = reduce64((u64)x * (u64)d.scal[c * N + 8 * tau + k], m);
+          d.scal_dst[scal_store + (long)c * crt_stride + 8 * tau + k] = x;
+        }
+        v[k] = x;
+      }
     }
     const u32* iw = inv_tables(T.tw, c);
     if (c == 1) __syncthreads();
