@@ -9,7 +9,6 @@
 // This unit: forward / inverse transform kernels, from_ntt of the sweep output, the transform-core micro-benchmark.
 #include "device_common.hpp"
 #include "bodies.hpp"
-#include "server.hpp"
 
 namespace spiral {
 
@@ -354,90 +353,13 @@ __global__ __launch_bounds__(256, 2) void k_from_sweep4(DevTables T, const u32* 
     }
   }
 }
-// EIGHT adjacent columns per workgroup (r06): two sets of 256 threads, each exactly k_from_sweep4's work on four columns with its
-// own LDS buffers, in lockstep -- the two sets ask for neighbouring 16-byte pieces of the same 2 x 2048 lines at the same moment,
-// so a line crosses from the L2 into this CU's L1 once for 32 of its bytes instead of once per 16 (k_from_sweep4: each line is
-// pulled into EIGHT CUs' L1s, 43 % of its time; profiles/r05_from_sweep_dissection.md).  134 KiB of LDS: one workgroup = eight waves
-// per CU, as two of k_from_sweep4's.  grid (np/8 * 2 * planes); the four workgroups that share a line sit on ONE XCD, back to back.
-__global__ __launch_bounds__(512, 1) void k_from_sweep8(DevTables T, const u32* src, int np, int premod, u64* dst) {
-  extern __shared__ __attribute__((aligned(16))) u32 smem_fs[];
-  const int sub = threadIdx.x >> 8, tau = threadIdx.x & 255;
-  u32* lds0 = smem_fs + (size_t)sub * 8 * LDS_WORDS;
-  u32* lds1 = lds0 + 4 * LDS_WORDS;
-  int g = blockIdx.x;                    // (plane, r, ii/8)
-  {
-    const int xcd = g & 7, t = g >> 3;   // block b -> XCD b % 8 handles line (b/32)*8 + b%8, group (b/8) % 4 of that line
-    g = ((t >> 2) * 8 + xcd) * 4 + (t & 3);
-  }
-  const int gpr = np / 8;  // groups per (plane, r)
-  const int groups_per_plane = gpr * 2;
-  const int plane = g / groups_per_plane, rem = g % groups_per_plane;
-  const int r = rem / gpr, gl = rem % gpr;
-  const int ii0 = gl * 8 + sub * 4;
-  const size_t base = ((size_t)plane * 4 + r * 2) * N * np + ii0;
-  u32 res0[4][8];
-  uint4 xin[2][8];
-#pragma unroll
-  for (int c = 0; c < 2; c++)
-#pragma unroll
-    for (int k = 0; k < 8; k++)
-      xin[c][k] = *reinterpret_cast<const uint4*>(src + base + (size_t)c * N * np + (size_t)(8 * tau + k) * np);
-#pragma unroll
-  for (int c = 0; c < 2; c++) {
-    const ModConst m = T.c.mod[c];
-    u32 v[4][8];
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-      uint4 x = xin[c][k];
-      if (premod) {
-        x.x %= m.q; x.y %= m.q; x.z %= m.q; x.w %= m.q;
-      }
-      v[0][k] = x.x; v[1][k] = x.y; v[2][k] = x.z; v[3][k] = x.w;
-    }
-    const u32* iw = inv_tables(T.tw, c);
-    if (c == 1) __syncthreads();
-    ntt_inv_block_m<4>(v, tau, lds0, lds1, iw, iw + N, m.q, m.two_q);
-    if (c == 0) {
-#pragma unroll
-      for (int mm = 0; mm < 4; mm++)
-#pragma unroll
-        for (int k = 0; k < 8; k++) res0[mm][k] = v[mm][k];
-    } else {
-      const u32 q0 = T.c.mod[0].q, q1 = T.c.mod[1].q;
-#pragma unroll
-      for (int mm = 0; mm < 4; mm++) {
-        u64* out = dst + (((size_t)plane * np + ii0 + mm) * 2 + r) * N;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          u32 x = res0[mm][k], y = v[mm][k];
-          u32 xm = x >= q1 ? x - q1 : x;
-          u32 dd = y >= xm ? y - xm : y + q1 - xm;
-          u32 qt = __umulhi(dd, T.c.q0_inv_q1_sh);
-          u32 e = dd * T.c.q0_inv_q1 - qt * q1;
-          e = e >= q1 ? e - q1 : e;
-          const u64 val = (u64)x + (u64)q0 * (u64)e;
-          out[tau + 256 * k] = val;
-        }
-      }
-    }
-  }
-}
-static void launch_from_sweep8(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
-  const unsigned groups = (unsigned)((np / 8) * 2 * n_planes);
-  const size_t lds = (size_t)2 * 8 * LDS_WORDS * sizeof(u32);
-  HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_from_sweep8), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  hipLaunchKernelGGL(k_from_sweep8, dim3(groups), dim3(512), lds, s, T, src, np, premod, dst);
-  launched(PATH_FROM_SWEEP4 | PATH_SWEEP_XCD_FROM, "k_from_sweep8");
-}
 void launch_from_sweep4(const DevTables& T, const u32* src, int np, int n_planes, int premod, u64* dst, hipStream_t s) {
   if (n_planes <= 0) return;
   const unsigned groups = (unsigned)((np / 4) * 2 * n_planes);
-  // (r06: the same loads as non-temporal ones, which bypass the L1 -- 16 of each line's 128 bytes are this workgroup's -- are
-  // SLOWER: 340 against 301 us per launch, profiles/r06_from_sweep8.md)
-  if (tunable("from_sweep8", 1) != 0 && (np % 32) == 0 && ((np / 8) * 2 * n_planes) % 32 == 0) {
-    launch_from_sweep8(T, src, np, n_planes, premod, dst, s);
-    return;
-  }
+  // (r06, both measured and removed, profiles/r06_from_sweep8.md: the same loads as non-temporal ones, which bypass the L1 -- 16 of
+  // each line's 128 bytes are this workgroup's -- are slower, 340 against 301 us per launch; EIGHT columns per 512-thread workgroup,
+  // two sets of threads asking for neighbouring pieces of the same lines in lockstep, is no faster alone -- 278 against 267 us --
+  // and, at 147 KiB of LDS, does not fit beside the sweep's resident wave: the pipelined query lost 6 %)
   const int xcd_map = tunable("from_sweep_xcd", 1) != 0 && (np % 32) == 0 && (groups % 64) == 0;
   // (r04: a persistent form of this kernel that pulled each workgroup's next operand into the L2 ahead of its transform was
   // measured on one allocation and changes nothing -- 85.8 vs 85.5 queries/s, 2.08 vs 2.05 ms of un-pipelined from_ntt +

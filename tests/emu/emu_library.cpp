@@ -12,7 +12,6 @@ alignas(16) thread_local unsigned char smem_q[LDS_ARRAY];
 alignas(16) thread_local unsigned char smem[LDS_ARRAY];
 alignas(16) thread_local unsigned char smem_rq[LDS_ARRAY];
 alignas(16) thread_local unsigned char smem_pl[LDS_ARRAY];
-alignas(16) thread_local uint32_t smem_fs[LDS_ARRAY / 4];
 }  // namespace spiral
 
 typedef unsigned char* (*emu_lds_getter)();
@@ -25,7 +24,6 @@ struct RegisterLds {
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem; });
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem_rq; });
     emu_register_dynamic_lds([]() -> unsigned char* { return spiral::smem_pl; });
-    emu_register_dynamic_lds([]() -> unsigned char* { return reinterpret_cast<unsigned char*>(spiral::smem_fs); });
   }
 } g_register_lds;
 }  // namespace
