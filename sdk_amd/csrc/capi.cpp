@@ -1183,11 +1183,12 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       // DISJOINT SETS OF CUs it is faster: the pass becomes a background stream on `batch_pass_cus` CUs under the folds, which
       // are the larger part of a 16-query step; run_batch_planes_pipelined, profiles/r06_batch_cu_split.md)
       const long pass_cus = tunable("batch_pass_cus", BATCH_PASS_CUS_DEFAULT);
+      if (pass_cus <= 0 && W0.D->masked_split != 0) W0.D->release_masked_streams();   // switched off: the hardware queues go too
       if (batch_pipeline_applies(p, d, pass_cus)) {
         Workspace* Ws[GROUP_MAX];
         for (int i = 0; i < B; i++) Ws[i] = qs[i]->ws.get();
         run_batch_planes_pipelined(Ws, B, d, (int)pass_cus);
-        HIP_CHECK(hipEventRecord(W0.ev[2], W0.masked_stream(0, (int)pass_cus)));   // the last plane's pass
+        HIP_CHECK(hipEventRecord(W0.ev[2], W0.D->masked_stream(0, (int)pass_cus)));   // the last plane's pass
         prev_pass = W0.ev[2];
         stamp("pass + folds enqueued");
         for (int i = 0; i < B; i++) {

@@ -12,11 +12,7 @@ struct Workspace {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
-  // streams confined to a set of CUs (batched per-plane pipeline, r06): [0] = the first `masked_split` CUs of the device (the
-  // group's database pass), [1] = all the others (the queries' folds).  Created on first use, re-created when the split changes.
-  hipStream_t stream_masked[2] = {nullptr, nullptr};
-  int masked_split = 0;
-  hipStream_t masked_stream(int which, int split);   // server.cpp
+
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)

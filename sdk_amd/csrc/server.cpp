@@ -623,24 +623,27 @@ Workspace::~Workspace() {
   if (ev_fold) (void)hipEventDestroy(ev_fold);
   for (hipEvent_t e : {ev_sw[0], ev_sw[1], ev_round0, ev_right})
     if (e) (void)hipEventDestroy(e);
-  for (hipStream_t& ms : stream_masked)
-    if (ms) (void)hipStreamDestroy(ms);
   if (stream2) (void)hipStreamDestroy(stream2);
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-// a stream whose kernels run only on CUs [0, split) (which = 0) or [split, all) (which = 1) of the device; the mask's bits are
+// a stream whose kernels run only on CUs [0, split) (which = 0) or [split, all) (which = 1, 2) of the device; the mask's bits are
 // dealt round-robin over the XCDs (probe: profiles/r02_cu_split_raw.txt), so either set keeps every XCD's L2 and memory channels
-hipStream_t Workspace::masked_stream(int which, int split) {
-  if (masked_split != split) {
-    for (hipStream_t& ms : stream_masked)
-      if (ms) {
-        (void)hipStreamSynchronize(ms);
-        (void)hipStreamDestroy(ms);
-        ms = nullptr;
-      }
-    masked_split = split;
-  }
+void DeviceState::release_masked_streams() {
+  std::lock_guard<std::mutex> lk(masked_mu);
+  for (hipStream_t& ms : stream_masked)
+    if (ms) {
+      (void)hipStreamSynchronize(ms);
+      (void)hipStreamDestroy(ms);
+      ms = nullptr;
+    }
+  masked_split = 0;
+}
+DeviceState::~DeviceState() { release_masked_streams(); }
+hipStream_t DeviceState::masked_stream(int which, int split) {
+  if (masked_split != split) release_masked_streams();
+  std::lock_guard<std::mutex> lk(masked_mu);
+  masked_split = split;
   if (!stream_masked[which]) {
     hipDeviceProp_t prop;
     HIP_CHECK(hipGetDeviceProperties(&prop, device));
@@ -1374,7 +1377,8 @@ void run_batch_planes_pipelined(Workspace* const* Ws, int B, const SweepBatchDes
   const Params& p = *W0.P;
   const int planes = (int)p.planes();
   const int defer_levels = tail_defer_levels(p, tunable("pipe_tail_defer", 256));
-  hipStream_t s_full = W0.stream, s_pass = W0.masked_stream(0, pass_cus);
+  DeviceState& D = *W0.D;
+  hipStream_t s_full = W0.stream, s_pass = D.masked_stream(0, pass_cus);
   for (int i = 0; i < B; i++) {
     Ws[i]->ensure_finish();
     Ws[i]->fold_tail.ensure(2 * (size_t)planes * (p.num_per() >> defer_levels) * 2 * POLY_LEN);  // (no-op: ensure_finish sized it)
@@ -1384,9 +1388,10 @@ void run_batch_planes_pipelined(Workspace* const* Ws, int B, const SweepBatchDes
     const bool last = pl + 1 == planes;
     for (int i = 0; i < B; i++) {
       Workspace& W = *Ws[i];
-      hipStream_t f = last ? W.stream : W.masked_stream(1, pass_cus);
-      if (last && planes > 1) {         // the query's earlier planes ran on its masked stream: order the main stream after them
-        HIP_CHECK(hipEventRecord(W.ev_fold, W.masked_stream(1, pass_cus)));
+      hipStream_t fm = D.masked_stream(1 + (i & 1), pass_cus);   // (a query keeps to one of the two: its planes stay in order)
+      hipStream_t f = last ? W.stream : fm;
+      if (last && planes > 1) {         // the query's earlier planes ran on a masked stream: order the main stream after them
+        HIP_CHECK(hipEventRecord(W.ev_fold, fm));
         HIP_CHECK(hipStreamWaitEvent(f, W.ev_fold, 0));
       }
       HIP_CHECK(hipStreamWaitEvent(f, W0.ev_plane[(size_t)pl], 0));
