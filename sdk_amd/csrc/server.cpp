@@ -1388,9 +1388,13 @@ void run_batch_planes_pipelined(Workspace* const* Ws, int B, const SweepBatchDes
     const bool last = pl + 1 == planes;
     for (int i = 0; i < B; i++) {
       Workspace& W = *Ws[i];
-      hipStream_t fm = D.masked_stream(1 + (i & 1), pass_cus);   // (a query keeps to one of the two: its planes stay in order)
-      hipStream_t f = last ? W.stream : fm;
-      if (last && planes > 1) {         // the query's earlier planes ran on a masked stream: order the main stream after them
+      // batch_fold_masked = 1: the folds of all but the last plane on two streams confined to the OTHER CUs (measured: the sixteen
+      // queries' launches then run two at a time in sequence and lose more to partial last rounds than the confinement gains);
+      // default: the queries' own un-masked streams -- only the pass is confined, the folds take whatever CU has room
+      const bool fold_masked = !last && tunable("batch_fold_masked", 0) != 0;
+      hipStream_t fm = fold_masked || (last && tunable("batch_fold_masked", 0) != 0) ? D.masked_stream(1 + (i & 1), pass_cus) : nullptr;
+      hipStream_t f = fold_masked ? fm : W.stream;
+      if (last && planes > 1 && fm) {   // the query's earlier planes ran on a masked stream: order the main stream after them
         HIP_CHECK(hipEventRecord(W.ev_fold, fm));
         HIP_CHECK(hipStreamWaitEvent(f, W.ev_fold, 0));
       }
