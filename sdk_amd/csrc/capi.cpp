@@ -1178,38 +1178,19 @@ int sp_process_query_batch(const sp_params_t* h, const sp_pp_t* const* pps, cons
       }
       sweep_batch_prepare(W0.D->T, d, W0.stream);
       // (a per-plane form of the pass with every query folding plane p beside the pass of plane p + 1 was measured in rounds
-      // 2 and 3 and is slower: the pass leaves no registers for a fold workgroup; profiles/r02_fold_batch_experiments.md.
-      // r06: with the pass on the matrix cores over the digit-planar copy -- no vector work in its loop -- and the two CONFINED TO
-      // DISJOINT SETS OF CUs it is faster: the pass becomes a background stream on `batch_pass_cus` CUs under the folds, which
-      // are the larger part of a 16-query step; run_batch_planes_pipelined, profiles/r06_batch_cu_split.md)
-      const long pass_cus = tunable("batch_pass_cus", BATCH_PASS_CUS_DEFAULT);
-      if (pass_cus <= 0 && W0.D->masked_split != 0) W0.D->release_masked_streams();   // switched off: the hardware queues go too
-      if (batch_pipeline_applies(p, d, pass_cus)) {
-        Workspace* Ws[GROUP_MAX];
-        for (int i = 0; i < B; i++) Ws[i] = qs[i]->ws.get();
-        run_batch_planes_pipelined(Ws, B, d, (int)pass_cus);
-        HIP_CHECK(hipEventRecord(W0.ev[2], W0.D->masked_stream(0, (int)pass_cus)));   // the last plane's pass
-        prev_pass = W0.ev[2];
-        stamp("pass + folds enqueued");
-        for (int i = 0; i < B; i++) {
-          Workspace& W = *qs[i]->ws;
-          if (i > 0) HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
-          run_finish(W, *qs[i]->pp, false);
+      // 2 and 3 and is slower: the pass leaves no registers for a fold workgroup; profiles/r02_fold_batch_experiments.md)
+      launch_sweep_batch(W0.D->T, d, W0.stream);
+      HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
+      prev_pass = W0.ev[2];
+      stamp("pass enqueued");
+      // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
+      for (int i = 0; i < B; i++) {
+        Workspace& W = *qs[i]->ws;
+        if (i > 0) {
+          HIP_CHECK(hipStreamWaitEvent(W.stream, W0.ev[2], 0));
+          HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
         }
-      } else {
-        launch_sweep_batch(W0.D->T, d, W0.stream);
-        HIP_CHECK(hipEventRecord(W0.ev[2], W0.stream));
-        prev_pass = W0.ev[2];
-        stamp("pass enqueued");
-        // 3. (rest of the) fold / pack per query, concurrently on the queries' own streams
-        for (int i = 0; i < B; i++) {
-          Workspace& W = *qs[i]->ws;
-          if (i > 0) {
-            HIP_CHECK(hipStreamWaitEvent(W.stream, W0.ev[2], 0));
-            HIP_CHECK(hipEventRecord(W.ev[2], W.stream));
-          }
-          run_finish(W, *qs[i]->pp, false);
-        }
+        run_finish(W, *qs[i]->pp, false);
       }
       prev_group = (size_t)B;
       stamp("folds enqueued");

@@ -397,8 +397,6 @@ struct SweepBatchDesc {
   // the two-tile pass then runs k_sweep_planar.  nullptr: the PACKED kernels.
   const unsigned char* planar;
 };
-// the same pass restricted to ONE plane (every batched kernel indexes planes from the launch's base pointers)
-SweepBatchDesc sweep_batch_plane(const SweepBatchDesc& d, int plane);
 // does this shape have a digit-planar form (whole 64-row blocks, the z-row's query planes in LDS, whole 128-column chunks)?
 bool sweep_planar_shape_ok(int num_per, int nj);
 size_t sweep_planar_bytes(int planes, int num_per, int nj);

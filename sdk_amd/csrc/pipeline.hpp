@@ -12,7 +12,6 @@ struct Workspace {
   int device = -1;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;            // fold of plane p runs here while plane p+1 is swept on `stream`
-
   std::vector<hipEvent_t> ev_plane;         // sweep of plane p done
   hipEvent_t ev_fold = nullptr;             // all folds done (stream2)
   hipEvent_t ev_round0 = nullptr, ev_right = nullptr;  // expansion round 0 done (main) / odd subtree + GSW side done (stream2)
@@ -83,13 +82,6 @@ void run_folding_neg(Workspace& W);
 void run_mats_to_wave(Workspace& W, size_t levels);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
-// The database pass and the folds of a group of queries as a per-plane pipeline on disjoint sets of CUs (r06; batched steps over
-// the digit-planar copy): the pass of plane p + 1 -- matrix cores and HBM, on `pass_cus` CUs -- beside the sixteen queries'
-// from_ntt + fold of plane p -- vector ALU, on the other CUs.  d: the group's pass, prepared (sweep_batch_prepare) on Ws[0]'s
-// stream.  Leaves every workspace in the state run_sweep_pipelined leaves it in: run_finish packs and encodes.
-constexpr long BATCH_PASS_CUS_DEFAULT = 64;
-bool batch_pipeline_applies(const Params& p, const SweepBatchDesc& d, long pass_cus);
-void run_batch_planes_pipelined(Workspace* const* Ws, int B, const SweepBatchDesc& d, int pass_cus);
 // B queries of one group (same params, un-pruned): the expansions' rounds as shared launches (kernels.hpp, GroupOff)
 void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_t* const* queries, const size_t* query_lens, int B);
 void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query_len, int j0 = 0, int nj = 0,

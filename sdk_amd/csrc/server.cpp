@@ -627,35 +627,6 @@ Workspace::~Workspace() {
   if (stream) (void)hipStreamDestroy(stream);
 }
 
-// a stream whose kernels run only on CUs [0, split) (which = 0) or [split, all) (which = 1, 2) of the device; the mask's bits are
-// dealt round-robin over the XCDs (probe: profiles/r02_cu_split_raw.txt), so either set keeps every XCD's L2 and memory channels
-void DeviceState::release_masked_streams() {
-  std::lock_guard<std::mutex> lk(masked_mu);
-  for (hipStream_t& ms : stream_masked)
-    if (ms) {
-      (void)hipStreamSynchronize(ms);
-      (void)hipStreamDestroy(ms);
-      ms = nullptr;
-    }
-  masked_split = 0;
-}
-DeviceState::~DeviceState() { release_masked_streams(); }
-hipStream_t DeviceState::masked_stream(int which, int split) {
-  if (masked_split != split) release_masked_streams();
-  std::lock_guard<std::mutex> lk(masked_mu);
-  masked_split = split;
-  if (!stream_masked[which]) {
-    hipDeviceProp_t prop;
-    HIP_CHECK(hipGetDeviceProperties(&prop, device));
-    const int cus = prop.multiProcessorCount;
-    if (split <= 0 || split >= cus) throw ArgError("CU split out of range");
-    std::vector<uint32_t> m((size_t)(cus + 31) / 32, 0u);
-    for (int k = which == 0 ? 0 : split; k < (which == 0 ? split : cus); k++) m[(size_t)k / 32] |= 1u << (k % 32);
-    HIP_CHECK(hipExtStreamCreateWithCUMask(&stream_masked[which], (uint32_t)m.size(), m.data()));
-  }
-  return stream_masked[which];
-}
-
 void Workspace::ensure_expand() {
   const Params& p = *P;
   const size_t g = p.g();
@@ -1361,69 +1332,6 @@ void run_sweep_pipelined(Workspace& W, const sp_db& db) {
   W.have_sweep_span = true;
   W.pipelined = true;
   note_path(PATH_PIPELINED);
-}
-
-bool batch_pipeline_applies(const Params& p, const SweepBatchDesc& d, long pass_cus) {
-  // (wide planes only: a plane's folds have to be worth a pipeline stage; the tests lower `batch_pipeline_min_cols`)
-  return pass_cus > 0 && d.planar && d.use_mfma && sweep_batch_tiles(d.batch) == 2 && p.planes() >= 2 &&
-         (long)p.num_per() >= tunable("batch_pipeline_min_cols", 1024) && tail_defer_levels(p, tunable("pipe_tail_defer", 256)) > 0;
-}
-
-// (pipeline.hpp)  Plane 0's pass and the last plane's folds have the whole device; in between the pass of plane p + 1 runs on
-// `pass_cus` CUs beside the folds of plane p on the others.  Every query folds a plane down to `pipe_tail_defer` ciphertexts and
-// parks it; the parked planes' last levels run together at the end (as in the pipelined single query).
-void run_batch_planes_pipelined(Workspace* const* Ws, int B, const SweepBatchDesc& d, int pass_cus) {
-  Workspace& W0 = *Ws[0];
-  const Params& p = *W0.P;
-  const int planes = (int)p.planes();
-  const int defer_levels = tail_defer_levels(p, tunable("pipe_tail_defer", 256));
-  DeviceState& D = *W0.D;
-  hipStream_t s_full = W0.stream, s_pass = D.masked_stream(0, pass_cus);
-  for (int i = 0; i < B; i++) {
-    Ws[i]->ensure_finish();
-    Ws[i]->fold_tail.ensure(2 * (size_t)planes * (p.num_per() >> defer_levels) * 2 * POLY_LEN);  // (no-op: ensure_finish sized it)
-  }
-  note_path(PATH_FOLD_TAIL_BATCHED | PATH_PIPELINED);
-  auto folds_of_plane = [&](int pl) {   // every query's from_ntt + first levels of plane pl (+ the parked tails after the last)
-    const bool last = pl + 1 == planes;
-    for (int i = 0; i < B; i++) {
-      Workspace& W = *Ws[i];
-      // batch_fold_masked = 1: the folds of all but the last plane on two streams confined to the OTHER CUs (measured: the sixteen
-      // queries' launches then run two at a time in sequence and lose more to partial last rounds than the confinement gains);
-      // default: the queries' own un-masked streams -- only the pass is confined, the folds take whatever CU has room
-      const bool fold_masked = !last && tunable("batch_fold_masked", 0) != 0;
-      hipStream_t fm = fold_masked || (last && tunable("batch_fold_masked", 0) != 0) ? D.masked_stream(1 + (i & 1), pass_cus) : nullptr;
-      hipStream_t f = fold_masked ? fm : W.stream;
-      if (last && planes > 1 && fm) {   // the query's earlier planes ran on a masked stream: order the main stream after them
-        HIP_CHECK(hipEventRecord(W.ev_fold, fm));
-        HIP_CHECK(hipStreamWaitEvent(f, W.ev_fold, 0));
-      }
-      HIP_CHECK(hipStreamWaitEvent(f, W0.ev_plane[(size_t)pl], 0));
-      hipStream_t own = W.stream;
-      W.stream = f;
-      try {
-        fold_plane_head(W, (size_t)pl, defer_levels);
-        if (last) fold_tails(W, defer_levels);
-      } catch (...) {
-        W.stream = own;
-        throw;
-      }
-      W.stream = own;
-    }
-  };
-  for (int pl = 0; pl < planes; pl++) {
-    hipStream_t s = pl == 0 ? s_full : s_pass;
-    if (pl == 1) HIP_CHECK(hipStreamWaitEvent(s_pass, W0.ev_plane[0], 0));   // (after the query tables and plane 0)
-    launch_sweep_batch(W0.D->T, sweep_batch_plane(d, pl), s);
-    HIP_CHECK(hipEventRecord(W0.ev_plane[(size_t)pl], s));
-    if (pl > 0) folds_of_plane(pl - 1);
-  }
-  folds_of_plane(planes - 1);
-  for (int i = 0; i < B; i++) {
-    Workspace& W = *Ws[i];
-    HIP_CHECK(hipEventRecord(W.ev_fold, W.stream));
-    W.pipelined = true;   // run_finish: wait for ev_fold (already in order on this stream), pack, encode
-  }
 }
 
 // k_fold_fused* keep gadget digits in u32 and need digit < 2q, i.e. at most 28 bits per digit (t_gsw >= 2)

@@ -128,17 +128,6 @@ struct RoundPlan {
 
 struct DeviceState {
   int device = -1;
-  // Streams confined to a set of CUs (batched per-plane pipeline, r06): [0] = the first `masked_split` CUs of the device (a
-  // group's database pass), [1], [2] = all the others (the queries' folds, dealt to the two).  THREE for the whole handle, not
-  // one per workspace: every such stream is a hardware queue of its own, and with seventeen of them alive everything on the
-  // device -- the un-masked streams too -- ran at half speed (profiles/r06_batch_cu_split.md).  Created on first use, re-created
-  // when the split changes, released with split = 0.
-  hipStream_t stream_masked[3] = {nullptr, nullptr, nullptr};
-  int masked_split = 0;
-  std::mutex masked_mu;
-  hipStream_t masked_stream(int which, int split);   // server.cpp
-  void release_masked_streams();
-  ~DeviceState();
   DevTables T;
   DevBuf<u32> tw;
   DevBuf<u32> neg1;        // [g][1 poly]

@@ -565,14 +565,6 @@ static void launch_sweep_mfma(const DevTables& T, const SweepBatchDesc& d, hipSt
   hipLaunchKernelGGL((k_sweep_mfma_batch<2, 2>), grid, dim3(256), lds, s, T, m);
   launched(PATH_SWEEP_BATCH | PATH_SWEEP_MFMA, "k_sweep_mfma_batch");
 }
-SweepBatchDesc sweep_batch_plane(const SweepBatchDesc& d, int plane) {
-  SweepBatchDesc o = d;
-  o.planes = 1;
-  o.db = d.db + db_bytes(1, d.num_per, d.nj, true) / sizeof(u64) * (size_t)plane;   // (the batched passes read PACKED databases)
-  if (d.planar) o.planar = d.planar + sweep_planar_bytes(1, d.num_per, d.nj) * (size_t)plane;
-  for (int b = 0; b < d.batch; b++) o.out[b] = d.out[b] + (size_t)plane * 4 * N * d.num_per;
-  return o;
-}
 void launch_sweep_batch(const DevTables& T, const SweepBatchDesc& d, hipStream_t s) {
   if (d.use_mfma && d.rq) {
     launch_sweep_mfma(T, d, s);

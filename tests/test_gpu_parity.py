@@ -1262,44 +1262,6 @@ def test_planar_copy_lifecycle(sp, oracle_mod, nu_1, nu_2):
     assert sp.Database(sp.Params(dict(cfg, nu_2=3))).prepare_batch() is False
 
 
-@pytest.mark.parametrize("nu_1,nu_2,B,inst", [(6, 7, 16, 1), (7, 8, 11, 2)], ids=["64x128-B16", "128x256-B11-inst2"])
-def test_batched_pass_and_folds_on_disjoint_cus(sp, oracle_mod, nu_1, nu_2, B, inst):
-    """r06: a group of 9-16 queries as a per-plane pipeline -- the pass of plane p + 1 on `batch_pass_cus` CUs (a CU-masked
-    stream) beside every query's from_ntt + first fold levels of plane p on the other CUs, the parked planes' last levels
-    together at the end (run_batch_planes_pipelined).  Byte-identical to the oracle, to the one-pass-then-folds flow
-    (batch_pass_cus = 0) and to another split; the path bit proves the pipeline ran (the shapes here are far below its default
-    threshold of 1024 columns: the test lowers it)."""
-    import ctypes as C
-    cfg = {"n": 2, "nu_1": nu_1, "nu_2": nu_2, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8,
-           "t_exp_right": 56, "instances": inst, "db_item_size": 256 * inst}
-    o = oracle_mod.Params(cfg)
-    p = sp.Params(cfg)
-    cl = oracle_mod.Client(o)
-    pp = cl.generate_keys(71)
-    gpp = sp.PublicParameters.deserialize(p, pp)
-    item, db = o.generate_random_db_and_get_item(5)
-    gdb = sp.Database(p).load(db)
-    qs = [cl.generate_query((733 * i + 5) % o.num_items, 300 + i) for i in range(B)]
-    want = [o.process_query(pp, q, db) for q in qs]
-    L = sp.lib()
-    try:
-        L.sp_debug_set(b"batch_pipeline_min_cols", C.c_long(128))
-        L.sp_debug_set(b"pipe_tail_defer", C.c_long(32))
-        for cus in (64, 0, 96):
-            L.sp_debug_set(b"batch_pass_cus", C.c_long(cus))
-            sp.paths_taken()
-            got = sp.process_query_batch(p, gpp, qs, gdb)
-            taken = sp.paths_taken()
-            assert "sweep_batch_planar" in taken, taken
-            assert ("pipelined_fold_overlap" in taken) == (cus > 0), (cus, taken)
-            assert got == want, cus
-        assert cl.decode_response(got[0]) == o.item_to_vec(item)
-    finally:
-        L.sp_debug_set(b"batch_pipeline_min_cols", C.c_long(1024))
-        L.sp_debug_set(b"pipe_tail_defer", C.c_long(256))
-        L.sp_debug_set(b"batch_pass_cus", C.c_long(64))
-
-
 def test_process_query_batch_matrix_core_extreme_digits(sp, oracle_mod):
     """Database words whose residues sit at the edges of the signed-digit split (every byte 0x80 / 0x7f, q - 1, 0, the
     largest top digit) in every row: the i32 digit sums of k_sweep_mfma_batch reach their largest magnitudes; 256 rows.
