@@ -36,7 +36,8 @@ SUBSET = ("test_params_tables_match or test_ntt_forward_inverse or test_to_ntt_f
           # the production kernels of the large configurations: wave-per-transform fold (nine gadget widths), ring-form sweep
           # with batched fold tails, the matrix-core batched pass
           "or (test_wave_fold_kernel_gadget_widths and (0 or 4 or 9 or 13)) or (test_ring_sweep_and_batched_tails_parity and 5-10-4-8-1-256)")
-LONG_SUBSET = "test_wave_fold_kernel_gadget_widths or (test_process_query_batch_matrix_core_sweep and 64x128) or (test_process_query_batch_two_query_tiles and 32x128-B19)"
+LONG_SUBSET = ("test_wave_fold_kernel_gadget_widths or (test_process_query_batch_matrix_core_sweep and 64x128) or (test_process_query_batch_two_query_tiles and 32x128-B19) "
+               "or (test_planar_copy_lifecycle and 64x128)")
 RACE_SUBSET = ("test_ntt_forward_inverse or test_to_ntt_from_ntt or test_fold_pack_encode or test_fused_fold_kernel "
                "or (test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_1)) "
                "or (test_wave_fold_kernel_gadget_widths and (0 or 13))")
@@ -72,6 +73,13 @@ def test_parity_subset_on_the_emulated_device(emulated):
     the one under which a missing wait between a plane's sweep and its fold fails -- see
     test_host_pipeline_survives_adversarial_stream_orders.)"""
     assert _run(emulated, SUBSET, {"SPIRAL_EMU_STREAMS": "starve:1"}) >= 38
+
+
+def test_group_expansion_on_the_emulated_device(emulated):
+    """r06: a batched group's expansions as shared launches (one more grid dimension = the query, per-query buffers behind byte
+    offsets: run_begin_group) -- a list of eleven queries on a PACKED database against the oracle, with the streams in an
+    adversarial order (the group flow hands work from the leader's stream back to every query's own)."""
+    assert _run(emulated, "test_process_query_batch and packed", {"SPIRAL_EMU_STREAMS": "random:11"}, at_least=1) >= 1
 
 
 @long_only
