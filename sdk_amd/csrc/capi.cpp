@@ -750,7 +750,11 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     Workspace& W = *q->ws;
     HIP_CHECK(hipEventRecord(W.ev[0], W.stream));
     // a long (per-plane, pipelined) sweep follows: worth moving the fold's half of the expansion off the critical path
-    W.long_sweep_follows = db && !db->sparse && sweep_is_pipelined(h->p, *db);
+    // (r06: also before the per-plane sweeps of a ROW SHARD -- the multi-GPU flows: the even subtree, pruned to the shard's rows,
+    // is short there, and the odd subtree + GSW side, which only the fold needs, then runs beside the sweeps and their exchanges
+    // instead of in front of them; switch expand_split_shards)
+    const bool shard_planes = rows && db->packed && h->p.planes() > 1 && h->p.num_per() >= 1024 && tunable("expand_split_shards", 1) != 0;
+    W.long_sweep_follows = db && !db->sparse && (sweep_is_pipelined(h->p, *db) || shard_planes);
     debug_stage(1);
     if (tunable("query_cache_sync", 0) != 0) launch_cache_sync(nullptr, W.stream);  // diagnostic: L2 write-back + invalidate per query
     run_begin(W, *pp, query, query_len, rows ? db->j0 : 0, rows ? db->nj : 0, plan);

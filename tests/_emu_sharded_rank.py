@@ -48,7 +48,10 @@ def main():
     comm.reserve(p)
     sp.paths_taken()
     outs = [comm.process_query(p, gpp, qq, shard) for qq in (q, q2, q)]
-    assert "rccl_in_library" in sp.paths_taken()
+    taken = sp.paths_taken()
+    assert "rccl_in_library" in taken
+    if os.environ.get("SPIRAL_EXPAND_SPLIT") == "1":      # (the caller forces the split expansion of wide row shards on this shape)
+        assert "expand_split" in taken and "expand_pruned" in taken, taken
     info = comm.describe()      # sp_comm_describe: what bench.py --gpus N logs per rank
     assert info["world"] == world and info["rank"] == rank and info["transport"] == "rccl" and info["planes"] == o.instances * o.n * o.n
     assert info["reduce_scatter_u32"]["per_plane_recv_bytes"] == 4 * 2048 * o.num_per // world * 4

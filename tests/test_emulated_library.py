@@ -135,6 +135,10 @@ def test_row_sharded_query_over_process_ranks(emulated, tmp_path, world, name, s
     test_host_pipeline_survives_adversarial_stream_orders -- comm.cpp orders its two streams with five events per query.)"""
     id_file = str(tmp_path / "comm_id")
     env = dict(os.environ, SPIRAL_HIP_LIB=emulated, SPIRAL_EMU_THREADS="2" if world <= 4 else "1", SPIRAL_EMU_STREAMS=streams)
+    if name == "packed":
+        # r06: wide row shards split their expansion (odd subtree + GSW side on the second stream, beside the per-plane sweeps and
+        # their exchanges); these shapes are below that rule's width, so force it -- with the second stream starved where it hurts
+        env.update(SPIRAL_EXPAND_SPLIT="1", SPIRAL_EMU_STREAMS="starve:2")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "_emu_sharded_rank.py"), str(r), str(world), id_file, name],
                               cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
