@@ -221,6 +221,8 @@ int sp_debug_set(const char* name, long value) {
   return SP_OK;
 }
 // internal hooks for comm.cpp (not declared in the public header)
+static thread_local int g_shard_split_hint = 1;   // 0 while a list of sharded queries is being enqueued
+extern "C" void sp_shard_split_hint_(int on) { g_shard_split_hint = on; }
 void sp_set_last_error_(const char* msg) { g_last_error = msg ? msg : ""; }
 void sp_note_path_(uint64_t bits) { note_path(bits); }
 
@@ -753,7 +755,12 @@ sp_query_t* sp_query_begin_for_db(const sp_params_t* h, const sp_pp_t* pp, const
     // (r06: also before the per-plane sweeps of a ROW SHARD -- the multi-GPU flows: the even subtree, pruned to the shard's rows,
     // is short there, and the odd subtree + GSW side, which only the fold needs, then runs beside the sweeps and their exchanges
     // instead of in front of them; switch expand_split_shards)
-    const bool shard_planes = rows && db->packed && h->p.planes() > 1 && h->p.num_per() >= 1024 && tunable("expand_split_shards", 1) != 0;
+    // NOT for a LIST of sharded queries (sp_process_queries_sharded): query k + 1 already expands under query k's sweeps there,
+    // and its odd subtree beside its own sweeps costs them more than it saves -- measured, one rank of 8 alone with a null
+    // transport: 2.59-2.64 -> 2.45-2.56 ms per query one at a time, 2.09-2.13 -> 2.38 in a list (profiles/r06_rank_critical_path.md);
+    // comm.cpp says which it is through sp_shard_split_hint_
+    const bool shard_planes = rows && db->packed && h->p.planes() > 1 && h->p.num_per() >= 1024 && g_shard_split_hint != 0 &&
+                              tunable("expand_split_shards", 1) != 0;
     W.long_sweep_follows = db && !db->sparse && (sweep_is_pipelined(h->p, *db) || shard_planes);
     debug_stage(1);
     if (tunable("query_cache_sync", 0) != 0) launch_cache_sync(nullptr, W.stream);  // diagnostic: L2 write-back + invalidate per query

@@ -30,6 +30,7 @@
 
 extern "C" void sp_set_last_error_(const char* msg);  // capi.cpp
 extern "C" void sp_note_path_(uint64_t bits);         // capi.cpp
+extern "C" void sp_shard_split_hint_(int on);         // capi.cpp: may the next sp_query_begin_for_db of this thread split the expansion?
 
 namespace {
 
@@ -244,10 +245,15 @@ struct ShardedRun {
   hipStream_t main = nullptr;
   size_t planes = 0, local_words = 0;
 };
+// on_critical_path: nothing of this rank's runs beside the expansion (a single query, the first of a list) -- then its odd subtree
+// and GSW side may move beside the sweeps that follow (capi.cpp, expand_split_shards); a list's later queries expand under their
+// predecessor's sweeps and keep the one-stream form
 void sharded_begin(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* pp, const uint8_t* query, size_t query_len,
-                   const sp_db_t* shard, ShardedRun& r) {
+                   const sp_db_t* shard, ShardedRun& r, bool on_critical_path) {
   r.planes = (size_t)sp_params_get(h, "instances") * sp_params_get(h, "n") * sp_params_get(h, "n");
+  sp_shard_split_hint_(on_critical_path ? 1 : 0);
   r.q = sp_query_begin_for_db(h, pp, query, query_len, shard);
+  sp_shard_split_hint_(1);
   if (!r.q) throw Fail{SP_E_ARG, std::string("sp_query_begin_for_db: ") + sp_last_error()};
   r.main = (hipStream_t)sp_query_stream(r.q);
   r.local_words = sp_query_local_cts_words(r.q);
@@ -320,7 +326,7 @@ int sp_process_query_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t* 
     hip_ok(hipGetDevice(&dev), "hipGetDevice");
     if (dev != c->device) throw Fail{SP_E_ARG, "the communicator was created on another HIP device"};
     comm_reserve(c, h);   // no-op after sp_comm_reserve / the first query with these params
-    sharded_begin(c, h, pp, query, query_len, shard, r);
+    sharded_begin(c, h, pp, query, query_len, shard, r, true);
     sharded_sweeps(c, shard, r, true);
     sharded_finish(c, r, out, out_cap, out_len, true);
     // [0] sweep launches incl. the exchanges overlapped with them, [1] exchange tail + local fold + all-gather
@@ -356,11 +362,11 @@ int sp_process_queries_sharded(sp_comm_t* c, const sp_params_t* h, const sp_pp_t
     *out_len = 0;
     if (n == 0) return;
     comm_reserve(c, h);
-    sharded_begin(c, h, pps[0], queries[0], query_lens[0], shard, cur);
+    sharded_begin(c, h, pps[0], queries[0], query_lens[0], shard, cur, true);
     for (int k = 0; k < n; k++) {
       sharded_sweeps(c, shard, cur, k == n - 1);
       // query k + 1 expands (on its own workspace's streams) while query k's planes are swept and exchanged
-      if (k + 1 < n) sharded_begin(c, h, pps[k + 1], queries[k + 1], query_lens[k + 1], shard, nxt);
+      if (k + 1 < n) sharded_begin(c, h, pps[k + 1], queries[k + 1], query_lens[k + 1], shard, nxt, false);
       size_t len = 0;
       sharded_finish(c, cur, c->rank == 0 ? out + (size_t)k * out_stride : nullptr, out_stride, &len, k == n - 1);
       if (c->rank == 0) *out_len = len;
