@@ -91,12 +91,18 @@ def main():
         paths = sorted(sp.paths_taken())
         ok = got == want
         extra = wire
-        if ok and rng.random() < 0.3:
-            B = int(rng.integers(2, 6))
-            lst = [q] * B
+        if ok and rng.random() < (0.8 if cfg["nu_2"] >= 7 else 0.3):
+            # lists: DISTINCT queries, and on PACKED shapes (nu_2 >= 7) often more than 8 of them -- r06: a batched group's expansions
+            # run as shared launches with per-query buffers behind byte offsets (run_begin_group), two query tiles from 9 queries
+            B = int(rng.integers(2, 12 if cfg["nu_2"] >= 7 else 6))
+            idxs = [int(rng.integers(0, o.num_items)) for _ in range(B)]
+            lst = [q] + ([cl.generate_query(i, qs + 7 + k) for k, i in enumerate(idxs[1:])] if not wire else [q] * (B - 1))
+            wants = [want] + ([o.process_query(pp, x, db) for x in lst[1:]] if not wire else [want] * (B - 1))
+            sp.paths_taken()
             outs = sp.process_query_batch(p, gpp, lst, gdb)
-            ok = all(x == want for x in outs)
-            extra = " list%d" % B
+            paths = sorted(set(paths) | sp.paths_taken())
+            ok = outs == wants
+            extra = wire + " list%d" % B
         if ok and rng.random() < 0.3 and not cfg.get("direct_upload") and cfg["p"] == 256:   # (lib/server stores bytes: p = 256)
             # lib/server's sparse bucket (SparseDb + update_item_raw; pruned expansion, present-items-only multiply, fold
             # shortcuts) against oracle/sparse_server.cpp, a random fraction of the items present
