@@ -8,6 +8,7 @@
 // a GPU most of the time and fails here every time.
 #include <hip/hip_runtime.h>
 
+#include <map>
 #include <set>
 
 void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds_bytes, const std::function<void()>& work_item);  // emu_runtime.cpp
@@ -165,8 +166,39 @@ void enqueue(hipStream_t st, std::function<void()> f) {
 bool pinned(const void* p) { return g_pinned.count(p) != 0; }
 }  // namespace
 
+// A budget of "device" memory (0 = none): with one set, hipMalloc fails with hipErrorOutOfMemory once the live device bytes would
+// exceed it and hipMemGetInfo reports what is left -- how the tests drive the library's out-of-memory paths (the batched call's
+// ladder), which no GPU run reaches on purpose.  Pinned host memory is not counted.
+namespace {
+size_t g_dev_budget = 0, g_dev_live = 0;
+std::map<void*, size_t> g_dev_sizes;
+}  // namespace
+extern "C" void emu_set_device_budget(size_t bytes) {
+  std::lock_guard<std::recursive_mutex> g(g_m);
+  g_dev_budget = bytes;
+}
+extern "C" size_t emu_device_live_bytes() {
+  std::lock_guard<std::recursive_mutex> g(g_m);
+  return g_dev_live;
+}
+hipError_t hipMemGetInfo(size_t* fr, size_t* tot) {
+  std::lock_guard<std::recursive_mutex> g(g_m);
+  if (g_dev_budget) {
+    *tot = g_dev_budget;
+    *fr = g_dev_budget > g_dev_live ? g_dev_budget - g_dev_live : 0;
+  } else {
+    *fr = (size_t)1 << 35;
+    *tot = (size_t)1 << 36;
+  }
+  return hipSuccess;
+}
+
 hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host) {
   void* q = nullptr;
+  if (!pinned_host) {
+    std::lock_guard<std::recursive_mutex> g(g_m);
+    if (g_dev_budget && g_dev_live + bytes > g_dev_budget) return hipErrorOutOfMemory;
+  }
   // + 16 bytes: the host compiler loads a three-dword vector (global_load_dwordx3 on the GPU: 12 bytes) as 16 bytes, so the
   // last lane of the last PACKED unit of a buffer touches one dword past its end
   if (posix_memalign(&q, 256, bytes + 16) != 0) return hipErrorOutOfMemory;
@@ -174,9 +206,14 @@ hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host) {
   // time instead of on the day the allocator returns a used page (SPIRAL_EMU_POISON=-1 leaves it as malloc returns it)
   static const int poison = std::getenv("SPIRAL_EMU_POISON") ? std::atoi(std::getenv("SPIRAL_EMU_POISON")) : 0xA5;
   if (poison >= 0) std::memset(q, poison & 0xff, bytes + 16);
-  if (pinned_host) {
+  {
     std::lock_guard<std::recursive_mutex> g(g_m);
-    g_pinned.insert(q);
+    if (pinned_host) {
+      g_pinned.insert(q);
+    } else {
+      g_dev_sizes[q] = bytes;
+      g_dev_live += bytes;
+    }
   }
   *p = q;
   return hipSuccess;
@@ -184,6 +221,11 @@ hipError_t emu_malloc(void** p, size_t bytes, bool pinned_host) {
 hipError_t hipFree(void* p) {
   std::lock_guard<std::recursive_mutex> g(g_m);
   if (mode() != 0) drain_all();
+  auto it = g_dev_sizes.find(p);
+  if (it != g_dev_sizes.end()) {
+    g_dev_live -= it->second;
+    g_dev_sizes.erase(it);
+  }
   std::free(p);
   return hipSuccess;
 }

@@ -222,7 +222,7 @@ inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) { *p = hipDeviceProp_t(); return hipSuccess; }
-inline hipError_t hipMemGetInfo(size_t* fr, size_t* tot) { *fr = (size_t)1 << 35; *tot = (size_t)1 << 36; return hipSuccess; }
+hipError_t hipMemGetInfo(size_t* fr, size_t* tot);   // emu_streams.cpp: 32 GiB free unless a device-memory budget is set (emu_set_device_budget)
 inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return hipSuccess; }
 enum hipDeviceAttribute_t { hipDeviceAttributeSharedMemPerBlockOptin = 97 };
 inline hipError_t hipDeviceGetAttribute(int* v, hipDeviceAttribute_t, int) { *v = 160 * 1024; return hipSuccess; }  // gfx950: 160 KiB of LDS per workgroup
