@@ -62,6 +62,7 @@ def main():
         assert got == want, "case A: responses differ"
         # ... until the copy is given back (2.5 workspaces' worth): then all eleven run as ONE group through the PACKED two-tile kernel
         assert "sweep_batch_mfma_two_tiles" in taken and "sweep_batch_planar" not in taken, taken
+        assert "expand_group" in taken, taken        # (the group's expansions ran as shared launches, run_begin_group)
         assert gdb.batch_copy_bytes() == 0
         L.emu_set_device_budget(0)
         assert gdb.prepare_batch() is True and gdb.batch_copy_bytes() == copy          # a later call may build it again

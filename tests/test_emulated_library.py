@@ -75,6 +75,7 @@ def test_parity_subset_on_the_emulated_device(emulated):
     assert _run(emulated, SUBSET, {"SPIRAL_EMU_STREAMS": "starve:1"}) >= 38
 
 
+@long_only
 def test_group_expansion_on_the_emulated_device(emulated):
     """r06: a batched group's expansions as shared launches (one more grid dimension = the query, per-query buffers behind byte
     offsets: run_begin_group) -- a list of eleven queries on a PACKED database against the oracle, with the streams in an
@@ -82,11 +83,13 @@ def test_group_expansion_on_the_emulated_device(emulated):
     assert _run(emulated, "test_process_query_batch and packed", {"SPIRAL_EMU_STREAMS": "random:11"}, at_least=1) >= 1
 
 
-@pytest.mark.parametrize("case", ["A", pytest.param("B", marks=long_only), "C"])
+@pytest.mark.parametrize("case", ["A", pytest.param("B", marks=long_only), pytest.param("C", marks=long_only)])
 def test_out_of_memory_ladder_of_the_batched_call(emulated, case):
     """sp_process_query_batch when device memory runs out inside a group (capi.cpp): the emulator's device-memory
     budget makes hipMalloc fail at a chosen point (tests/_emu_oom_ladder.py).  A: the digit-planar copy is given back and the list
-    runs through the PACKED two-tile kernel; B: groups of 8, one at a time; C: one query at a time.  Every response == oracle."""
+    runs through the PACKED two-tile kernel; B: groups of 8, one at a time; C: one query at a time.  Every response == oracle.
+    (Case A is also the default suite's run of a batched group's SHARED expansion launches -- eleven queries, path bit asserted;
+    B, C and the adversarial-stream-order run of the group expansion are in the SPIRAL_EMU_LONG set.)"""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_emu_oom_ladder.py"), case], cwd=ROOT,
                        env=dict(os.environ, SPIRAL_HIP_LIB=emulated), capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0 and "oom-ladder-ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
