@@ -260,24 +260,30 @@ __device__ __forceinline__ void folding_neg_body(const DevTables& T, const Foldi
   row[(size_t)col * 2 * N + e] = add_mod(g, cv ? q - cv : 0u, q);
 }
 
-// tile over (z, j) for a fixed r: bx -> j tile, by -> z tile, r; tile = 32 x 33 u64 of LDS
-__device__ __forceinline__ void reorient_body(const ReorientDesc& d, int bx, int by, int r, u64* tile) {
+// tile over (z, j), BOTH rows r: bx -> j tile, by -> z tile; tile = 2 x 32 x 33 u64 of LDS.  (r06: with one row per workgroup
+// every 16-byte (j, r = 0 | 1) pair of the output was written half by one workgroup and half by another -- 8 of every 16 bytes per
+// store instruction; with both rows a wave stores 512 contiguous bytes per z.)
+__device__ __forceinline__ void reorient_body(const ReorientDesc& d, int bx, int by, u64* tile) {
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   const int j0 = bx * 32, z0 = by * 32;
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int j = j0 + ty + 8 * i;
-    if (j < d.dim0) {
-      const u32* p = d.v + ((size_t)(d.first + d.step * j) * 2 + r) * 2 * N;
-      tile[(ty + 8 * i) * 33 + tx] = (u64)p[z0 + tx] | ((u64)p[N + z0 + tx] << 32);
-    }
-  }
-  __syncthreads();
+  for (int r = 0; r < 2; r++)
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
-    int z = z0 + ty + 8 * i;
-    int j = j0 + tx;
-    if (j < d.dim0) d.out[((size_t)z * d.dim0 + j) * 2 + r] = tile[tx * 33 + ty + 8 * i];
+    for (int i = 0; i < 4; i++) {
+      const int j = j0 + ty + 8 * i;
+      if (j < d.dim0) {
+        const u32* p = d.v + ((size_t)(d.first + d.step * j) * 2 + r) * 2 * N;
+        tile[r * (32 * 33) + (ty + 8 * i) * 33 + tx] = (u64)p[z0 + tx] | ((u64)p[N + z0 + tx] << 32);
+      }
+    }
+  __syncthreads();
+  const int w = threadIdx.x & 63, jl = w >> 1, r = w & 1, zr = threadIdx.x >> 6;  // 64 (j, r) pairs x 4 z per pass
+  if (j0 + jl < d.dim0) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int zl = zr + 4 * i;
+      d.out[((size_t)(z0 + zl) * d.dim0 + j0 + jl) * 2 + r] = tile[r * (32 * 33) + jl * 33 + zl];
+    }
   }
 }
 

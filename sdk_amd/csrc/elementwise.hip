@@ -273,27 +273,26 @@ void launch_encode(const EncodeDesc& d, hipStream_t s) {
 
 // out[z][j][r] = v[ct_j][r][0][z] | v[ct_j][r][1][z] << 32   (util.rs:343-350; residues already < q)
 __global__ __launch_bounds__(256) void k_reorient(ReorientDesc d) {
-  __shared__ u64 tile[32 * 33];
-  reorient_body(d, blockIdx.x, blockIdx.y, blockIdx.z, tile);
+  __shared__ u64 tile[2 * 32 * 33];
+  reorient_body(d, blockIdx.x, blockIdx.y, tile);
 }
 void launch_reorient(u64* out, const u32* v, int first, int step, int dim0, hipStream_t s) {
   const ReorientDesc d{out, v, first, step, dim0};
-  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32, 2), dim3(256), 0, s, d);
+  hipLaunchKernelGGL(k_reorient, dim3((dim0 + 31) / 32, N / 32), dim3(256), 0, s, d);
   launched(0, "k_reorient");
 }
 
-__global__ __launch_bounds__(256) void k_reorient_group(ReorientDesc d, GroupOff g, int tiles_x) {
-  __shared__ u64 tile[32 * 33];
-  const int qi = blockIdx.x / tiles_x;
+__global__ __launch_bounds__(256) void k_reorient_group(ReorientDesc d, GroupOff g) {
+  __shared__ u64 tile[2 * 32 * 33];
+  const int qi = blockIdx.z;
   d.out = group_rebase(d.out, g.raw[qi]);
   d.v = group_rebase(d.v, g.v[qi]);
-  reorient_body(d, blockIdx.x - qi * tiles_x, blockIdx.y, blockIdx.z, tile);
+  reorient_body(d, blockIdx.x, blockIdx.y, tile);
 }
 void launch_reorient_group(u64* out, const u32* v, int first, int step, int dim0, const GroupOff& g, int B, hipStream_t s) {
   if (B <= 0) return;
   const ReorientDesc d{out, v, first, step, dim0};
-  const int tiles_x = (dim0 + 31) / 32;
-  hipLaunchKernelGGL(k_reorient_group, dim3(tiles_x * B, N / 32, 2), dim3(256), 0, s, d, g, tiles_x);
+  hipLaunchKernelGGL(k_reorient_group, dim3((dim0 + 31) / 32, N / 32, B), dim3(256), 0, s, d, g);
   launched(PATH_EXPAND_GROUP, "k_reorient_group");
 }
 

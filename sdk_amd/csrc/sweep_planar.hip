@@ -25,7 +25,7 @@ void launch_query_tables_planar2(const DevTables& T, const u64* const* qv, int b
   q.j0 = j0;
   q.nj = nj;
   const size_t entries = (size_t)N * (nj >> 4) * 128;   // 16-byte entries of one tile's table (== N * blocks * 8 * 64)
-  hipLaunchKernelGGL(k_query_digits_planar2, dim3((unsigned)((entries + 255) / 256), 2), dim3(256), 0, s, q);
+  hipLaunchKernelGGL(k_query_digits_planar2, dim3((unsigned)((entries / 8 + 255) / 256), 2), dim3(256), 0, s, q);   // a thread per 8 entries
   launched(0, "k_query_digits_planar2");
   hipLaunchKernelGGL(k_query_offset_terms2, dim3(N, 2), dim3(256), 0, s, T, q, rq + (size_t)2 * entries * 4);
   launched(0, "k_query_offset_terms2");

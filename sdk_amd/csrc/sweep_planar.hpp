@@ -82,28 +82,53 @@ struct QueryDigits2Desc {
   u32* rq;                          // [tile][...] tables, then the offset terms [tile][N][32]
   int batch, dim0, j0, nj;
 };
+// One thread per (z, 64-row block, lane = 16 kb + m) writes that lane's entry of ALL EIGHT operands (modulus c, digit b): the 16
+// query words it needs are read once instead of once per operand, as eight 16-byte loads per lane PAIR (m even / odd = the two
+// rows r of one query share every 16-byte (row j, r = 0 | 1) pair of the reoriented query: the even lane fetches rows 0..7, the odd
+// one rows 8..15, and they swap halves) -- the first form read 8 bytes of every 16, sixteen times per thread, for each of the
+// eight operands: 280 us for the two tables of a 16-query group.
 static __global__ __launch_bounds__(256) void k_query_digits_planar2(QueryDigits2Desc d) {
   const int blocks = d.nj >> 6;
-  const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;   // one 16-byte entry per thread
-  const size_t entries = (size_t)N * blocks * 8 * 64;
-  if (idx >= entries) return;
+  const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (size_t)N * blocks * 64) return;      // (whole waves: 64 lanes per (z, block))
   const int tile = blockIdx.y;
-  const int lane = (int)(idx & 63), b = (int)((idx >> 6) & 3), c = (int)((idx >> 8) & 1);
-  const size_t zb = idx >> 9;
+  const int lane = (int)(t & 63);
+  const size_t zb = t >> 6;
   const int block = (int)(zb % blocks), z = (int)(zb / blocks);
   const int m = lane & 15, kb = lane >> 4, qb = 8 * tile + (m >> 1), r = m & 1;
-  mf_u32x4_t o = {0u, 0u, 0u, 0u};
-  if (qb < d.batch) {
-    const u64* q = d.qv[qb] + ((size_t)z * d.dim0 + d.j0 + 64 * block + 16 * kb) * 2 + r;
+  const size_t entries = (size_t)N * blocks * 8 * 64;
+  mf_u32x4_t* out = reinterpret_cast<mf_u32x4_t*>(d.rq) + (size_t)tile * entries + zb * 512 + lane;   // + (c * 4 + b) * 64
+  const bool active = qb < d.batch;      // (query columns past the batch: zero entries; every lane still takes part in the swaps)
+  u64 w[16];
+  {
+    // rows 16 kb .. 16 kb + 15 of query qb at z, both r: 16 x 16 bytes; this lane fetches 8 of them (r = 0: the first 8 rows)
+    const ulonglong2* q2 = reinterpret_cast<const ulonglong2*>(d.qv[active ? qb : 0] + ((size_t)z * d.dim0 + d.j0 + 64 * block + 16 * kb) * 2) + 8 * r;
+    ulonglong2 mine[8];
 #pragma unroll
-    for (int t = 0; t < 16; t++) {
-      const u64 w = q[2 * t];
-      const u32 x = c ? (u32)(w >> 32) : (u32)w;
-      const u32 dg = (signed_digits(x) >> (8 * b)) & 0xffu;
-      o[t >> 2] |= dg << (8 * (t & 3));
+    for (int i = 0; i < 8; i++) mine[i] = active ? q2[i] : ulonglong2{0ull, 0ull};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      // what the partner needs of my rows is its r's half; what I need of the partner's rows is my r's half
+      const u64 give = r == 0 ? mine[i].y : mine[i].x;
+      const u64 got = __shfl_xor(give, 1, 64);
+      const u64 keep = r == 0 ? mine[i].x : mine[i].y;
+      w[(r == 0 ? 0 : 8) + i] = keep;     // my own rows
+      w[(r == 0 ? 8 : 0) + i] = got;      // the partner's rows, my r
     }
   }
-  reinterpret_cast<mf_u32x4_t*>(d.rq)[(size_t)tile * entries + idx] = o;
+#pragma unroll
+  for (int c = 0; c < 2; c++) {
+    u32 sd[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) sd[i] = active ? signed_digits(c ? (u32)(w[i] >> 32) : (u32)w[i]) : 0u;
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+      mf_u32x4_t o = {0u, 0u, 0u, 0u};
+#pragma unroll
+      for (int i = 0; i < 16; i++) o[i >> 2] |= ((sd[i] >> (8 * b)) & 0xffu) << (8 * (i & 3));
+      out[(size_t)(c * 4 + b) * 64] = o;
+    }
+  }
 }
 // (k_query_offset_terms of sweep_mfma.hpp with the tile as grid.y)
 static __global__ __launch_bounds__(256) void k_query_offset_terms2(DevTables T, QueryDigits2Desc d, u32* off) {
