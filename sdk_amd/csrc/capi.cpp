@@ -234,7 +234,7 @@ const char* sp_path_name(int bit) {
                                 "rccl_in_library", "fold_wave", "cu_split_overlap", "expand_split", "pipe_class_split",
                                 "sweep_batch_mfma", "custom_transport", "from_sweep_wave",
                                 "fold_tail_batched", "sweep_ring", "sweep_batch_mfma_two_tiles", "fold_wave8", "sweep_batch_planar",
-                                "expand_group"};
+                                "expand_group", "expand_wave"};
   return bit >= 0 && bit < (int)(sizeof(names) / sizeof(names[0])) ? names[bit] : nullptr;
 }
 
@@ -686,6 +686,13 @@ sp_pp_t* sp_pp_deserialize(const sp_params_t* h, const uint8_t* data, size_t len
       for (size_t r = 0; r < n; r++)  // (copy kernel, not a copy-engine transfer: see upload_words)
         launch_copy_words(pp->pack_cat.p + (rr * n * tc + r * tc) * 2 * POLY_LEN,
                           pp->all.p + (pp->off_packing + r * (n + 1) * tc + rr * tc) * 2 * POLY_LEN, tc * 2 * POLY_LEN, 0);
+    if (p.expand_queries) {   // wave-layout copy + the constants 0 | 1 (k_expand_wave)
+      pp->all_w.alloc((off + 1) * 2 * POLY_LEN);
+      launch_mats_to_wave(pp->all_w.p, pp->all.p, off * 2 * POLY_LEN, 0);
+      std::vector<u32> zero_one(2 * POLY_LEN, 0u);
+      for (size_t i = POLY_LEN; i < 2 * POLY_LEN; i++) zero_one[i] = 1u;
+      h2d_sync(pp->all_w.p + off * 2 * POLY_LEN, zero_one.data(), zero_one.size() * sizeof(u32));
+    }
     HIP_CHECK(hipDeviceSynchronize());
     out = pp.release();
   });

@@ -543,6 +543,123 @@ _Pragma("unroll") for (int g = 0; g < 8; g++) {                                 
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One expansion round's MANY-DIGIT side on the wave-per-transform NTT (r06): k_expand_round's work for the ciphertexts of ONE side,
+// in the shape of k_fold_wave -- a workgroup per (ciphertext, modulus, query), the t digit polynomials of the ciphertext's first row
+// dealt to four waves (digit dg -> wave dg % 4), each transformed without a workgroup barrier and multiply-accumulated into the
+// wave's private 64-bit sums of both output rows (FoldMac: the side's expansion key in WAVE layout, ExpandWaveDesc::A_w), the four
+// partial sums combined through LDS, + the addend, stored.  The transform of the ciphertext's second row rides along as one more
+// "digit" whose operands are the constant polynomials 0 (row 0) and 1 (row 1) (ExpandWaveDesc::const_w).
+// Why: k_expand_round runs at its cooperative transform core's rate (3.75 ns per transform at two workgroups per CU,
+// profiles/r01_ntt_core.md); the wave transform runs at 2.0 -- but only fused with its consumer (profiles/r05_fwd_wave.md).  A
+// right-hand ciphertext has 56 one-bit digits: 14 per wave, the table staging and the reduction paid once per 57 transforms.
+// Sums: at most 15 terms of < 12 q x q < 2^59.6 per wave -- below 2^64.
+// LDS: [4 transpose buffers 18 KiB | forward tables 16 KiB | the ciphertext's first row, raw, 16 KiB].  grid (cnt, 2 moduli, queries).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 2) void k_expand_wave(DevTables T, ExpandWaveDesc d, GroupOff g) {
+  extern __shared__ __attribute__((aligned(16))) u32 smem_fw[];
+  u32* wbuf = smem_fw;
+  u32* ltw = smem_fw + 4 * WBUF_WORDS;
+  u64* raw0 = reinterpret_cast<u64*>(ltw + 2 * N);
+  const int tau = threadIdx.x, lane = tau & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);
+  const int b = (int)blockIdx.x, c = (int)blockIdx.y, qi = (int)blockIdx.z;
+  const ModConst m = T.c.mod[c];
+  const u32* fw = T.tw + (size_t)c * 4 * N;
+  const u64* src = group_rebase(d.raw, g.raw[qi]) + (size_t)d.pos[b] * 2 * N;
+  const u32* A_w = group_rebase(d.A_w, g.pp[qi]);
+  u32* vout = group_rebase(d.v, g.v[qi]);
+  u32* mybuf = wbuf + wv * WBUF_WORDS;
+  wtw_stage(ltw, wave_fwd_image(T.tw, c), tau);
+#pragma unroll
+  for (int k = 0; k < 8; k++) raw0[tau + 256 * k] = src[tau + 256 * k];
+  __syncthreads();
+  const u64 mask = (1ULL << d.bits) - 1ULL;
+  u64 acc0[32], acc1[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) acc0[k] = acc1[k] = 0;
+  // "digit" d.t is the ciphertext's second row (poly.rs:613-623: reduced mod q first), multiplied by (0, 1)
+#pragma unroll 1
+  for (int dg = wv; dg <= d.t; dg += 4) {
+    int ln = lane;
+    const u32* fwi = fw;
+    asm volatile("" : "+v"(ln));     // (as in k_fold_wave: keeps the loop's addresses and scalar twiddles from being hoisted and spilled)
+    asm volatile("" : "+s"(fwi));
+    WaveScalarTw stw;
+    wntt_scalar_tw(stw, fwi);
+    u32 v[32];
+    if (dg < d.t) {
+      const int sh = dg * d.bits;
+#pragma unroll
+      for (int k = 0; k < 32; k++) v[k] = sh < 64 ? (u32)((raw0[64 * k + ln] >> (sh & 63)) & mask) : 0u;   // gadget.rs:48-53
+    } else {
+#pragma unroll
+      for (int k = 0; k < 32; k++) v[k] = reduce64(src[(size_t)N + 64 * k + ln], m);
+    }
+    SP_SB();
+    const u32* a0 = dg < d.t ? A_w + ((size_t)dg * 2 + c) * N : d.const_w;
+    const u32* a1 = dg < d.t ? A_w + ((size_t)(d.t + dg) * 2 + c) * N : d.const_w + N;
+    FoldMac hk{acc0, acc1, reinterpret_cast<const u32x4w_t*>(a0) + ln, reinterpret_cast<const u32x4w_t*>(a1) + ln};
+    wntt_fwd<false>(v, ln, mybuf, fwi, stw, ltw, m.q, m.two_q, hk);
+  }
+  // the four waves' partial sums -> wave 0 (row 0) and wave 1 (row 1), as in k_fold_wave
+  int lt = lane;
+  asm volatile("" : "+v"(lt));
+  u32 r0[32], r1[32];
+#pragma unroll
+  for (int k = 0; k < 32; k++) {
+    r0[k] = reduce64(acc0[k], m);
+    r1[k] = reduce64(acc1[k], m);
+  }
+  u32x4w_t* sc = reinterpret_cast<u32x4w_t*>(smem_fw);
+#define SP_PUT(R, REGION)                                                                              \
+_Pragma("unroll") for (int g4 = 0; g4 < 8; g4++) {                                                   \
+  u32x4w_t t4;                                                                                       \
+  t4.x = R[4 * g4]; t4.y = R[4 * g4 + 1]; t4.z = R[4 * g4 + 2]; t4.w = R[4 * g4 + 3];                \
+  sc[(REGION) * 512 + g4 * 64 + lt] = t4;                                                            \
+}
+#define SP_ADD(R, REGION)                                                                              \
+_Pragma("unroll") for (int g4 = 0; g4 < 8; g4++) {                                                   \
+  const u32x4w_t t4 = sc[(REGION) * 512 + g4 * 64 + lt];                                             \
+  R[4 * g4] = add_mod(R[4 * g4], t4.x, m.q); R[4 * g4 + 1] = add_mod(R[4 * g4 + 1], t4.y, m.q);      \
+  R[4 * g4 + 2] = add_mod(R[4 * g4 + 2], t4.z, m.q); R[4 * g4 + 3] = add_mod(R[4 * g4 + 3], t4.w, m.q); \
+}
+  __syncthreads();  // every wave is done with its transpose buffer, the tables and the raw row
+  if (wv == 2) { SP_PUT(r0, 0) SP_PUT(r1, 1) }
+  if (wv == 3) { SP_PUT(r0, 2) SP_PUT(r1, 3) }
+  __syncthreads();
+  if (wv == 0) { SP_ADD(r0, 0) SP_ADD(r0, 2) }
+  if (wv == 1) { SP_ADD(r1, 1) SP_ADD(r1, 3) }
+  __syncthreads();
+  if (wv == 0) { SP_PUT(r1, 0) }
+  if (wv == 1) { SP_PUT(r0, 1) }
+  __syncthreads();
+  if (wv == 0) { SP_ADD(r0, 1) }
+  if (wv == 1) { SP_ADD(r1, 0) }
+#undef SP_PUT
+#undef SP_ADD
+  // register k of lane L is NTT-domain coefficient 32 L + k (wave_layout_word): the natural layout, 128 contiguous bytes per lane
+  if (wv < 2) {
+    u32* o = vout + ((size_t)d.out_idx[b] * 2 + c) * N + (size_t)wv * 2 * N + 32 * lt;   // row wv of the output ciphertext
+#pragma unroll
+    for (int g4 = 0; g4 < 8; g4++) {
+      const uint4 a = reinterpret_cast<const uint4*>(o)[g4];
+      uint4 w;
+      w.x = add_mod(wv == 0 ? r0[4 * g4] : r1[4 * g4], a.x, m.q);
+      w.y = add_mod(wv == 0 ? r0[4 * g4 + 1] : r1[4 * g4 + 1], a.y, m.q);
+      w.z = add_mod(wv == 0 ? r0[4 * g4 + 2] : r1[4 * g4 + 2], a.z, m.q);
+      w.w = add_mod(wv == 0 ? r0[4 * g4 + 3] : r1[4 * g4 + 3], a.w, m.q);
+      reinterpret_cast<uint4*>(o)[g4] = w;
+    }
+  }
+}
+void launch_expand_wave(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s) {
+  if (d.cnt <= 0 || B <= 0) return;
+  const size_t lds = (size_t)(4 * WBUF_WORDS + 2 * N) * 4 + (size_t)N * 8;
+  hipLaunchKernelGGL(k_expand_wave, dim3(d.cnt, 2, B), dim3(256), lds, s, T, d, g);
+  launched(PATH_EXPAND_FUSED | PATH_EXPAND_WAVE, "k_expand_wave");
+}
+
 // fold_mats (NTT polynomials [crt][z]) -> wave layout, same polynomial order: one thread per word
 __global__ __launch_bounds__(256) void k_mats_to_wave(MatsToWaveDesc d) { mats_to_wave_body(d, blockIdx.x); }
 void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s) {

@@ -77,7 +77,8 @@ enum PathBit : u64 {
   PATH_SWEEP_MFMA2 = 1ull << 29,      // k_sweep_mfma_batch with two query tiles (9 .. 16 queries per database pass)
   PATH_FOLD_WAVE8 = 1ull << 30,       // (retired in the round that built it: k_fold_wave8, profiles/r05_fold_wave8.md)
   PATH_SWEEP_PLANAR = 1ull << 31,     // k_sweep_planar: the 9 .. 16-query pass over the digit-planar copy of the database
-  PATH_EXPAND_GROUP = 1ull << 32      // a group's expansions with every round's launches shared (grid dimension = query; r06)
+  PATH_EXPAND_GROUP = 1ull << 32,     // a group's expansions with every round's launches shared (grid dimension = query; r06)
+  PATH_EXPAND_WAVE = 1ull << 33       // k_expand_wave: a round's many-digit side on the wave-per-transform NTT (r06)
 };
 // Run-time tunables (sp_debug_set / environment SPIRAL_<NAME>): read on every launch, so that variants can be A/B
 // measured inside one process on ONE database allocation (HBM placement alone moves the sweep by +-5 %).
@@ -224,6 +225,20 @@ void launch_copy_polys_group(u32* dst, const int* dst_idx, int dst_row_stride, c
 void launch_folding_neg_group(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, const GroupOff& g, int B,
                               hipStream_t s);                                                                                       // mats: v
 void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, const GroupOff& g, int B, hipStream_t s);                  // dst: raw; src: v
+// ... and the many-digit (right-hand) side of a large round on the wave-per-transform NTT (fold.hip, k_expand_wave): ciphertexts
+// pos[0 .. cnt) of `raw`, t digits of `bits` bits, expansion key of the round in WAVE layout (A_w: the polynomials of
+// ExpandSideDesc::A through k_mats_to_wave), const_w: the constant polynomials 0 and 1 (N words each)
+struct ExpandWaveDesc {
+  const u64* raw;
+  const int* pos;
+  const int* out_idx;
+  const u32* A_w;
+  const u32* const_w;
+  u32* v;
+  int cnt, t, bits;
+};
+void launch_expand_wave(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s);   // raw: raw; A_w: pp; v: v
+constexpr long EXPAND_WAVE_MIN_DIGITS_DEFAULT = 16;     // sides with at least this many digits per ciphertext take the wave kernel
 constexpr long EXPAND_GROUP_ROUND_MIN_DEFAULT = 4096;   // digit transforms per modulus of the WHOLE group from which a round is one launch
 
 // ---- fused fold step (server.rs:407-424) ----------------------------------------------------

@@ -854,13 +854,38 @@ void run_group_expansion(Workspace* const* Ws, const sp_pp* const* pps, int B, s
       throw ArgError("a group's public parameters must have one layout");
   }
   const long group_min = tunable("expand_group_round_min", EXPAND_GROUP_ROUND_MIN_DEFAULT);
+  const long wave_min_digits = tunable("expand_wave_min_digits", EXPAND_WAVE_MIN_DIGITS_DEFAULT);   // 0: never
+  bool wave_ok = wave_min_digits > 0;
+  GroupOff gw = g;   // k_expand_wave reads the public parameters' WAVE-layout copies
+  for (int i = 0; i < B; i++) {
+    wave_ok = wave_ok && pps[i]->all_w.p != nullptr && pps[i]->all_w.n == pps[0]->all_w.n;
+    if (wave_ok) gw.pp[i] = off(pps[i]->all_w.p, pps[0]->all_w.p);
+  }
   for (size_t r = 0; r < g_rounds; r++) {
     const RoundPlan& rp = D.rounds[r];
     if (rp.n_all == 0 && rp.n_skip2 == 0) continue;
     const RoundLaunches R = round_launches(W0, *pps[0], rp, r, L, 0);
     launch_ntt_inv_group(D.T, R.inv, g, B, s);
     if (R.round_transforms * B >= group_min && R.digits_fit) {
-      launch_expand_round_group(D.T, R.es[0], R.es[1], g, B, s);
+      // a side with many digits per ciphertext (the right-hand side's 56 one-bit digits) on the wave-per-transform engine, the
+      // other side on the cooperative kernel (a left-hand ciphertext's 9 transforms would be overhead-bound in the wave shape)
+      ExpandSideDesc coop[2] = {R.es[0], R.es[1]};
+      for (int side = 1; side >= 0; side--)
+        if (wave_ok && coop[side].cnt > 0 && coop[side].t >= wave_min_digits && coop[side].t <= 56) {
+          ExpandWaveDesc w{};
+          w.raw = coop[side].raw;
+          w.pos = coop[side].pos;
+          w.out_idx = coop[side].out_idx;
+          w.A_w = pps[0]->all_w.p + (coop[side].A - pps[0]->all.p);   // the same polynomials, wave layout
+          w.const_w = pps[0]->all_w.p + pps[0]->all.n;                  // (0 | 1 live behind the copy, at the same offset in every pp)
+          w.v = coop[side].v;
+          w.cnt = coop[side].cnt;
+          w.t = coop[side].t;
+          w.bits = coop[side].bits;
+          launch_expand_wave(D.T, w, gw, B, s);
+          coop[side].cnt = 0;
+        }
+      launch_expand_round_group(D.T, coop[0], coop[1], g, B, s);
     } else {
       launch_ntt_fwd3_group(D.T, R.fd[0], R.fd[1], R.fd[2], g, B, s);
       launch_mac2_group(D.T, R.md[0], R.md[1], g, B, s);

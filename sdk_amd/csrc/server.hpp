@@ -191,6 +191,9 @@ struct sp_pp {
   size_t off_packing = 0, off_left = 0, off_right = 0, off_conv = 0;  // poly offsets
   bool has_right = false;
   spiral::DevBuf<spiral::u32> pack_cat;  // [(n+1)][n*t_conv] = [W_0 | W_1 | ...]
+  // r06: `all` once more in WAVE layout (k_mats_to_wave, same polynomial order) for k_expand_wave, followed by one more slot that
+  // holds the constant polynomials 0 and 1 (N words each); empty when the parameters have no query expansion
+  spiral::DevBuf<spiral::u32> all_w;
 };
 
 struct sp_db {

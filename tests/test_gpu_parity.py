@@ -1104,7 +1104,11 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
     # per-query offsets); one query at a time on sixteen streams -- the r02-r05 form -- must give the same bytes, and so must
     # both extremes of the shared rounds' dispatch (every round as three launches / every round as k_expand_round)
     assert "expand_group" in taken, taken
-    for switch, value in ((b"expand_group", 0), (b"expand_group_round_min", 1 << 40), (b"expand_group_round_min", 1)):
+    # ... and the right-hand side of the large rounds (56 one-bit digits per ciphertext) on the wave-per-transform engine
+    # (k_expand_wave: the expansion key in wave layout, the second row's transform as a 57th "digit" times the constants 0 | 1)
+    assert "expand_wave" in taken, taken
+    for switch, value in ((b"expand_group", 0), (b"expand_group_round_min", 1 << 40), (b"expand_group_round_min", 1), (b"expand_wave_min_digits", 0),
+                          (b"expand_wave_min_digits", 1)):
         sp.lib().sp_debug_set(switch, C.c_long(value))
         try:
             sp.paths_taken()
@@ -1113,8 +1117,10 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
             assert ("expand_group" in taken) == (switch != b"expand_group"), (switch, taken)
             if switch == b"expand_group_round_min":
                 assert ("expand_round_one_launch" in taken) == (value == 1), (value, taken)
+            if switch == b"expand_wave_min_digits":      # 0: never; 1: the 8-digit left-hand side too
+                assert ("expand_wave" in taken) == (value == 1), (value, taken)
         finally:
-            sp.lib().sp_debug_set(switch, C.c_long(1 if switch == b"expand_group" else 4096))
+            sp.lib().sp_debug_set(switch, C.c_long({b"expand_group": 1, b"expand_group_round_min": 4096, b"expand_wave_min_digits": 16}[switch]))
     sp.lib().sp_debug_set(b"batch_mfma", C.c_long(0))
     try:
         sp.paths_taken()
