@@ -24,7 +24,7 @@ def cls(n):
         return 'fold'
     if n.startswith('k_from'):
         return 'from_ntt'
-    if n.startswith(('k_expand', 'k_ntt_inv_group', 'k_ntt_fwd3', 'k_mac2')):
+    if n.startswith(("k_expand", "k_ntt_inv_group", "k_ntt_fwd3", "k_mac2")):
         return 'expand_rounds'
     if n.startswith(('k_ntt_', 'k_mac', 'k_reorient', 'k_copy_polys', 'k_folding_neg', 'k_mats_to_wave', 'k_add_poly', 'k_query_')):
         return 'expand_tail+pack'
