@@ -653,85 +653,11 @@ _Pragma("unroll") for (int g4 = 0; g4 < 8; g4++) {                              
     }
   }
 }
-// The same work with ONE WAVE per (ciphertext, modulus) unit -- four units of one modulus per workgroup, sharing its table image:
-// a wave transforms all t + 1 "digits" of its ciphertext in sequence and owns both output rows' sums, so there is no raw row in
-// LDS (the digits are cut from the raw words as they are read: 32 eight-byte loads per lane and digit, L1 / L2 hits), no
-// cross-wave reduction and no barrier after the staging one; the 64-bit sums are Barrett-folded every 14 terms (14 x 12 q x q
-// < 2^64).  For sides with FEW digits per ciphertext (the left-hand side's 8), where k_expand_wave's per-workgroup costs -- staging,
-// reduction, two of four waves short of work -- are not amortised.  LDS: transpose buffers + tables = 34 KiB.
-// grid (ceil(cnt / 4), 2 moduli, queries).
-__global__ __launch_bounds__(256, 2) void k_expand_unit(DevTables T, ExpandWaveDesc d, GroupOff g) {
-  extern __shared__ __attribute__((aligned(16))) u32 smem_fw[];
-  u32* ltw = smem_fw + 4 * WBUF_WORDS;
-  const int tau = threadIdx.x, lane = tau & 63;
-  const int wv = __builtin_amdgcn_readfirstlane(tau >> 6);
-  const int b = (int)blockIdx.x * 4 + wv, c = (int)blockIdx.y, qi = (int)blockIdx.z;
-  const ModConst m = T.c.mod[c];
-  const u32* fw = T.tw + (size_t)c * 4 * N;
-  wtw_stage(ltw, wave_fwd_image(T.tw, c), tau);
-  __syncthreads();
-  if (b >= d.cnt) return;   // (no barrier follows)
-  const u64* src = group_rebase(d.raw, g.raw[qi]) + (size_t)d.pos[b] * 2 * N;
-  const u32* A_w = group_rebase(d.A_w, g.pp[qi]);
-  u32* vout = group_rebase(d.v, g.v[qi]);
-  u32* mybuf = smem_fw + wv * WBUF_WORDS;
-  const u64 mask = (1ULL << d.bits) - 1ULL;
-  u64 acc0[32], acc1[32];
-#pragma unroll
-  for (int k = 0; k < 32; k++) acc0[k] = acc1[k] = 0;
-#pragma unroll 1
-  for (int dg = 0; dg <= d.t; dg++) {
-    int ln = lane;
-    const u32* fwi = fw;
-    asm volatile("" : "+v"(ln));
-    asm volatile("" : "+s"(fwi));
-    WaveScalarTw stw;
-    wntt_scalar_tw(stw, fwi);
-    u32 v[32];
-    if (dg < d.t) {
-      const int sh = dg * d.bits;
-#pragma unroll
-      for (int k = 0; k < 32; k++) v[k] = sh < 64 ? (u32)((src[64 * k + ln] >> (sh & 63)) & mask) : 0u;   // gadget.rs:48-53
-    } else {
-#pragma unroll
-      for (int k = 0; k < 32; k++) v[k] = reduce64(src[(size_t)N + 64 * k + ln], m);
-    }
-    SP_SB();
-    const u32* a0 = dg < d.t ? A_w + ((size_t)dg * 2 + c) * N : d.const_w;
-    const u32* a1 = dg < d.t ? A_w + ((size_t)(d.t + dg) * 2 + c) * N : d.const_w + N;
-    FoldMac hk{acc0, acc1, reinterpret_cast<const u32x4w_t*>(a0) + ln, reinterpret_cast<const u32x4w_t*>(a1) + ln};
-    wntt_fwd<false>(v, ln, mybuf, fwi, stw, ltw, m.q, m.two_q, hk);
-    if ((dg % 14) == 13) {
-#pragma unroll
-      for (int k = 0; k < 32; k++) {
-        acc0[k] = reduce64(acc0[k], m);
-        acc1[k] = reduce64(acc1[k], m);
-      }
-    }
-  }
-  int lt = lane;
-  asm volatile("" : "+v"(lt));
-#pragma unroll
-  for (int row = 0; row < 2; row++) {
-    u32* o = vout + ((size_t)d.out_idx[b] * 2 + c) * N + (size_t)row * 2 * N + 32 * lt;
-#pragma unroll
-    for (int g4 = 0; g4 < 8; g4++) {
-      const uint4 a = reinterpret_cast<const uint4*>(o)[g4];
-      uint4 w;
-      w.x = add_mod(reduce64(row ? acc1[4 * g4] : acc0[4 * g4], m), a.x, m.q);
-      w.y = add_mod(reduce64(row ? acc1[4 * g4 + 1] : acc0[4 * g4 + 1], m), a.y, m.q);
-      w.z = add_mod(reduce64(row ? acc1[4 * g4 + 2] : acc0[4 * g4 + 2], m), a.z, m.q);
-      w.w = add_mod(reduce64(row ? acc1[4 * g4 + 3] : acc0[4 * g4 + 3], m), a.w, m.q);
-      reinterpret_cast<uint4*>(o)[g4] = w;
-    }
-  }
-}
-void launch_expand_unit(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s) {
-  if (d.cnt <= 0 || B <= 0) return;
-  const size_t lds = (size_t)(4 * WBUF_WORDS + 2 * N) * 4;
-  hipLaunchKernelGGL(k_expand_unit, dim3((d.cnt + 3) / 4, 2, B), dim3(256), lds, s, T, d, g);
-  launched(PATH_EXPAND_FUSED | PATH_EXPAND_WAVE, "k_expand_unit");
-}
+// (r06, measured and removed: the same work with ONE WAVE per (ciphertext, modulus) unit, four units per workgroup, digits cut from
+// the raw words as they are read from global memory, no cross-wave reduction -- meant for the 8-digit left-hand side.  6.8 ns per
+// transform against the cooperative kernel's 4.4 on the two left-hand-only rounds, 965 against 718 us on round 7's right-hand side:
+// every digit waits for 32 dependent-free but un-hidden loads with two waves per SIMD.  profiles/r06_group_expansion.md,
+// scripts/archive/r06_expand_unit/.)
 void launch_expand_wave(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s) {
   if (d.cnt <= 0 || B <= 0) return;
   const size_t lds = (size_t)(4 * WBUF_WORDS + 2 * N) * 4 + (size_t)N * 8;

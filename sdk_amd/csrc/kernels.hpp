@@ -238,7 +238,6 @@ struct ExpandWaveDesc {
   int cnt, t, bits;
 };
 void launch_expand_wave(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s);   // raw: raw; A_w: pp; v: v
-void launch_expand_unit(const DevTables& T, const ExpandWaveDesc& d, const GroupOff& g, int B, hipStream_t s);   // one wave per (ciphertext, modulus)
 constexpr long EXPAND_WAVE_MIN_DIGITS_DEFAULT = 16;     // sides with at least this many digits per ciphertext take the wave kernel
 constexpr long EXPAND_GROUP_ROUND_MIN_DEFAULT = 4096;   // digit transforms per modulus of the WHOLE group from which a round is one launch
 

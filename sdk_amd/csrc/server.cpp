@@ -870,9 +870,8 @@ void run_group_expansion(Workspace* const* Ws, const sp_pp* const* pps, int B, s
       // a side with many digits per ciphertext (the right-hand side's 56 one-bit digits) on the wave-per-transform engine, the
       // other side on the cooperative kernel (a left-hand ciphertext's 9 transforms would be overhead-bound in the wave shape)
       ExpandSideDesc coop[2] = {R.es[0], R.es[1]};
-      const long unit_mode = tunable("expand_unit", 0);   // (experiment) 1: sides below the wave threshold, 2: every side, one wave per unit
       for (int side = 1; side >= 0; side--)
-        if (wave_ok && coop[side].cnt > 0 && coop[side].t <= 56 && (coop[side].t >= wave_min_digits || unit_mode > 0)) {
+        if (wave_ok && coop[side].cnt > 0 && coop[side].t >= wave_min_digits && coop[side].t <= 56) {
           ExpandWaveDesc w{};
           w.raw = coop[side].raw;
           w.pos = coop[side].pos;
@@ -883,10 +882,7 @@ void run_group_expansion(Workspace* const* Ws, const sp_pp* const* pps, int B, s
           w.cnt = coop[side].cnt;
           w.t = coop[side].t;
           w.bits = coop[side].bits;
-          if (unit_mode == 2 || (unit_mode == 1 && coop[side].t < wave_min_digits))
-            launch_expand_unit(D.T, w, gw, B, s);
-          else
-            launch_expand_wave(D.T, w, gw, B, s);
+          launch_expand_wave(D.T, w, gw, B, s);
           coop[side].cnt = 0;
         }
       launch_expand_round_group(D.T, coop[0], coop[1], g, B, s);

@@ -13,7 +13,6 @@ pytestmark = pytest.mark.gpu
 
 Q0, Q1 = 268369921, 249561089
 Q = Q0 * Q1
-EXPAND_UNIT_DEFAULT = 0     # (server.cpp `expand_unit`: which sides of a grouped expansion round run one wave per ciphertext)
 
 
 @pytest.fixture(scope="module")
@@ -1109,7 +1108,7 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
     # (k_expand_wave: the expansion key in wave layout, the second row's transform as a 57th "digit" times the constants 0 | 1)
     assert "expand_wave" in taken, taken
     for switch, value in ((b"expand_group", 0), (b"expand_group_round_min", 1 << 40), (b"expand_group_round_min", 1), (b"expand_wave_min_digits", 0),
-                          (b"expand_wave_min_digits", 1), (b"expand_unit", 1), (b"expand_unit", 2)):
+                          (b"expand_wave_min_digits", 1)):
         sp.lib().sp_debug_set(switch, C.c_long(value))
         try:
             sp.paths_taken()
@@ -1121,8 +1120,7 @@ def test_process_query_batch_matrix_core_sweep(sp, oracle_mod, nu_1, nu_2, B, ch
             if switch == b"expand_wave_min_digits":      # 0: never; 1: the 8-digit left-hand side too
                 assert ("expand_wave" in taken) == (value == 1), (value, taken)
         finally:
-            sp.lib().sp_debug_set(switch, C.c_long({b"expand_group": 1, b"expand_group_round_min": 4096, b"expand_wave_min_digits": 16,
-                                                    b"expand_unit": EXPAND_UNIT_DEFAULT}[switch]))
+            sp.lib().sp_debug_set(switch, C.c_long({b"expand_group": 1, b"expand_group_round_min": 4096, b"expand_wave_min_digits": 16}[switch]))
     sp.lib().sp_debug_set(b"batch_mfma", C.c_long(0))
     try:
         sp.paths_taken()
