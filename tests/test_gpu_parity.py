@@ -428,6 +428,47 @@ def test_query_list_in_flight_errors_and_threads(sp, oracle_mod):
     assert got[0] == exp and got[1] == exp[1:] + exp[:1]
 
 
+def test_grouped_lists_errors_and_threads(sp, oracle_mod):
+    """Lists on a PACKED database run as groups with shared expansion launches (r06, run_begin_group): a malformed query in the
+    middle of a group fails the call before anything of the group is enqueued and leaves its workspaces usable (the next list
+    is answered correctly); two host threads submit lists of 9 (two query tiles, planar copy) and 6 against one database at the
+    same time, three times each."""
+    import threading
+    cfg = {"n": 2, "nu_1": 6, "nu_2": 7, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8, "t_exp_right": 56,
+           "instances": 1, "db_item_size": 256}
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(14)
+    item, db = o.generate_random_db_and_get_item(9)
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    gdb = sp.Database(p).load(db)
+    qs = [cl.generate_query((389 * i + 1) % o.num_items, 170 + i) for i in range(9)]
+    exp = [o.process_query(pp, q, db) for q in qs]
+    bad = list(qs)
+    bad[4] = qs[4][:-8]
+    with pytest.raises(sp.SpiralError):
+        sp.process_query_batch(p, gpp, bad, gdb)
+    sp.paths_taken()
+    assert sp.process_query_batch(p, gpp, qs, gdb) == exp
+    assert {"expand_group", "sweep_batch_planar"} <= sp.paths_taken()
+    lists = [qs, qs[3:]]
+    want = [exp, exp[3:]]
+    got, errs = [None, None], []
+
+    def work(t):
+        try:
+            for _ in range(3):
+                got[t] = sp.process_query_batch(p, gpp, lists[t], gdb)
+        except Exception as e:  # pragma: no cover
+            errs.append(e)
+    th = [threading.Thread(target=work, args=(t,)) for t in range(2)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert got == want
+
+
 def test_process_query_c1(sp, oracle_mod):
     """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
     idx = 12345
