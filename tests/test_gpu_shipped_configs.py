@@ -205,3 +205,43 @@ def test_e2e_params_real_database(sp, oracle_mod, cfg):
     _assert_decodes_to_item(o, cl.decode_response(resp), blob, idx)
     del gdb, exp
     gc.collect()
+
+
+# --------------------------------------------------------------------------------------------- the same sets, row-sharded
+@pytest.mark.parametrize("cfg,G", [(E2E_V0, 4), (dict(CFG_16_100000, nu_2=3), 8), (E2E_V1, 2)],
+                         ids=["v0-verbatim-G4", "p512-inst11-G8", "v1-verbatim-G2"])
+def test_shipped_configs_row_sharded_loopback(sp, oracle_mod, cfg, G):
+    """The multi-GPU answer path (sp_process_query_sharded: per-plane reduce-scatter, distributed fold, all-gather; G ranks as host
+    threads on this one GPU over the loopback transport) on the reference's shipped parameter sets: e2e v0.json verbatim (n = 4: 16
+    planes, 4 x 4 packing) over 4 ranks, CFG_16_100000 with every gadget and its 44 planes verbatim (nu_1 = 10: 128 rows per rank,
+    p = 512; nu_2 shortened to 3) over 8, e2e v1.json verbatim (packing version 1) over 2.  Rank 0's response == the oracle's
+    process_query on the unsharded real database, a single query and a pipelined list."""
+    from sdk_amd.sharding import LoopbackWorld
+    o = oracle_mod.Params(cfg)
+    cl = oracle_mod.Client(o)
+    pp = cl.generate_keys(1801)
+    idx = o.num_items // 3
+    item, db = o.generate_random_db_and_get_item(idx)
+    qs = [cl.generate_query(idx, 1802), cl.generate_query(o.num_items - 1, 1803), cl.generate_query(0, 1804)]
+    expect = [o.process_query(pp, q, db) for q in qs]
+    p = sp.Params(cfg)
+    gpp = sp.PublicParameters.deserialize(p, pp)
+    shards = [sp.Database(p, s, G).load(db) for s in range(G)]
+    del db
+    gc.collect()
+    world = LoopbackWorld(G)
+
+    def rank_main(r):
+        sp.lib().sp_set_device(0)
+        sp.paths_taken()
+        one = world.comm(r).process_query(p, gpp, qs[0], shards[r])
+        lst = world.comm(r).process_queries(p, gpp, qs, shards[r])
+        return one, lst, sp.paths_taken()
+    res = world.run(rank_main)
+    assert res[0][0] == expect[0]
+    assert res[0][1] == expect
+    for r in range(G):
+        assert {"scatter_out", "custom_transport", "expand_pruned"} <= res[r][2], res[r][2]
+    assert cl.decode_response(res[0][0]) == o.item_to_vec(item)
+    del shards, world
+    gc.collect()
