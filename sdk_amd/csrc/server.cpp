@@ -841,7 +841,8 @@ void run_group_expansion(Workspace* const* Ws, const sp_pp* const* pps, int B, s
   const int* L = D.lists.p;
   if (B < 1 || B > GROUP_MAX) throw ArgError("group size out of range");
   GroupOff g{};
-  auto off = [](const void* q, const void* q0) { return (long long)((const char*)q - (const char*)q0); };
+  // (integer arithmetic on addresses: the buffers are separate allocations, a pointer difference between them is not defined)
+  auto off = [](const void* q, const void* q0) { return (long long)((uintptr_t)q - (uintptr_t)q0); };
   for (int i = 0; i < B; i++) {
     Workspace& W = *Ws[i];
     if (W.P != W0.P || W.D != W0.D) throw ArgError("a group's queries must share params and device");
@@ -1050,7 +1051,8 @@ static void run_group_after_rounds(Workspace* const* Ws, const sp_pp* const* pps
   DeviceState& D = *W0.D;
   hipStream_t s = W0.stream;
   const int* L = D.lists.p;
-  auto off = [](const void* q, const void* q0) { return (long long)((const char*)q - (const char*)q0); };
+  // (integer arithmetic on addresses: the buffers are separate allocations, a pointer difference between them is not defined)
+  auto off = [](const void* q, const void* q0) { return (long long)((uintptr_t)q - (uintptr_t)q0); };
   const int nb = (int)(p.db_dim_2 * p.t_gsw);
   const int four_t = (int)(4 * p.t_gsw);
   const size_t mats_words = p.db_dim_2 * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
@@ -1142,7 +1144,7 @@ void run_begin_group(Workspace* const* Ws, const sp_pp* const* pps, const uint8_
       W.right_pending = false;
     }
     gq.raw[i] = (long long)((size_t)i * 2 * POLY_LEN * sizeof(u64));
-    gq.dig[i] = (long long)((const char*)W.v.p - (const char*)W0.v.p);
+    gq.dig[i] = (long long)((uintptr_t)W.v.p - (uintptr_t)W0.v.p);
   }
   HIP_CHECK(hipMemcpyAsync(W0.group_q_raw.p, W0.h_group_query, (size_t)B * 2 * POLY_LEN * sizeof(u64), hipMemcpyHostToDevice, W0.stream));
   {
