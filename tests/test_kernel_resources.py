@@ -23,9 +23,12 @@ LIMITS = {
     "fold.hip": {"k_fold_waveILi1E": (8, 256), "k_fold_waveILi2E": (8, 256), "k_fold_waveILi4E": (8, 256),
                  # k_fold_fused2 (fallback for gadget widths the wave kernel does not take): 12 bytes since the lazy inverse butterfly
                  # (r05, timed: profiles/r05_call1_ab.md), three dwords outside its transform loops
-                 "k_fold_fusedE": (0, 256), "k_fold_fused2E": (16, 256)},
+                 "k_fold_fusedE": (0, 256), "k_fold_fused2E": (16, 256),
+                 # r06: the grouped expansion's wave-per-digit round (four waves per workgroup: one wave per SIMD, 256 VGPRs each)
+                 "k_expand_waveE": (0, 256)},
     "ntt.hip": {"k_from_sweep4E": (0, 256), "k_ntt_invE": (0, 128), "k_ntt_fwdE": (0, 128), "k_ntt_fwd3E": (0, 128),
-                "k_expand_roundE": (0, 168)},
+                "k_expand_roundE": (0, 168), "k_expand_round_groupE": (0, 168), "k_ntt_inv_groupE": (0, 128),
+                "k_ntt_fwd3_groupE": (0, 128)},
     "sweep.hip": {"k_sweep_packed_ringILi8E": (0, 256), "k_sweep_packed_ringILi4E": (0, 256), "k_sweep_packed_ringILi2E": (0, 256),
                   "k_sweep_packed_persistE": (0, 256), "k_sweep_wideE": (0, 256),
                   # the batched passes on the matrix cores over the PACKED words.  The two-tile form (16 queries, one wave per SIMD,
