@@ -3,7 +3,8 @@
 Random VALID parameter sets (gadget widths, moduli sizes, instances, pack version, item sizes, nu_1 <= 7, nu_2 <= 8), random
 item index and key / query seeds; response bytes of sp_process_query (and, on PACKED shapes, of a list through
 sp_process_query_batch) must equal the oracle's.  Usage:
-    SPIRAL_HIP_LIB=tests/emu/_build/libspiral_emu.so python scripts/emu_fuzz.py [--seed S] [--minutes M] [--streams POLICY]
+    SPIRAL_HIP_LIB=tests/emu/_build/libspiral_emu.so python scripts/emu_fuzz.py [--seed S] [--minutes M]
+    python scripts/emu_fuzz.py --device [--seed S] [--minutes M]      (the same cases against the real library on a GPU box)
 Prints one line per case; a mismatch prints the configuration as JSON (paste it into tests/test_gpu_parity.py::_FUZZ) and exits 1.
 """
 import argparse
@@ -45,10 +46,14 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--minutes", type=float, default=10)
+    ap.add_argument("--device", action="store_true", help="the real library on a real GPU (gfx950) instead of the emulated build")
     a = ap.parse_args()
     import oracle
     import sdk_amd as sp
-    assert hasattr(sp.lib(), "sp_emulated_device_marker"), "set SPIRAL_HIP_LIB to the emulated build"
+    if a.device:
+        assert not hasattr(sp.lib(), "sp_emulated_device_marker"), "--device is for the real library"
+    else:
+        assert hasattr(sp.lib(), "sp_emulated_device_marker"), "set SPIRAL_HIP_LIB to the emulated build"
     rng = np.random.default_rng(a.seed)
     t_end = time.time() + 60 * a.minutes
     n = 0
