@@ -17,7 +17,7 @@ import bench
 import sdk_amd as sp
 
 DEFAULTS = {"batch_planar": 1, "pipeline": 1, "fused_min_pairs": 256, "pipe_tail_defer": 256, "fold_skip_dead_digits": 1, "fold_variant": 5,
-            "batch_in_flight": 3, "expand_split": -1, "sweep_prio": 1, "pipe_ring": 8, "pipe_ring_wgs": 1, "from_sweep_xcd": 1, "sweep_nt_store": 1, "expand_round_min": 2048, "expand_round_odd": 0, "expand_group": 1, "expand_group_round_min": 4096, "expand_group_tail": 1, "batch_tables_merged": 1, "expand_wave_min_digits": 16}
+            "batch_in_flight": 3, "expand_split": -1, "sweep_prio": 1, "pipe_ring": 8, "pipe_ring_wgs": 1, "from_sweep_xcd": 1, "sweep_nt_store": 1, "expand_round_min": 2048, "expand_round_odd": 0, "expand_group": 1, "expand_group_round_min": 4096, "expand_group_tail": 1, "batch_tables_merged": 1, "expand_wave_min_digits": 16, "fold_neg_materialise": 0, "fused_min_pairs_cap": 1 << 62}
 
 
 def single(p, pp, qs, db, steps):

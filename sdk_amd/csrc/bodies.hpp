@@ -293,6 +293,7 @@ __device__ __forceinline__ void mats_to_wave_body(const MatsToWaveDesc& d, size_
   const size_t idx = blk * 256 + threadIdx.x;
   if (idx >= d.n_words) return;
   const size_t poly = idx >> POLY_LEN_LOG2;  // (polynomial, crt) pairs are N words each
+  if (d.half_polys > 0 && (((poly >> 1) / (size_t)d.half_polys) & 1) == 0) return;   // a G - C polynomial: not needed
   const int n = (int)(idx & (N - 1));
   d.dst[poly * N + wave_layout_word(n)] = d.src[idx];
 }

@@ -667,9 +667,9 @@ void launch_expand_wave(const DevTables& T, const ExpandWaveDesc& d, const Group
 
 // fold_mats (NTT polynomials [crt][z]) -> wave layout, same polynomial order: one thread per word
 __global__ __launch_bounds__(256) void k_mats_to_wave(MatsToWaveDesc d) { mats_to_wave_body(d, blockIdx.x); }
-void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s) {
+void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s, int half_polys) {
   if (n_words == 0) return;
-  const MatsToWaveDesc d{dst, src, n_words};
+  const MatsToWaveDesc d{dst, src, n_words, half_polys};
   hipLaunchKernelGGL(k_mats_to_wave, dim3((unsigned)((n_words + 255) / 256)), dim3(256), 0, s, d);
   launched(0, "k_mats_to_wave");
 }
@@ -681,9 +681,9 @@ __global__ __launch_bounds__(256) void k_mats_to_wave_group(MatsToWaveDesc d, Gr
   d.src = group_rebase(d.src, g.v[qi]);
   mats_to_wave_body(d, blockIdx.x);
 }
-void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, const GroupOff& g, int B, hipStream_t s) {
+void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, int half_polys, const GroupOff& g, int B, hipStream_t s) {
   if (n_words == 0 || B <= 0) return;
-  const MatsToWaveDesc d{dst, src, n_words};
+  const MatsToWaveDesc d{dst, src, n_words, half_polys};
   hipLaunchKernelGGL(k_mats_to_wave_group, dim3((unsigned)((n_words + 255) / 256), B), dim3(256), 0, s, d, g);
   launched(PATH_EXPAND_GROUP, "k_mats_to_wave_group");
 }

@@ -224,7 +224,7 @@ void launch_copy_polys_group(u32* dst, const int* dst_idx, int dst_row_stride, c
                              int R, int batch, const GroupOff& g, int B, hipStream_t s);                                            // dst: raw; src: v
 void launch_folding_neg_group(const DevTables& T, u32* mats, const u32* gadget_ntt, int nu2, int two_t, const GroupOff& g, int B,
                               hipStream_t s);                                                                                       // mats: v
-void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, const GroupOff& g, int B, hipStream_t s);                  // dst: raw; src: v
+void launch_mats_to_wave_group(u32* dst, const u32* src, size_t n_words, int half_polys, const GroupOff& g, int B, hipStream_t s);                  // dst: raw; src: v
 // ... and the many-digit (right-hand) side of a large round on the wave-per-transform NTT (fold.hip, k_expand_wave): ciphertexts
 // pos[0 .. cnt) of `raw`, t digits of `bits` bits, expansion key of the round in WAVE layout (A_w: the polynomials of
 // ExpandSideDesc::A through k_mats_to_wave), const_w: the constant polynomials 0 and 1 (N words each)
@@ -263,7 +263,7 @@ struct FoldDesc {
   const u32* mats_w;
 };
 // fold_mats -> wave layout (wave_ntt.hpp wave_layout_word), n_words = polynomials * 2 * N
-void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s);
+void launch_mats_to_wave(u32* dst, const u32* src, size_t n_words, hipStream_t s, int half_polys = 0);
 // SPIRAL_FOLD_VARIANT: 5 = k_fold_wave (wave-per-transform NTT; used while two workgroups fit a CU's LDS, else falls
 // through), 3 = k_fold_fused2 (two cooperative transforms per pass, even t_gsw, twiddles in LDS), 0 = k_fold_fused.
 // profiles/r02_fold_batch_experiments.md has the measurements behind the default.
@@ -341,6 +341,9 @@ struct MatsToWaveDesc {  // launch_mats_to_wave
   u32* dst;
   const u32* src;
   size_t n_words;
+  // > 0: the polynomials are rows of [ G - C | C ] with half_polys polynomials per half; only the C halves are converted
+  // (the query path's fold kernels read nothing else: server.cpp run_fold_operands)
+  int half_polys;
 };
 struct AddPolyIntoDesc {  // launch_add_poly_into
   u32* dst;

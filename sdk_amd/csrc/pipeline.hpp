@@ -31,7 +31,7 @@ struct Workspace {
   DevBuf<u32> exp_dig_r, exp_ct1_r;
   DevBuf<u64> qv;         // reoriented first-dimension query [N][dim0][2]
   DevBuf<u32> fold_mats;  // [nu_2][2 rows][ G - C | C ] (2 x 4 t_gsw NTT polys per GSW ct)
-  DevBuf<u32> fold_mats_w;  // the same polynomials in wave layout (k_fold_wave), filled by run_folding_neg
+  DevBuf<u32> fold_mats_w;  // the same polynomials in wave layout (k_fold_wave), filled by run_fold_operands (query path: the C halves only)
   bool mats_w_ready = false;
   DevBuf<u64> gsw_raw;
   DevBuf<u32> gsw_dig;
@@ -79,7 +79,8 @@ void run_coefficient_expansion(Workspace& W, const sp_pp& pp, size_t g_rounds, c
 void join_right(Workspace& W);
 void run_regev_to_gsw(Workspace& W, const sp_pp& pp, const u32* v_src, const int* src_ct, const int* src_poly);
 void run_folding_neg(Workspace& W);
-void run_mats_to_wave(Workspace& W, size_t levels);
+void run_mats_to_wave(Workspace& W, size_t levels, bool c_only = false);
+void run_fold_operands(Workspace& W);
 void run_begin_direct(Workspace& W, const uint8_t* query);
 // j0 / nj > 0: only the first-dimension rows [j0, j0 + nj) of the expanded query will be used (row shards)
 // B queries of one group (same params, un-pruned): the expansions' rounds as shared launches (kernels.hpp, GroupOff)

@@ -949,14 +949,29 @@ void run_folding_neg(Workspace& W) {
   run_mats_to_wave(W, p.db_dim_2);
 }
 
+// What the QUERY path does in get_v_folding_neg's place (server.rs:505-523, 660): nothing but the wave-layout copy of the C halves.
+// Every fold step of this library is the delta form  ct_i + C (*) (G^-1(ct_{i+half}) - G^-1(ct_i))  -- exactly
+// (G - C) (*) ct_i + C (*) ct_{i+half}  mod q0, q1, because G G^-1(x) = x for the unsigned digit slices -- in the fused kernels
+// (fold.hip: kk = two_t + ...) and in the tree tail (run_fold, delta_tail): G - C is never read.  r01-r05 computed it all the same
+// (k_folding_neg, 9-16 us per query, 73 us per 16-query group) and converted both halves to the wave layout.  The stage export
+// sp_get_v_folding_neg still computes it (run_folding_neg), and sp_fold_ciphertexts takes the caller's.
+// Switch fold_neg_materialise = 1: the old behaviour.
+void run_fold_operands(Workspace& W) {
+  if (tunable("fold_neg_materialise", 0) != 0) {
+    run_folding_neg(W);
+    return;
+  }
+  run_mats_to_wave(W, W.P->db_dim_2, true);
+}
+
 // the fold operands once more in wave layout when the wave-per-transform fold kernel is selected (fold_variant 5)
-void run_mats_to_wave(Workspace& W, size_t levels) {
+void run_mats_to_wave(Workspace& W, size_t levels, bool c_only) {
   const Params& p = *W.P;
   W.mats_w_ready = false;
   if (tunable("fold_variant", FOLD_VARIANT_DEFAULT) != 5 || !fused_fold_supported(p) || levels == 0) return;
   const size_t words = levels * 2 * 4 * p.t_gsw * 2 * POLY_LEN;
   W.fold_mats_w.ensure(words);
-  launch_mats_to_wave(W.fold_mats_w.p, W.fold_mats.p, words, W.stream);
+  launch_mats_to_wave(W.fold_mats_w.p, W.fold_mats.p, words, W.stream, c_only ? (int)(2 * p.t_gsw) : 0);
   W.mats_w_ready = true;
 }
 
@@ -1001,7 +1016,7 @@ void run_begin_direct(Workspace& W, const uint8_t* query) {
       HIP_CHECK(hipMemcpyAsync(W.fold_mats.p + ((d * 2 + r) * 2 * two_t + two_t) * 2 * POLY_LEN,
                                gsw + ((d * 2 + r) * two_t) * 2 * POLY_LEN, two_t * 2 * POLY_LEN * sizeof(u32),
                                hipMemcpyDeviceToDevice, s));
-  run_folding_neg(W);
+  run_fold_operands(W);
   HIP_CHECK(hipStreamSynchronize(s));  // the host staging vectors go out of scope
 }
 
@@ -1037,7 +1052,7 @@ static void run_begin_after_rounds(Workspace& W, const sp_pp& pp) {
   if (p.db_dim_2 > 0) {
     launch_reorient(W.qv.p, W.v.p, 0, 2, (int)p.dim0(), W.stream);  // v_reg_inp[i] = v[2i]   (server.rs:566-568)
     run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-    run_folding_neg(W);
+    run_fold_operands(W);
   } else {
     launch_reorient(W.qv.p, W.v.p, 0, 1, (int)p.dim0(), W.stream);  // server.rs:574-576
   }
@@ -1113,8 +1128,10 @@ static void run_group_after_rounds(Workspace* const* Ws, const sp_pp* const* pps
     MacDesc none_m{};
     launch_mac2_group(D.T, m, none_m, g_mac, B, s);
   }
-  launch_folding_neg_group(D.T, W0.fold_mats.p, D.gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), g_neg, B, s);
-  launch_mats_to_wave_group(W0.fold_mats_w.p, W0.fold_mats.p, mats_words, g_wave, B, s);
+  // (G - C is not needed by the query path: run_fold_operands)
+  const bool neg = tunable("fold_neg_materialise", 0) != 0;
+  if (neg) launch_folding_neg_group(D.T, W0.fold_mats.p, D.gadget_gsw.p, (int)p.db_dim_2, (int)(2 * p.t_gsw), g_neg, B, s);
+  launch_mats_to_wave_group(W0.fold_mats_w.p, W0.fold_mats.p, mats_words, neg ? 0 : (int)(2 * p.t_gsw), g_wave, B, s);
   for (int i = 0; i < B; i++) Ws[i]->mats_w_ready = true;
 }
 
@@ -1212,7 +1229,7 @@ void run_begin(Workspace& W, const sp_pp& pp, const uint8_t* query, size_t query
     on_stream(W, W.stream2, [&] {
       run_coefficient_expansion(W, pp, g, pl, 2, 1);
       run_regev_to_gsw(W, pp, W.v.p, L + D.gsw_src_ct, L + D.gsw_src_poly);
-      run_folding_neg(W);
+      run_fold_operands(W);
     });
     HIP_CHECK(hipEventRecord(W.ev_right, W.stream2));
     W.right_pending = true;
@@ -1379,13 +1396,16 @@ u64* run_fold(Workspace& W, u64* X, u64* Y, int np, int num_cts, int top, int d_
   // levels [d_begin, d_end) of the tree (default: all)
   if (d_end < 0) d_end = further;
   int cur = num_cts >> d_begin;
+  // the workspace's threshold (read when it was created: the digit staging of the unfused levels is sized from it), lowered -- never
+  // raised -- by the run-time switch fused_min_pairs_cap (in-process A/B)
+  const long fused_min = std::min(W.fused_min_pairs, tunable("fused_min_pairs_cap", 1L << 62));
   for (int d = d_begin; d < d_end; d++) {
     const int half = cur / 2;
     // enough independent pairs to fill the chip: one fused workgroup per pair; otherwise (tree tail)
     // the three-kernel form, which parallelises over digits
     if (W.zero_shortcuts && !fused_fold_supported(p))
       throw ArgError("sparse buckets need gadget parameters the fused fold supports (3 <= t_gsw <= 32)");
-    if (W.zero_shortcuts || ((long)np * half >= W.fused_min_pairs && fused_fold_supported(p))) {
+    if (W.zero_shortcuts || ((long)np * half >= fused_min && fused_fold_supported(p))) {
       FoldDesc fd{};
       fd.zero_shortcuts = W.zero_shortcuts ? 1 : 0;
       fd.mats_w = W.mats_w_ready ? W.fold_mats_w.p + (size_t)(top_idx - d) * 2 * 2 * two_t * 2 * POLY_LEN : nullptr;

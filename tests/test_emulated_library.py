@@ -37,7 +37,7 @@ SUBSET = ("test_params_tables_match or test_ntt_forward_inverse or test_to_ntt_f
           # with batched fold tails, the matrix-core batched pass
           "or (test_wave_fold_kernel_gadget_widths and (0 or 4 or 9 or 13)) or (test_ring_sweep_and_batched_tails_parity and 5-10-4-8-1-256)")
 LONG_SUBSET = ("test_wave_fold_kernel_gadget_widths or (test_process_query_batch_matrix_core_sweep and 64x128) or (test_process_query_batch_two_query_tiles and 32x128-B19) "
-               "or (test_planar_copy_lifecycle and 64x128)")
+               "or (test_planar_copy_lifecycle and 64x128) or test_query_path_without_folding_neg")
 RACE_SUBSET = ("test_ntt_forward_inverse or test_to_ntt_from_ntt or test_fold_pack_encode or test_fused_fold_kernel "
                "or (test_process_query_bytes_and_decode and (fast-0 or fast56 or nu2_1)) "
                "or (test_wave_fold_kernel_gadget_widths and (0 or 13))")

@@ -469,6 +469,40 @@ def test_grouped_lists_errors_and_threads(sp, oracle_mod):
     assert got == want
 
 
+@pytest.mark.parametrize("split", ["0", "1"], ids=["one-stream", "split"])
+def test_query_path_without_folding_neg(sp, oracle_mod, monkeypatch, split):
+    """r06: the query path no longer computes G - C (get_v_folding_neg, server.rs:505-523): every fold step is the delta form, which
+    reads C only (server.cpp run_fold_operands).  Same bytes as the oracle -- whose process_query does compute and use it -- with
+    the switch either way, for a single query (split and un-split expansion), a direct-upload query, 56-bit gadget digits and a
+    grouped list; the stage export sp_get_v_folding_neg keeps computing it (test_coefficient_expansion_and_regev_to_gsw)."""
+    import ctypes as C
+    monkeypatch.setenv("SPIRAL_EXPAND_SPLIT", split)
+    cases = [({"n": 2, "nu_1": 6, "nu_2": 7, "p": 256, "q2_bits": 20, "t_gsw": 4, "t_conv": 4, "t_exp_left": 8, "t_exp_right": 56,
+               "instances": 1, "db_item_size": 256}, 4),
+             ({"n": 2, "nu_1": 5, "nu_2": 3, "p": 256, "q2_bits": 20, "t_gsw": 8, "t_conv": 4, "t_exp_left": 8, "t_exp_right": 8,
+               "instances": 2, "db_item_size": 2048, "direct_upload": 1}, 0),
+             ({"n": 2, "nu_1": 4, "nu_2": 4, "p": 256, "q2_bits": 20, "t_gsw": 1, "t_conv": 4, "t_exp_left": 8, "t_exp_right": 8,
+               "instances": 1, "db_item_size": 256}, 0)]     # (56-bit gadget digits: no fused fold, the delta tail on every level)
+    try:
+        for cfg, B in cases:
+            o = oracle_mod.Params(cfg)
+            cl = oracle_mod.Client(o)
+            pp = cl.generate_keys(21)
+            item, db = o.generate_random_db_and_get_item(3)
+            qs = [cl.generate_query((37 * i + 3) % o.num_items, 40 + i) for i in range(max(B, 1))]
+            exp = [o.process_query(pp, q, db) for q in qs]
+            p = sp.Params(cfg)
+            gpp = sp.PublicParameters.deserialize(p, pp)
+            gdb = sp.Database(p).load(db)
+            for materialise in (0, 1, 0):
+                sp.lib().sp_debug_set(b"fold_neg_materialise", C.c_long(materialise))
+                assert sp.process_query(p, gpp, qs[0], gdb) == exp[0], (cfg, materialise)
+                if B:
+                    assert sp.process_query_batch(p, gpp, qs, gdb) == exp, (cfg, materialise)
+    finally:
+        sp.lib().sp_debug_set(b"fold_neg_materialise", C.c_long(0))
+
+
 def test_process_query_c1(sp, oracle_mod):
     """BASELINE.json configs[0]: 2^14 items x 256 B (nu = (9,5)), full DB, bytes-exact."""
     idx = 12345
