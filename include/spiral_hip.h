@@ -170,7 +170,8 @@ int sp_process_query_batch(const sp_params_t*, const sp_pp_t* const* pps, const 
 
 /* Multi-GPU split of process_query around the one exchange step (sum of per-shard partial
  * first-dimension outputs):
- *   begin  : Query::deserialize + expand_query + get_v_folding_neg     (server.rs:664-680)
+ *   begin  : Query::deserialize + expand_query + get_v_folding_neg     (server.rs:664-680; G - C itself is not materialised:
+ *            every fold step of the library is the delta form, which reads C only -- DESIGN.md section 3)
  *   sweep  : multiply_reg_by_database over this shard's rows             (server.rs:698-705)
  *            -> partial residues (u32, < q) at sp_query_partial_ptr(), layout
  *               [plane][r][crt][z][ii], sp_query_partial_words() u32 words; DEVICE memory
@@ -386,8 +387,9 @@ int sp_expand_query(const sp_params_t*, const sp_pp_t*, const uint8_t* query, si
  * entries are scratch in the reference too and are returned unmodified here) */
 int sp_fold_ciphertexts(const sp_params_t*, uint64_t* cts, size_t num_per, const uint64_t* v_folding,
                         const uint64_t* v_folding_neg);
-/* The same fold the way process_query runs it: v_folding_neg is formed on the device as G - v_folding
- * (get_v_folding_neg, server.rs:505-523) and levels with at least `fused_min_pairs` pairs go through the fused
+/* The same fold the way process_query runs it -- every step in the delta form  ct_i + C (*) (G^-1(ct_{i+half}) - G^-1(ct_i)),
+ * which equals (G - C) (*) ct_i + C (*) ct_{i+half} exactly (this export still forms G - C = get_v_folding_neg(v_folding) on the
+ * device, server.rs:505-523; nothing reads it) -- and levels with at least `fused_min_pairs` pairs go through the fused
  * one-workgroup-per-step kernel (0: the library's default threshold, 1: every level fused); the remaining levels use
  * the three-launch tree tail.  Result in cts[0 .. 2N); byte-identical to
  * fold_ciphertexts(cts, v_folding, get_v_folding_neg(v_folding)). */
