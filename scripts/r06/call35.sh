@@ -1,0 +1,11 @@
+#!/bin/bash
+mkdir -p gpurun_out/r06_call35
+python -c "import __graft_entry__ as g; g.build()" > gpurun_out/r06_call35/build.log 2>&1 || { tail -3 gpurun_out/r06_call35/build.log; exit 1; }
+O=gpurun_out/r06_call35
+( time timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -p no:cacheprovider -k test_database_reload_beside_other_processes ) > $O/pytest_reload.log 2>&1; tail -5 $O/pytest_reload.log
+( SPIRAL_DB_STAGE_KEEP=0 timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -p no:cacheprovider -k test_database_reload_beside_other_processes ) > $O/pytest_reload_old_loader.log 2>&1; tail -3 $O/pytest_reload_old_loader.log
+for s in 204 301 302 303 304 305 306 307; do
+  timeout 1000 python scripts/emu_fuzz.py --device --seed $s --minutes 14 > $O/seed_$s.log 2>&1 &
+done
+wait
+grep -h "fuzz:\|FAIL\|MISMATCH\|Traceback" $O/seed_*.log

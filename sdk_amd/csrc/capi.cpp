@@ -394,7 +394,12 @@ int sp_db_load_plane(sp_db_t* d, int plane, int z0, int nz, const uint64_t* word
     const size_t row_words = p.num_per() * p.dim0();
     const size_t max_stage = ((size_t)64 << 20) / 8;  // 64 MiB staging
     const int zs = (int)std::max<size_t>(1, std::min<size_t>((size_t)nz, max_stage / row_words));
-    DevBuf<u64> stage((size_t)zs * row_words);
+    // the upload window: ONE device buffer per handle, kept (db_stage_keep, default 1) -- not one allocation per call
+    // (profiles/r06_stale_staging.md)
+    DevBuf<u64> local;
+    const bool keep = tunable("db_stage_keep", 1) != 0;
+    DevBuf<u64>& stage = keep ? d->load_stage : local;
+    stage.ensure((size_t)zs * row_words);
     for (int z = 0; z < nz; z += zs) {
       const int cnt = std::min(zs, nz - z);
       h2d_sync(stage.p, words + (size_t)z * row_words, (size_t)cnt * row_words * 8);
@@ -544,11 +549,15 @@ int sp_db_update_item(sp_db_t* d, size_t item_idx, const uint8_t* data, size_t l
     while (((u64)1 << logp) < p.pt_modulus) logp++;
     const size_t chunks = p.planes();
     const size_t bpc = (p.db_item_size + chunks - 1) / chunks;
-    DevBuf<uint8_t> win(std::max<size_t>(p.db_item_size, 1));
-    HIP_CHECK(hipMemset(win.p, 0, p.db_item_size));
-    if (len) h2d_sync(win.p, data, len);
+    // the item's bytes on the device: the handle's own staging buffer, reused across updates -- never a fresh allocation per
+    // update (a buffer that is freed and allocated again at the same address between kernels is what one XCD's workgroups can
+    // read the PREVIOUS contents of when several processes share the GPU: profiles/r06_stale_staging.md)
+    d->staging.ensure(std::max<size_t>(p.db_item_size, 1));
+    uint8_t* const win = d->staging.p;
+    HIP_CHECK(hipMemset(win, 0, p.db_item_size));
+    if (len) h2d_sync(win, data, len);
     DbEncodeDesc e{};
-    e.win = win.p;
+    e.win = win;
     e.win_item0 = item_idx;
     e.win_bytes = p.db_item_size;
     e.file_len = (item_idx + 1) * p.db_item_size;  // the record itself is complete (zero padded)

@@ -238,5 +238,6 @@ struct sp_db {
   };
   std::shared_ptr<const SparseIndex> sparse_index;
   spiral::DevBuf<uint8_t> staging;             // one item's bytes (sp_db_update_item), reused
+  spiral::DevBuf<spiral::u64> load_stage;              // sp_db_load_plane's upload window, kept for the handle's life (switch db_stage_keep; capi.cpp)
   std::shared_ptr<const SparseIndex> ensure_sparse_index();  // capi.cpp
 };

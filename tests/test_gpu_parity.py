@@ -7,7 +7,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import C1, FAST, FAST56, P2, SERVER_DEFAULT, SMALL_INST2
+from conftest import C1, FAST, FAST56, P2, ROOT, SERVER_DEFAULT, SMALL_INST2
 
 pytestmark = pytest.mark.gpu
 
@@ -501,6 +501,22 @@ def test_query_path_without_folding_neg(sp, oracle_mod, monkeypatch, split):
                     assert sp.process_query_batch(p, gpp, qs, gdb) == exp, (cfg, materialise)
     finally:
         sp.lib().sp_debug_set(b"fold_neg_materialise", C.c_long(0))
+
+
+def test_database_reload_beside_other_processes(sp):
+    """r06 (profiles/r06_stale_staging.md): with several PROCESSES on one GPU, a device buffer that is freed and allocated again
+    between two kernels can be read by one XCD's workgroups as what its address held before -- sp_db_load_plane used to allocate
+    its staging buffer per plane, and about one load in 500 then came out with one XCD's share of one plane wrong (found by the
+    GPU fuzz: a wrong response from a handle whose database differed from what had been loaded).  The loaders keep one staging
+    buffer per handle now.  Six processes reload a database 200 times each and check a query after every load (the old loader
+    fails this two times out of three)."""
+    import subprocess
+    import sys
+    worker = os.path.join(ROOT, "tests", "_gpu_reload_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, "200"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for _ in range(6)]
+    outs = [pr.communicate(timeout=900)[0] for pr in procs]
+    assert all(pr.returncode == 0 for pr in procs), "\n".join(o[-600:] for o in outs)
 
 
 def test_process_query_c1(sp, oracle_mod):
