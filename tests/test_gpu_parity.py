@@ -508,13 +508,13 @@ def test_database_reload_beside_other_processes(sp):
     between two kernels can be read by one XCD's workgroups as what its address held before -- sp_db_load_plane used to allocate
     its staging buffer per plane, and about one load in 500 then came out with one XCD's share of one plane wrong (found by the
     GPU fuzz: a wrong response from a handle whose database differed from what had been loaded).  The loaders keep one staging
-    buffer per handle now.  Six processes reload a database 200 times each and check a query after every load (the old loader
-    fails this two times out of three)."""
+    buffer per handle now.  Eight processes reload a database 1000 times each and check a query after every load (with the old
+    loader, SPIRAL_DB_STAGE_KEEP=0, about ten of these 8000 loads go wrong)."""
     import subprocess
     import sys
     worker = os.path.join(ROOT, "tests", "_gpu_reload_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, "200"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-             for _ in range(6)]
+    procs = [subprocess.Popen([sys.executable, worker, "1000"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for _ in range(8)]
     outs = [pr.communicate(timeout=900)[0] for pr in procs]
     assert all(pr.returncode == 0 for pr in procs), "\n".join(o[-600:] for o in outs)
 
