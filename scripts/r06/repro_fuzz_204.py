@@ -20,6 +20,7 @@ qmode = len(sys.argv) > 3 and sys.argv[3] == "queries"      # same handles, a DI
 same = same or qmode
 reload = len(sys.argv) > 3 and sys.argv[3] == "reload"        # same handles; the SAME database handle is loaded again every repetition
 same = same or reload
+pponly = len(sys.argv) > 3 and sys.argv[3] == "pponly"        # fresh PUBLIC PARAMETERS every repetition, everything else kept
 dbonly = len(sys.argv) > 3 and sys.argv[3] == "dbonly"      # fresh DATABASE handle per repetition, everything else kept
 o = oracle.Params(cfg)
 cl = oracle.Client(o)
@@ -34,7 +35,10 @@ sp.lib().sp_debug_set(b"fold_neg_materialise", C.c_long(mat))
 bad = 0
 h = None
 for r in range(reps):
-    if h is not None and dbonly:
+    if h is not None and pponly:
+        h = (h[0], None, h[2])
+        h = (h[0], sp.PublicParameters.deserialize(h[0], pp), h[2])
+    elif h is not None and dbonly:
         h = (h[0], h[1], None)
         h = (h[0], h[1], sp.Database(h[0]).load(db))
     elif h is None or not same:
@@ -63,7 +67,7 @@ for r in range(reps):
         print("   same handles again: %s" % ("equal" if again == want else "differs (%s)" % ("same bytes" if again == got else "other bytes")), flush=True)
         # which handle holds wrong data?  the database read back in the reference layout against what was loaded; the public
         # parameters exported against a fresh deserialisation's export
-        if (dbonly or reload) and bad > 3:
+        if (dbonly or reload or pponly) and bad > 3:
             continue
         dbh = np.asarray(db, dtype=np.uint64).reshape(o.get("instances") * 4, 2048, 8, 64)
         wrong = []
