@@ -110,7 +110,9 @@ void sp_db_free(sp_db_t*);
 /* Upload (a z-range of) one (instance,trial) plane given in the reference layout [z][ii][j] with
  * the FULL dim0 rows per (z,ii); the shard keeps only its rows.  `words` points at row z0.
  * Equivalent of handing generate_random_db_and_get_item / load_db_from_seek /
- * load_preprocessed_db_from_file output (server.rs:223-275, 320-386) to process_query. */
+ * load_preprocessed_db_from_file output (server.rs:223-275, 320-386) to process_query.
+ * The handle keeps its device-side upload window (at most 64 MiB, not counted by sp_db_device_bytes) from the first call on:
+ * nothing is allocated or freed between the kernels of a load (allocation rule). */
 int sp_db_load_plane(sp_db_t*, int plane, int z0, int nz, const uint64_t* words);
 /* Whole database in one call: `words` = instances*n*n*N*num_per*dim0 u64 in the reference layout. */
 int sp_db_load(sp_db_t*, const uint64_t* words, size_t n_words);
